@@ -1,0 +1,194 @@
+/* slamx.h -- C ABI of the MI355X-native frontend hot path of daviyan5/SLAM-CIN0051.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer:
+ * its seam is the public C++ class API of the headers under include/slam/frontend.  Each
+ * entry point below names the reference interface it replaces (file:line,
+ * relative to the reference root); include/slam/... in this repo is the C++17
+ * facade with the reference's own class names built on top of these calls, and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns an int status (SLAMX_OK == 0); the facade maps
+ *     SLAMX_ERR_INVALID_ARGUMENT -> std::invalid_argument and every other
+ *     failure -> std::runtime_error, matching the reference's exception types
+ *     (feature_detector.hpp:55-93, feature_matcher.cpp:97-111);
+ *   - slamx_last_error() returns a thread-local message for the last failure;
+ *   - all compute runs on the GPU.  There is no CPU fallback: with no usable HIP
+ *     device slamx_ctx_create fails with SLAMX_ERR_NO_DEVICE;
+ *   - handles are not thread-safe; distinct contexts are independent.
+ */
+#ifndef SLAMX_H
+#define SLAMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMX_OK 0
+#define SLAMX_ERR_INVALID_ARGUMENT 1 /* std::invalid_argument in the reference  */
+#define SLAMX_ERR_RUNTIME 2          /* std::runtime_error in the reference      */
+#define SLAMX_ERR_HIP 3              /* a HIP runtime call failed                */
+#define SLAMX_ERR_CAPACITY 4         /* an output or workspace capacity exceeded */
+#define SLAMX_ERR_NO_DEVICE 5        /* no usable gfx950 device                  */
+
+/* slam::Keypoint, include/slam/frontend/feature_detector.hpp:28-38 (5 floats, 20 B). */
+typedef struct slamx_keypoint {
+    float x, y, size, angle, response;
+} slamx_keypoint;
+
+/* slam::Match, include/slam/frontend/feature_matcher.hpp:18-25 (12 B). */
+typedef struct slamx_match {
+    int32_t queryIdx, trainIdx;
+    float distance;
+} slamx_match;
+
+/* The six YAML keys slam::FeatureDetector reads, feature_detector.hpp:60-93. */
+typedef struct slamx_detector_config {
+    int32_t intensity_threshold;         /* IntensityThreshold        [0,255]       */
+    int32_t contiguous_pixels_threshold; /* ContiguousPixelsThreshold [0,16]        */
+    int32_t non_max_suppression;         /* NonMaxSuppression         0|1           */
+    int32_t suppression_window_size;     /* SuppressionWindowSize     > 0           */
+    int32_t patch_size;                  /* PatchSize                 odd, > 0      */
+    int32_t num_brief_pairs;             /* NumBRIEFPairs             multiple of 8 */
+} slamx_detector_config;
+
+/* The five YAML keys slam::FeatureMatcher reads, feature_matcher.cpp:25-57. */
+typedef struct slamx_matcher_config {
+    int32_t distance_type; /* 0 = HAMMING, 1 = L2 (L2 is accepted at construction and
+                              refused by match(), as in feature_matcher.cpp:83-87)    */
+    int32_t filter_matches;
+    int32_t good_matches_count;
+    int32_t use_ratio_test;
+    float ratio_test_threshold;
+} slamx_matcher_config;
+
+/* Capacities of a device-resident frame batch (all per frame except max_frames). */
+typedef struct slamx_batch_shape {
+    int32_t rows, cols;
+    int32_t max_frames;
+    int32_t max_candidates; /* raw FAST corners per frame (0 = rows*cols/16)        */
+    int32_t max_keypoints;  /* keypoints kept per frame   (0 = max_candidates)      */
+} slamx_batch_shape;
+
+typedef struct slamx_ctx slamx_ctx;
+typedef struct slamx_detector slamx_detector;
+typedef struct slamx_matcher slamx_matcher;
+typedef struct slamx_batch slamx_batch;
+
+const char* slamx_last_error(void);
+const char* slamx_version(void);
+
+/* ---- context: one per GPU; owns (or borrows) the HIP stream all work is enqueued on. ---- */
+/* hip_stream == NULL: the context creates its own non-blocking stream. */
+int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out);
+void slamx_ctx_destroy(slamx_ctx* ctx);
+int slamx_ctx_synchronize(slamx_ctx* ctx);
+void* slamx_ctx_stream(slamx_ctx* ctx);
+int slamx_ctx_device_name(slamx_ctx* ctx, char* buf, int cap);
+/* hipEvent pair on the context's stream (bench.py times kernels on THIS stream). */
+int slamx_ctx_timer_start(slamx_ctx* ctx);
+int slamx_ctx_timer_stop_ms(slamx_ctx* ctx, float* ms); /* synchronizes */
+
+/* ---- configuration files (the OpenCV FileStorage YAML-1.0 subset the reference uses) ---- */
+/* replaces the cv::FileStorage reads of feature_detector.hpp:54-94 */
+int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out);
+/* replaces feature_matcher.cpp:18-59 */
+int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out);
+
+/* ---- slam::FeatureDetector ---- */
+/* FeatureDetector::FeatureDetector, feature_detector.hpp:53-107 (validation + pattern). */
+int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slamx_detector** out);
+void slamx_detector_destroy(slamx_detector* det);
+/* generateBRIEFPattern, feature_detector.cpp:286-313: xy4 receives {x1,y1,x2,y2} per pair. */
+int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pairs, int* n_pairs);
+int slamx_detector_descriptor_width(const slamx_detector* det); /* NumBRIEFPairs / 8 */
+
+/* FeatureDetector::detect, feature_detector.cpp:8-18.  img: row-major uint8, host memory.
+ * Writes up to cap keypoints; *n is the true count (SLAMX_ERR_CAPACITY if *n > cap). */
+int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                 slamx_keypoint* kps, int cap, int* n);
+/* FeatureDetector::compute, feature_detector.cpp:20-47.  kps[i].angle is overwritten;
+ * desc is n x descriptor_width, row-major, host memory.  n == 0 is a no-op. */
+int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                  slamx_keypoint* kps, int n, uint8_t* desc);
+/* FeatureDetector::detectAndCompute, feature_detector.cpp:49-54. */
+int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                             slamx_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* Intermediate products, exposed for the parity tests (same kernels as above):
+ * raster-ordered FAST candidates with their scores (detectFASTKeypoints + computeFASTScore,
+ * feature_detector.cpp:56-68, 190-203) and the blurred image (gaussianBlur, :315-364). */
+int slamx_fast_candidates(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                          slamx_keypoint* kps, int cap, int* n);
+int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                        uint8_t* out /* rows*cols dense */);
+/* The std::sort call of applyNonMaxSuppression (feature_detector.cpp:160-161) on its own:
+ * sorts n scores (each an integer 0..4095) descending exactly as libstdc++'s introsort
+ * permutes them; perm_out[r] = input index that lands at sorted position r. */
+int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out);
+/* The glibc libm calls of computeOrientation / computeBRIEFDescriptor
+ * (feature_detector.cpp:229, 247-249) as evaluated on the device. */
+int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, float* angle_deg, float* cos_out,
+                     float* sin_out);
+
+/* ---- slam::FeatureMatcher ---- */
+/* FeatureMatcher::FeatureMatcher, feature_matcher.cpp:18-69. */
+int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out);
+void slamx_matcher_destroy(slamx_matcher* m);
+/* FeatureMatcher::match, feature_matcher.cpp:71-95.  d1: n1 x width1, d2: n2 x width2, host
+ * memory.  kp1/kp2 may be NULL with nkp == 0 (the "{}" defaults): the jump-radius penalty is
+ * applied only when both are non-empty (:150).  Errors: n1 == 0 or n2 == 0 ->
+ * SLAMX_ERR_INVALID_ARGUMENT; width mismatch or L2 -> SLAMX_ERR_RUNTIME. */
+int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1, const uint8_t* d2, int n2, int width2,
+                const slamx_keypoint* kp1, int nkp1, const slamx_keypoint* kp2, int nkp2, slamx_match* out, int cap,
+                int* n);
+
+/* ---- device-resident batches: frames stay in HBM, nothing returns to the host until asked ---- */
+int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slamx_batch** out);
+void slamx_batch_destroy(slamx_batch* b);
+/* Device pointer of frame 0; frame f row r starts at base + f*frame_stride + r*pitch. */
+uint8_t* slamx_batch_frames(slamx_batch* b, size_t* pitch, size_t* frame_stride);
+/* Host -> HBM copy of n frames (row-major, given stride) into slots first..first+n-1 (async). */
+int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                       ptrdiff_t frame_stride);
+/* detectAndCompute on frames 0..nframes-1 (async on the context stream). */
+int slamx_batch_detect_and_compute(slamx_batch* b, int nframes);
+/* match(desc[k], desc[k-1], kps[k], kps[k-1]) for k = 1..nframes-1 (frame 0 has no previous
+ * frame); use_keypoints selects the jump-radius penalty.  Results stay on the device in
+ * query order, before filterAndSortMatches (async). */
+int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints);
+/* Synchronize and copy out.  A frame whose candidate/keypoint count exceeded the shape's
+ * capacity makes these return SLAMX_ERR_CAPACITY. */
+int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches);
+int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* Matches of frame k against frame k-1, with the matcher's filter step applied on request. */
+int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
+                                 int cap, int* n);
+/* Per-stage device time of the last batch call, from hipEvents recorded on the stream
+ * (requires slamx_batch_set_profiling(b, 1); adds events, no synchronization). */
+#define SLAMX_STAGE_FAST 0
+#define SLAMX_STAGE_SCAN 1
+#define SLAMX_STAGE_EXPAND 2
+#define SLAMX_STAGE_SORT 3
+#define SLAMX_STAGE_NMS 4
+#define SLAMX_STAGE_BLUR 5
+#define SLAMX_STAGE_DESCRIBE 6
+#define SLAMX_STAGE_MATCH 7
+#define SLAMX_STAGE_COUNT 8
+int slamx_batch_set_profiling(slamx_batch* b, int enable);
+int slamx_batch_stage_ms(slamx_batch* b, float* ms /* SLAMX_STAGE_COUNT entries */);
+
+/* ---- deterministic synthetic frames, host side, for tests and bench ---- */
+/* Frame k of the sequence with the given seed: background 96, n_rect filled rectangles with
+ * sides in [rect_min, rect_max], per-pixel noise in [-4,4], translated by (2k mod 64, k mod 32). */
+int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max,
+                      uint8_t* out /* rows*cols dense */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMX_H */

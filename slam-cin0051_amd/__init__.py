@@ -1,0 +1,468 @@
+"""slam-cin0051_amd -- ctypes binding of libslamx.so, the MI355X-native frontend hot path.
+
+Host-side mirror of the reference's operator interface for this path, in Python for the tests
+and bench.py (the C++17 facade with the reference's class names lives in include/slam/):
+
+    FeatureDetector(config).detect / compute / detectAndCompute
+        <- slam::FeatureDetector, include/slam/frontend/feature_detector.hpp:47-192
+    FeatureMatcher(config).match
+        <- slam::FeatureMatcher, include/slam/frontend/feature_matcher.hpp:37-88
+
+Errors follow the reference's exception types: std::invalid_argument -> ValueError,
+std::runtime_error -> RuntimeError.  Everything computes on the GPU through the C ABI
+(include/slamx.h); if libslamx.so is missing or no HIP device is usable the import / the
+Context constructor raise -- there is no CPU fallback.
+
+The directory name contains a hyphen, so load it with importlib (see __graft_entry__.py /
+tests/conftest.py) under the module name ``slam_cin0051_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslamx.so")
+
+OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE = range(6)
+STAGES = ("fast", "scan", "expand", "sort", "nms", "blur", "describe", "match")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4")], align=False
+)
+MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("distance", "<f4")], align=False)
+assert KEYPOINT_DTYPE.itemsize == 20 and MATCH_DTYPE.itemsize == 12
+
+
+class DetectorConfig(C.Structure):
+    _fields_ = [
+        ("intensity_threshold", C.c_int32),
+        ("contiguous_pixels_threshold", C.c_int32),
+        ("non_max_suppression", C.c_int32),
+        ("suppression_window_size", C.c_int32),
+        ("patch_size", C.c_int32),
+        ("num_brief_pairs", C.c_int32),
+    ]
+
+    def __repr__(self):
+        return "DetectorConfig(%s)" % ", ".join("%s=%d" % (f, getattr(self, f)) for f, _ in self._fields_)
+
+
+class MatcherConfig(C.Structure):
+    _fields_ = [
+        ("distance_type", C.c_int32),
+        ("filter_matches", C.c_int32),
+        ("good_matches_count", C.c_int32),
+        ("use_ratio_test", C.c_int32),
+        ("ratio_test_threshold", C.c_float),
+    ]
+
+
+class BatchShape(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("max_frames", C.c_int32),
+        ("max_candidates", C.c_int32),
+        ("max_keypoints", C.c_int32),
+    ]
+
+
+# every symbol include/slamx.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "slamx_last_error", "slamx_version", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
+    "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
+    "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_detector_create", "slamx_detector_destroy",
+    "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
+    "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
+    "slamx_debug_trig", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
+    "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
+    "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
+    "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libslamx.so (built by `make -C slam-cin0051_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libslamx.so is not built (%s): run `make -C slam-cin0051_amd` or __graft_entry__.build(). "
+            "The slamx hot path has no CPU fallback." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.slamx_last_error.restype = C.c_char_p
+    lib.slamx_version.restype = C.c_char_p
+    lib.slamx_ctx_stream.restype = C.c_void_p
+    lib.slamx_batch_frames.restype = C.c_void_p
+    vp = C.c_void_p
+    lib.slamx_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.slamx_ctx_destroy.argtypes = [vp]
+    lib.slamx_ctx_synchronize.argtypes = [vp]
+    lib.slamx_ctx_stream.argtypes = [vp]
+    lib.slamx_ctx_device_name.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.slamx_ctx_timer_start.argtypes = [vp]
+    lib.slamx_ctx_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.slamx_detector_config_load.argtypes = [C.c_char_p, C.POINTER(DetectorConfig)]
+    lib.slamx_matcher_config_load.argtypes = [C.c_char_p, C.POINTER(MatcherConfig)]
+    lib.slamx_detector_create.argtypes = [vp, C.POINTER(DetectorConfig), C.POINTER(vp)]
+    lib.slamx_detector_destroy.argtypes = [vp]
+    lib.slamx_detector_pattern.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_detector_descriptor_width.argtypes = [vp]
+    img = [vp, vp, C.c_int, C.c_int, C.c_ssize_t]
+    lib.slamx_detect.argtypes = img + [vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_compute.argtypes = img + [vp, C.c_int, vp]
+    lib.slamx_detect_and_compute.argtypes = img + [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_fast_candidates.argtypes = img + [vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_gaussian_blur.argtypes = img + [vp]
+    lib.slamx_debug_sort_desc.argtypes = [vp, vp, C.c_int, vp]
+    lib.slamx_debug_trig.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+    lib.slamx_matcher_create.argtypes = [vp, C.POINTER(MatcherConfig), C.POINTER(vp)]
+    lib.slamx_matcher_destroy.argtypes = [vp]
+    lib.slamx_matcher_match.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp,
+                                        C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_batch_create.argtypes = [vp, C.POINTER(BatchShape), C.POINTER(vp)]
+    lib.slamx_batch_destroy.argtypes = [vp]
+    lib.slamx_batch_frames.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.slamx_batch_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
+    lib.slamx_batch_detect_and_compute.argtypes = [vp, C.c_int]
+    lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.slamx_batch_counts.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.slamx_batch_download.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
+    lib.slamx_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.slamx_synth_frame.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    _lib = lib
+    return lib
+
+
+class CapacityError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    msg = load_library().slamx_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)  # std::invalid_argument
+    if rc == ERR_CAPACITY:
+        raise CapacityError(msg)
+    raise RuntimeError("slamx error %d: %s" % (rc, msg))  # std::runtime_error
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _as_image(image):
+    img = np.asarray(image)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise ValueError("image must be a 2-D uint8 array (EigenGrayMatrix)")
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+def synth_frame(seed, k, rows, cols, n_rect, rect_min=16, rect_max=64):
+    """Deterministic synthetic frame k; host-side generator inside libslamx."""
+    out = np.empty((rows, cols), np.uint8)
+    _check(load_library().slamx_synth_frame(seed, k, rows, cols, n_rect, rect_min, rect_max, _ptr(out)))
+    return out
+
+
+def load_detector_config(path):
+    cfg = DetectorConfig()
+    _check(load_library().slamx_detector_config_load(os.fsencode(path), C.byref(cfg)))
+    return cfg
+
+
+def load_matcher_config(path):
+    cfg = MatcherConfig()
+    _check(load_library().slamx_matcher_config_load(os.fsencode(path), C.byref(cfg)))
+    return cfg
+
+
+class Context:
+    """One per GPU: owns the HIP stream every call is enqueued on."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_ctx_create(device, stream, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.slamx_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.lib.slamx_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.slamx_ctx_stream(self.h)
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _check(self.lib.slamx_ctx_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def timer_start(self):
+        _check(self.lib.slamx_ctx_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        _check(self.lib.slamx_ctx_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def debug_sort_desc(self, scores):
+        s = np.ascontiguousarray(scores, dtype=np.uint32)
+        perm = np.empty(s.shape[0], np.uint32)
+        _check(self.lib.slamx_debug_sort_desc(self.h, _ptr(s), s.shape[0], _ptr(perm)))
+        return perm
+
+    def debug_trig(self, m01, m10):
+        a = np.ascontiguousarray(m01, dtype=np.float32)
+        b = np.ascontiguousarray(m10, dtype=np.float32)
+        deg, c, s = (np.empty_like(a) for _ in range(3))
+        _check(self.lib.slamx_debug_trig(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(deg), _ptr(c), _ptr(s)))
+        return deg, c, s
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class FeatureDetector:
+    """slam::FeatureDetector (feature_detector.hpp:47-192).  config: YAML path or DetectorConfig."""
+
+    def __init__(self, config, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.cfg = config if isinstance(config, DetectorConfig) else load_detector_config(config)
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_detector_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
+        self.width = self.lib.slamx_detector_descriptor_width(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.slamx_detector_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pattern(self):
+        n = C.c_int()
+        _check(self.lib.slamx_detector_pattern(self.h, None, 0, C.byref(n)))
+        xy = np.empty((n.value, 4), np.int32)
+        _check(self.lib.slamx_detector_pattern(self.h, _ptr(xy), n.value, C.byref(n)))
+        return xy
+
+    def _sized(self, fn, img, *extra_out):
+        cap = max(1024, img.shape[0] * img.shape[1] // 16)
+        while True:
+            kps = np.empty(cap, KEYPOINT_DTYPE)
+            n = C.c_int()
+            try:
+                rc = fn(kps, cap, n)
+                _check(rc)
+                return kps, n.value
+            except CapacityError:
+                if n.value <= cap:
+                    raise
+                cap = n.value
+
+    def detect(self, image):
+        img = _as_image(image)
+
+        def call(kps, cap, n):
+            return self.lib.slamx_detect(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(kps), cap,
+                                         C.byref(n))
+
+        kps, n = self._sized(call, img)
+        return kps[:n].copy()
+
+    def compute(self, image, keypoints):
+        img = _as_image(image)
+        kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE).copy()
+        n = kps.shape[0]
+        if n == 0:
+            return kps, np.zeros((0, 0), np.uint8)  # DescriptorMatrix(0, 0), feature_detector.cpp:22-25
+        desc = np.empty((n, self.width), np.uint8)
+        _check(self.lib.slamx_compute(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(kps), n,
+                                      _ptr(desc)))
+        return kps, desc
+
+    def detectAndCompute(self, image):
+        img = _as_image(image)
+        cap = max(1024, img.shape[0] * img.shape[1] // 16)
+        while True:
+            kps = np.empty(cap, KEYPOINT_DTYPE)
+            desc = np.empty((cap, self.width), np.uint8)
+            n = C.c_int()
+            try:
+                _check(self.lib.slamx_detect_and_compute(self.h, _ptr(img), img.shape[0], img.shape[1],
+                                                         img.strides[0], _ptr(kps), _ptr(desc), cap, C.byref(n)))
+                break
+            except CapacityError:
+                if n.value <= cap:
+                    raise
+                cap = n.value
+        if n.value == 0:
+            return kps[:0].copy(), np.zeros((0, 0), np.uint8)
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    # intermediate products for the parity tests
+    def fast_candidates(self, image):
+        img = _as_image(image)
+
+        def call(kps, cap, n):
+            return self.lib.slamx_fast_candidates(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0],
+                                                  _ptr(kps), cap, C.byref(n))
+
+        kps, n = self._sized(call, img)
+        return kps[:n].copy()
+
+    def gaussian_blur(self, image):
+        img = _as_image(image)
+        out = np.empty(img.shape, np.uint8)
+        _check(self.lib.slamx_gaussian_blur(self.h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(out)))
+        return out
+
+
+class FeatureMatcher:
+    """slam::FeatureMatcher (feature_matcher.hpp:37-88).  config: YAML path or MatcherConfig."""
+
+    def __init__(self, config, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.cfg = config if isinstance(config, MatcherConfig) else load_matcher_config(config)
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_matcher_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.slamx_matcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match(self, descriptors1, descriptors2, keypoints1=None, keypoints2=None):
+        d1 = np.ascontiguousarray(descriptors1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(descriptors2, dtype=np.uint8)
+        n1 = d1.shape[0] if d1.ndim == 2 else 0
+        n2 = d2.shape[0] if d2.ndim == 2 else 0
+        w1 = d1.shape[1] if d1.ndim == 2 else 0
+        w2 = d2.shape[1] if d2.ndim == 2 else 0
+        k1 = np.ascontiguousarray(keypoints1, dtype=KEYPOINT_DTYPE) if keypoints1 is not None else None
+        k2 = np.ascontiguousarray(keypoints2, dtype=KEYPOINT_DTYPE) if keypoints2 is not None else None
+        out = np.empty(max(n1, 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(self.lib.slamx_matcher_match(self.h, _ptr(d1), n1, w1, _ptr(d2), n2, w2, _ptr(k1),
+                                            0 if k1 is None else k1.shape[0], _ptr(k2),
+                                            0 if k2 is None else k2.shape[0], _ptr(out), out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+
+class Batch:
+    """Device-resident frame batch: frames stay in HBM between the stages."""
+
+    def __init__(self, detector, rows, cols, max_frames, max_candidates=0, max_keypoints=0):
+        self.det = detector
+        self.lib = detector.lib
+        self.shape = BatchShape(rows, cols, max_frames, max_candidates, max_keypoints)
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_batch_create(detector.h, C.byref(self.shape), C.byref(self.h)))
+        self.rows, self.cols, self.max_frames = rows, cols, max_frames
+
+    def close(self):
+        if self.h:
+            self.lib.slamx_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def frames_device(self):
+        pitch, fstride = C.c_size_t(), C.c_size_t()
+        p = self.lib.slamx_batch_frames(self.h, C.byref(pitch), C.byref(fstride))
+        return p, pitch.value, fstride.value
+
+    def upload(self, frames, first=0):
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        if f.ndim == 2:
+            f = f[None]
+        _check(self.lib.slamx_batch_upload(self.h, first, f.shape[0], _ptr(f), f.strides[1], f.strides[0]))
+
+    def detect_and_compute(self, nframes):
+        _check(self.lib.slamx_batch_detect_and_compute(self.h, nframes))
+
+    def match_consecutive(self, matcher, nframes, use_keypoints=True):
+        _check(self.lib.slamx_batch_match_consecutive(self.h, matcher.h, nframes, 1 if use_keypoints else 0))
+
+    def counts(self, nframes):
+        a, b, c = (np.zeros(nframes, np.int32) for _ in range(3))
+        _check(self.lib.slamx_batch_counts(self.h, nframes, _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def download(self, frame):
+        n = C.c_int()
+        try:
+            _check(self.lib.slamx_batch_download(self.h, frame, None, None, 0, C.byref(n)))
+        except CapacityError:
+            if n.value == 0:
+                raise
+        kps = np.empty(n.value, KEYPOINT_DTYPE)
+        desc = np.empty((n.value, self.det.width), np.uint8)
+        _check(self.lib.slamx_batch_download(self.h, frame, _ptr(kps), _ptr(desc), n.value, C.byref(n)))
+        return kps, desc
+
+    def download_matches(self, matcher, frame, apply_filter=False):
+        n = C.c_int()
+        try:
+            _check(self.lib.slamx_batch_download_matches(self.h, matcher.h, frame, 1 if apply_filter else 0, None, 0,
+                                                         C.byref(n)))
+        except CapacityError:
+            pass
+        out = np.empty(max(n.value, 1), MATCH_DTYPE)
+        _check(self.lib.slamx_batch_download_matches(self.h, matcher.h, frame, 1 if apply_filter else 0, _ptr(out),
+                                                     out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+    def set_profiling(self, enable=True):
+        _check(self.lib.slamx_batch_set_profiling(self.h, 1 if enable else 0))
+
+    def stage_ms(self):
+        ms = (C.c_float * len(STAGES))()
+        _check(self.lib.slamx_batch_stage_ms(self.h, ms))
+        return dict(zip(STAGES, [float(x) for x in ms]))

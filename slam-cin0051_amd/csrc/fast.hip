@@ -1,0 +1,232 @@
+// fast.hip -- FAST-N segment test, raster-order compaction and corner score.
+//
+// Reference behaviour (paths relative to the reference root):
+//   detectFASTKeypoints   src/frontend/feature_detector.cpp:56-68   raster scan, border 3
+//   isFASTCorner          src/frontend/feature_detector.cpp:70-145  two pretests + 32-step walk
+//   computeFASTScore      src/frontend/feature_detector.cpp:190-203 sum of 16 |I_k - I_c|
+//   M_PIXEL_OFFSETS       include/slam/frontend/feature_detector.hpp:138-153
+//
+// MI355X design: integer-only, one image read.
+//   K1  fast_detect : one workgroup = 64 x 16 pixel tile, staged through LDS with a 3-px halo as
+//                     aligned dword loads; a wave owns a 64-pixel row segment, so the corner
+//                     predicate of a row segment is ONE 64-bit ballot = one word of a corner
+//                     bitmap.  The bitmap (W*H/8 bytes) is the only thing written.
+//   K1b scan        : per frame, exclusive prefix sum of the bitmap popcounts in raster order
+//                     (row-major, word-major) -> the raster index of every corner is
+//                     wordoff[word] + popcount(bits below it).  This bitmap+prefix pair is also
+//                     the spatial index the NMS kernel uses, so no cell grid is ever built.
+//   K1c expand      : one wave per non-empty word; lanes = set bits; writes (x,y) and the
+//                     sort key score<<20|rasterIndex in raster order.
+#include "slamx_internal.h"
+
+namespace slamx {
+
+namespace {
+
+// circle offsets {dx,dy}, clockwise from 12 o'clock (feature_detector.hpp:138-153)
+__device__ __constant__ int8_t CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__device__ __constant__ int8_t CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 16;
+constexpr int HALO = 3;
+constexpr int LDS_ROW_DW = 18;             // 72 bytes: columns [64wx-4, 64wx+68)
+constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 22
+
+// The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels.
+__device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
+    // pretest A (feature_detector.cpp:81-96): pixels 0 and 8
+    if (((B | D) & 0x0101u) == 0) {
+        return false;
+    }
+    // pretest B (:98-113): pixels 0,4,8,12 -- applied for every arc length, as the reference does
+    if (__popc(B & 0x1111u) < 3 && __popc(D & 0x1111u) < 3) {
+        return false;
+    }
+    // 32-step circular walk (:118-142): true iff the doubled sequence has a run >= arc.
+    if (arc <= 0) {
+        return true;  // "0 >= 0" fires on the first step
+    }
+    uint32_t mb = B | (B << 16);
+    uint32_t md = D | (D << 16);
+    uint32_t rb = mb;
+    uint32_t rd = md;
+    for (int s = 1; s < arc; ++s) {
+        rb &= mb >> s;
+        rd &= md >> s;
+    }
+    return (rb | rd) != 0;
+}
+
+__global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc) {
+    __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
+    const int wx = blockIdx.x;
+    const int ty = blockIdx.y;
+    const int f = blockIdx.z;
+    const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
+    const int x0 = wx * TILE_W - 4;
+    const int y0 = ty * TILE_H - HALO;
+    for (int i = threadIdx.x; i < LDS_ROWS * LDS_ROW_DW; i += 256) {
+        const int r = i / LDS_ROW_DW;
+        const int c = i - r * LDS_ROW_DW;
+        const int yy = y0 + r;
+        const int xx = x0 + c * 4;
+        uint32_t val = 0;
+        if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
+            val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+        }
+        tile[i] = val;
+    }
+    __syncthreads();
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = wx * TILE_W + lane;
+    unsigned long long* masks = v.masks + static_cast<size_t>(f) * v.rows * v.nw;
+#pragma unroll
+    for (int k = 0; k < TILE_H / 4; ++k) {
+        const int ry = wave * (TILE_H / 4) + k;
+        const int y = ty * TILE_H + ry;
+        if (y >= v.rows) {
+            break;  // wave-uniform
+        }
+        bool corner = false;
+        if (x >= HALO && x < v.cols - HALO && y >= HALO && y < v.rows - HALO) {
+            const uint8_t* p = t8 + (ry + HALO) * (LDS_ROW_DW * 4) + (lane + 4);
+            const int c = p[0];
+            const int hi = c + threshold;
+            const int lo = c - threshold;
+            uint32_t B = 0;
+            uint32_t D = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = p[CIRC_DY[q] * (LDS_ROW_DW * 4) + CIRC_DX[q]];
+                B |= static_cast<uint32_t>(n > hi) << q;
+                D |= static_cast<uint32_t>(n < lo) << q;
+            }
+            corner = segment_test(B, D, arc);
+        }
+        const unsigned long long m = __ballot(corner);
+        if (lane == 0) {
+            masks[static_cast<size_t>(y) * v.nw + wx] = m;
+        }
+    }
+}
+
+// One workgroup per frame: exclusive scan of popcount(masks) over rows*nw words.
+__global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry;
+    const int f = blockIdx.x;
+    const int n = v.rows * v.nw;
+    const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
+    uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        carry = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t c = i < n ? static_cast<uint32_t>(__popcll(masks[i])) : 0u;
+        // inclusive wave scan
+        uint32_t s = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(s, d);
+            if (lane >= d) {
+                s += t;
+            }
+        }
+        if (lane == 63) {
+            wave_sums[wave] = s;
+        }
+        __syncthreads();
+        uint32_t wbase = carry;
+        for (int w = 0; w < wave; ++w) {
+            wbase += wave_sums[w];
+        }
+        if (i < n) {
+            off[i] = wbase + s - c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry = wbase + s;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int m = static_cast<int>(carry);
+        int st = 0;
+        if (m > v.maxM) {
+            st = STATUS_CAND_OVERFLOW;  // fail loudly on the host; downstream kernels see M = 0
+            m = 0;
+        }
+        v.n_cand[f] = m;
+        v.status[f] = st;
+        v.n_kp[f] = 0;
+    }
+}
+
+// One wave per bitmap word (grid-stride); lanes = set bits.
+__global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
+    const int f = blockIdx.y;
+    const int m_total = v.n_cand[f];
+    if (m_total == 0) {
+        return;
+    }
+    const int n = v.rows * v.nw;
+    const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
+    const uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
+    const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
+    uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
+    uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    for (int w = wave_global; w < n; w += n_waves) {
+        const unsigned long long m = masks[w];
+        if (m == 0) {
+            continue;  // wave-uniform
+        }
+        if ((m >> lane) & 1ull) {
+            const int row = w / v.nw;
+            const int x = (w - row * v.nw) * 64 + lane;
+            const uint32_t idx = off[w] + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            const uint8_t* p = img + static_cast<size_t>(row) * v.pitch + x;
+            const int c = p[0];
+            int score = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nb = p[CIRC_DY[q] * v.pitch + CIRC_DX[q]];
+                score += abs(nb - c);
+            }
+            xy[idx] = (static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x);
+            keys[idx] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | idx;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
+    dim3 grid(v.nw, (v.rows + TILE_H - 1) / TILE_H, nframes);
+    hipLaunchKernelGGL(fast_detect_kernel, grid, dim3(256), 0, stream, v, p.threshold, p.arc);
+}
+
+void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_kernel, dim3(nframes), dim3(1024), 0, stream, v);
+}
+
+void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
+    (void)p;
+    const int n = v.rows * v.nw;
+    int blocks = (n + 4 * 8 - 1) / (4 * 8);  // ~8 words per wave
+    if (blocks < 1) {
+        blocks = 1;
+    }
+    hipLaunchKernelGGL(expand_kernel, dim3(blocks, nframes), dim3(256), 0, stream, v);
+}
+
+}  // namespace slamx

@@ -1,0 +1,1160 @@
+// slamx_api.hip -- host side of the C ABI declared in include/slamx.h.
+//
+// Host logic only: configuration, the BRIEF pattern and blur weights (constructor-time work the
+// reference also does on the CPU, with the same <random> / std::exp calls), device memory and
+// kernel sequencing, and the order-defining std::partial_sort / std::sort of
+// filterAndSortMatches (feature_matcher.cpp:191-204, kept on the host with the SAME libstdc++
+// calls: SURVEY.md section 7, hard part 4).  Every pixel / descriptor / pair operation of the
+// hot path runs in the HIP kernels; there is no CPU implementation to fall back to.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "slamx_internal.h"
+#include "yaml_lite.hpp"
+
+using namespace slamx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            return fail(SLAMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+        }                                                                                                  \
+    } while (0)
+
+#define SLAMX_TRY(expr)       \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_ != SLAMX_OK) { \
+            return rc_;       \
+        }                     \
+    } while (0)
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) {
+        count = 1;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return SLAMX_OK;
+}
+template <typename T>
+void dev_free(T*& p) {
+    if (p != nullptr) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+
+}  // namespace
+
+struct slamx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string name;
+};
+
+struct slamx_detector {
+    slamx_ctx* ctx = nullptr;
+    slamx_detector_config cfg{};
+    std::vector<int32_t> pattern;  // x1,y1,x2,y2 per surviving pair
+    int8_t* pattern_dev = nullptr;
+    double* weights_dev = nullptr;
+    slamx_batch* single = nullptr;  // lazily created 1-frame batch behind the host-buffer API
+};
+
+struct slamx_matcher {
+    slamx_ctx* ctx = nullptr;
+    slamx_matcher_config cfg{};
+    // scratch behind slamx_matcher_match: a 2-"frame" layout, frame 0 = train, frame 1 = query
+    int cap = 0, width = 0;
+    uint8_t* desc = nullptr;
+    slamx_keypoint* kps = nullptr;
+    int* n_kp = nullptr;
+    slamx_match* matches = nullptr;
+    int* n_matches = nullptr;
+    int2* best = nullptr;
+    int* second = nullptr;
+};
+
+struct slamx_batch {
+    slamx_detector* det = nullptr;
+    slamx_batch_shape shape{};
+    BatchView v{};
+    uint8_t* frames = nullptr;
+    // matcher outputs (allocated on first use)
+    slamx_match* matches = nullptr;
+    int* n_matches = nullptr;
+    int2* best = nullptr;
+    int* second = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[SLAMX_STAGE_COUNT + 2] = {};
+    bool ev_valid[SLAMX_STAGE_COUNT + 2] = {};
+    int last_frames = 0;
+};
+
+namespace {
+
+// generateBRIEFPattern, src/frontend/feature_detector.cpp:286-313 -- constructor-time, host.
+std::vector<int32_t> make_pattern(int patch_size, int num_pairs) {
+    std::vector<int32_t> out;
+    const float scale = static_cast<float>(patch_size) / 2.0F;
+    std::default_random_engine generator;
+    std::normal_distribution<float> distribution(0.0F, 1.0F);
+    for (int i = 0; i < num_pairs; ++i) {
+        const float x1 = distribution(generator) * scale;
+        const float y1 = distribution(generator) * scale;
+        const float x2 = distribution(generator) * scale;
+        const float y2 = distribution(generator) * scale;
+        if (std::abs(x1) < scale && std::abs(y1) < scale && std::abs(x2) < scale && std::abs(y2) < scale) {
+            out.push_back(static_cast<int>(x1));
+            out.push_back(static_cast<int>(y1));
+            out.push_back(static_cast<int>(x2));
+            out.push_back(static_cast<int>(y2));
+        }
+    }
+    return out;
+}
+
+// the kernel of gaussianBlur(image, 5, 1.0), feature_detector.cpp:321-335
+void make_blur_weights(double* w25) {
+    const int half = 2;
+    const double sigma = 1.0;
+    double sum = 0.0;
+    for (int i = -half; i <= half; ++i) {
+        for (int j = -half; j <= half; ++j) {
+            const double value = std::exp(-((i * i) + (j * j)) / (2 * sigma * sigma));
+            w25[(i + half) * 5 + (j + half)] = value;
+            sum += value;
+        }
+    }
+    for (int k = 0; k < 25; ++k) {
+        w25[k] /= sum;
+    }
+}
+
+int validate_detector_config(const slamx_detector_config& c) {
+    // messages follow include/slam/frontend/feature_detector.hpp:60-93
+    if (c.intensity_threshold < 0 || c.intensity_threshold > 255) {
+        return fail(SLAMX_ERR_RUNTIME, "Intensity threshold must be in the range [0, 255].");
+    }
+    if (c.contiguous_pixels_threshold < 0 || c.contiguous_pixels_threshold > 16) {
+        return fail(SLAMX_ERR_RUNTIME, "Contiguous pixels threshold must be in the range [0, 16].");
+    }
+    if (c.non_max_suppression != 0 && c.non_max_suppression != 1) {
+        return fail(SLAMX_ERR_RUNTIME, "Non-max suppression must be either 0 (false) or 1 (true).");
+    }
+    if (c.suppression_window_size <= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "Suppression window size must be a positive integer.");
+    }
+    if (c.patch_size <= 0 || c.patch_size % 2 == 0) {
+        return fail(SLAMX_ERR_RUNTIME, "Patch size must be a positive odd integer.");
+    }
+    if (c.num_brief_pairs <= 0 || c.num_brief_pairs % 8 != 0) {
+        return fail(SLAMX_ERR_RUNTIME, "Number of BRIEF pairs must be a positive multiple of 8.");
+    }
+    // limits of this implementation (not of the reference)
+    if (c.num_brief_pairs > MAX_PATTERN) {
+        return fail(SLAMX_ERR_RUNTIME, "NumBRIEFPairs above 1024 is not supported by the MI355X build.");
+    }
+    if (c.patch_size > 255) {
+        return fail(SLAMX_ERR_RUNTIME, "PatchSize above 255 is not supported by the MI355X build.");
+    }
+    return SLAMX_OK;
+}
+
+DetectorParams params_of(const slamx_detector* d) {
+    DetectorParams p;
+    p.threshold = d->cfg.intensity_threshold;
+    p.arc = d->cfg.contiguous_pixels_threshold;
+    p.nms = d->cfg.non_max_suppression;
+    p.window = d->cfg.suppression_window_size;
+    p.patch = d->cfg.patch_size;
+    p.npairs = d->cfg.num_brief_pairs;
+    p.pattern_len = static_cast<int>(d->pattern.size() / 4);
+    return p;
+}
+
+int status_to_error(int st, int frame) {
+    if (st & STATUS_CAND_OVERFLOW) {
+        return fail(SLAMX_ERR_CAPACITY, "frame " + std::to_string(frame) + ": FAST candidates exceed max_candidates");
+    }
+    if (st & STATUS_KP_OVERFLOW) {
+        return fail(SLAMX_ERR_CAPACITY, "frame " + std::to_string(frame) + ": keypoints exceed max_keypoints");
+    }
+    if (st & STATUS_SEG_OVERFLOW) {
+        return fail(SLAMX_ERR_CAPACITY, "frame " + std::to_string(frame) + ": sort segment list overflow");
+    }
+    return SLAMX_OK;
+}
+
+void record(slamx_batch* b, int idx) {
+    if (b->profiling) {
+        if (b->ev[idx] == nullptr) {
+            (void)hipEventCreate(&b->ev[idx]);
+        }
+        (void)hipEventRecord(b->ev[idx], b->det->ctx->stream);
+        b->ev_valid[idx] = true;
+    }
+}
+
+// detect part: FAST bitmap -> prefix -> candidates -> exact sort -> greedy NMS
+void enqueue_detect(slamx_batch* b, int nframes) {
+    hipStream_t s = b->det->ctx->stream;
+    const DetectorParams p = params_of(b->det);
+    record(b, 0);
+    launch_fast_detect(b->v, p, nframes, s);
+    record(b, 1);
+    launch_scan(b->v, nframes, s);
+    record(b, 2);
+    launch_expand(b->v, p, nframes, s);
+    record(b, 3);
+    if (p.nms != 0) {
+        launch_sort(b->v, nframes, s);
+        record(b, 4);
+        launch_nms(b->v, p, nframes, s);
+        record(b, 5);
+    } else {
+        launch_passthrough_keypoints(b->v, nframes, s);
+        record(b, 4);
+        record(b, 5);
+    }
+}
+
+// compute part: blur -> orientation + BRIEF
+void enqueue_compute(slamx_batch* b, int nframes) {
+    hipStream_t s = b->det->ctx->stream;
+    const DetectorParams p = params_of(b->det);
+    if (!b->ev_valid[5]) {
+        record(b, 5);
+    }
+    launch_blur(b->v, b->det->weights_dev, nframes, s);
+    record(b, 6);
+    launch_describe(b->v, p, b->det->pattern_dev, nframes, s);
+    record(b, 7);
+}
+
+int ensure_single(slamx_detector* det, int rows, int cols, int min_keypoints) {
+    slamx_batch* b = det->single;
+    if (b != nullptr && b->shape.rows == rows && b->shape.cols == cols && b->v.maxK >= min_keypoints) {
+        return SLAMX_OK;
+    }
+    if (b != nullptr) {
+        slamx_batch_destroy(b);
+        det->single = nullptr;
+    }
+    slamx_batch_shape sh{};
+    sh.rows = rows;
+    sh.cols = cols;
+    sh.max_frames = 1;
+    // the host-buffer API has no capacity knob: size for the worst case the image allows
+    const long long px = static_cast<long long>(rows) * cols;
+    long long cap = px / 4;
+    if (cap < 1024) {
+        cap = 1024;
+    }
+    if (cap > MAX_CANDIDATES_HARD) {
+        cap = MAX_CANDIDATES_HARD;
+    }
+    sh.max_candidates = static_cast<int>(cap);
+    sh.max_keypoints = std::max(static_cast<int>(cap), min_keypoints);
+    return slamx_batch_create(det, &sh, &det->single);
+}
+
+int check_image(const uint8_t* img, int rows, int cols, ptrdiff_t stride) {
+    if (img == nullptr || rows <= 0 || cols <= 0 || stride < cols) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "image pointer/shape/stride invalid");
+    }
+    if (rows > 65535 || cols > 65535) {
+        return fail(SLAMX_ERR_RUNTIME, "images larger than 65535 in a dimension are not supported");
+    }
+    return SLAMX_OK;
+}
+
+// filterAndSortMatches, src/frontend/feature_matcher.cpp:191-204 -- same libstdc++ calls.
+void filter_and_sort(std::vector<slamx_match>& m, int good_matches_count) {
+    const auto pred = [](const slamx_match& a, const slamx_match& b) { return a.distance < b.distance; };
+    if (m.size() > static_cast<size_t>(good_matches_count)) {
+        std::partial_sort(m.begin(), m.begin() + good_matches_count, m.end(), pred);
+        m.erase(m.begin() + good_matches_count, m.end());
+    } else {
+        std::sort(m.begin(), m.end(), pred);
+    }
+}
+
+uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* slamx_last_error(void) { return g_last_error.c_str(); }
+const char* slamx_version(void) { return "slamx 0.1 (gfx950)"; }
+
+int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
+    if (out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "out is null");
+    }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        return fail(SLAMX_ERR_NO_DEVICE, "no HIP device available: the slamx hot path has no CPU fallback");
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) {
+        return fail(SLAMX_ERR_NO_DEVICE, "device ordinal out of range");
+    }
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    auto* c = new slamx_ctx();
+    c->device = device_ordinal;
+    c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (hip_stream != nullptr) {
+        c->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(SLAMX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+        c->owns_stream = true;
+    }
+    (void)hipEventCreate(&c->t0);
+    (void)hipEventCreate(&c->t1);
+    *out = c;
+    return SLAMX_OK;
+}
+
+void slamx_ctx_destroy(slamx_ctx* ctx) {
+    if (ctx == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (ctx->t0 != nullptr) {
+        (void)hipEventDestroy(ctx->t0);
+    }
+    if (ctx->t1 != nullptr) {
+        (void)hipEventDestroy(ctx->t1);
+    }
+    if (ctx->owns_stream && ctx->stream != nullptr) {
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int slamx_ctx_synchronize(slamx_ctx* ctx) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAMX_OK;
+}
+void* slamx_ctx_stream(slamx_ctx* ctx) { return ctx->stream; }
+int slamx_ctx_device_name(slamx_ctx* ctx, char* buf, int cap) {
+    if (buf == nullptr || cap <= 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "buffer");
+    }
+    std::snprintf(buf, static_cast<size_t>(cap), "%s", ctx->name.c_str());
+    return SLAMX_OK;
+}
+int slamx_ctx_timer_start(slamx_ctx* ctx) {
+    HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
+    return SLAMX_OK;
+}
+int slamx_ctx_timer_stop_ms(slamx_ctx* ctx, float* ms) {
+    HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->t1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return SLAMX_OK;
+}
+
+int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out) {
+    YamlFile y;
+    if (yaml_path == nullptr || !y.open(yaml_path)) {
+        return fail(SLAMX_ERR_RUNTIME,
+                    std::string("Could not open feature detector file: ") + (yaml_path ? yaml_path : "(null)"));
+    }
+    out->intensity_threshold = y.get_int("IntensityThreshold");
+    out->contiguous_pixels_threshold = y.get_int("ContiguousPixelsThreshold");
+    out->non_max_suppression = y.get_int("NonMaxSuppression");
+    out->suppression_window_size = y.get_int("SuppressionWindowSize");
+    out->patch_size = y.get_int("PatchSize");
+    out->num_brief_pairs = y.get_int("NumBRIEFPairs");
+    return validate_detector_config(*out);
+}
+
+int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out) {
+    YamlFile y;
+    if (yaml_path == nullptr || !y.open(yaml_path)) {
+        return fail(SLAMX_ERR_RUNTIME,
+                    std::string("Could not open feature matcher config file: ") + (yaml_path ? yaml_path : "(null)"));
+    }
+    const std::string dt = y.get_string("DistanceType");
+    if (dt == "HAMMING") {
+        out->distance_type = 0;
+    } else if (dt == "L2") {
+        out->distance_type = 1;
+    } else {
+        return fail(SLAMX_ERR_RUNTIME, "Invalid distance type. Must be 'HAMMING' or 'L2'.");
+    }
+    out->filter_matches = y.get_int("FilterMatches");
+    out->good_matches_count = y.get_int("GoodMatchesCount");
+    out->use_ratio_test = y.get_int("UseRatioTest");
+    out->ratio_test_threshold = static_cast<float>(y.get_double("RatioTestThreshold"));
+    return SLAMX_OK;  // range checks happen in slamx_matcher_create, as in the constructor
+}
+
+int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slamx_detector** out) {
+    if (ctx == nullptr || cfg == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    *out = nullptr;
+    SLAMX_TRY(validate_detector_config(*cfg));
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto* d = new slamx_detector();
+    d->ctx = ctx;
+    d->cfg = *cfg;
+    d->pattern = make_pattern(cfg->patch_size, cfg->num_brief_pairs);
+    std::vector<int8_t> p8(d->pattern.size() + 4, 0);
+    for (size_t i = 0; i < d->pattern.size(); ++i) {
+        p8[i] = static_cast<int8_t>(d->pattern[i]);  // |coord| < patch/2 <= 127
+    }
+    double w25[25];
+    make_blur_weights(w25);
+    int rc = dev_alloc(&d->pattern_dev, p8.size());
+    if (rc == SLAMX_OK) {
+        rc = dev_alloc(&d->weights_dev, 25);
+    }
+    if (rc != SLAMX_OK) {
+        slamx_detector_destroy(d);
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(d->pattern_dev, p8.data(), p8.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->weights_dev, w25, sizeof(w25), hipMemcpyHostToDevice));
+    *out = d;
+    return SLAMX_OK;
+}
+
+void slamx_detector_destroy(slamx_detector* det) {
+    if (det == nullptr) {
+        return;
+    }
+    if (det->single != nullptr) {
+        slamx_batch_destroy(det->single);
+    }
+    dev_free(det->pattern_dev);
+    dev_free(det->weights_dev);
+    delete det;
+}
+
+int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pairs, int* n_pairs) {
+    const int n = static_cast<int>(det->pattern.size() / 4);
+    if (n_pairs != nullptr) {
+        *n_pairs = n;
+    }
+    if (xy4 != nullptr) {
+        const int m = std::min(n, cap_pairs);
+        std::memcpy(xy4, det->pattern.data(), static_cast<size_t>(m) * 4 * sizeof(int32_t));
+    }
+    return n <= cap_pairs || xy4 == nullptr ? SLAMX_OK : fail(SLAMX_ERR_CAPACITY, "pattern buffer too small");
+}
+
+int slamx_detector_descriptor_width(const slamx_detector* det) { return det->cfg.num_brief_pairs / 8; }
+
+// ------------------------------------------------------------------ batches
+int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slamx_batch** out) {
+    if (det == nullptr || shape == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    *out = nullptr;
+    if (shape->rows <= 0 || shape->cols <= 0 || shape->max_frames <= 0 || shape->rows > 65535 ||
+        shape->cols > 65535) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "batch shape invalid");
+    }
+    HIP_TRY(hipSetDevice(det->ctx->device));
+    auto* b = new slamx_batch();
+    b->det = det;
+    b->shape = *shape;
+    const long long px = static_cast<long long>(shape->rows) * shape->cols;
+    long long maxM = shape->max_candidates > 0 ? shape->max_candidates : std::max(1024LL, px / 16);
+    maxM = std::min<long long>(maxM, MAX_CANDIDATES_HARD);
+    long long maxK = shape->max_keypoints > 0 ? shape->max_keypoints : maxM;
+    b->shape.max_candidates = static_cast<int>(maxM);
+    b->shape.max_keypoints = static_cast<int>(maxK);
+    BatchView& v = b->v;
+    const size_t F = static_cast<size_t>(shape->max_frames);
+    v.rows = shape->rows;
+    v.cols = shape->cols;
+    v.pitch = (shape->cols + 63) / 64 * 64;
+    v.frame_stride = static_cast<size_t>(v.pitch) * v.rows;
+    v.nw = (shape->cols + 63) / 64;
+    v.maxM = static_cast<int>(maxM);
+    v.maxK = static_cast<int>(maxK);
+    v.maxSeg = static_cast<int>(maxM / 16 + 16);
+    v.width = det->cfg.num_brief_pairs / 8;
+    const size_t nwords = static_cast<size_t>(v.rows) * v.nw;
+    int rc = SLAMX_OK;
+    uint8_t* blurred = nullptr;
+    auto A = [&](auto** p, size_t n) {
+        if (rc == SLAMX_OK) {
+            rc = dev_alloc(p, n);
+        }
+    };
+    A(&b->frames, F * v.frame_stride + 64);
+    A(&blurred, F * v.frame_stride + 64);
+    A(&v.masks, F * nwords);
+    A(&v.wordoff, F * nwords);
+    A(&v.n_cand, F);
+    A(&v.cand_xy, F * v.maxM);
+    A(&v.keys, F * v.maxM);
+    A(&v.sorted, F * v.maxM);
+    A(&v.rank_of, F * v.maxM);
+    A(&v.state, F * v.maxM);
+    A(&v.segstart, F * (static_cast<size_t>(v.maxM) + 1));
+    A(&v.seglist, F * 2 * v.maxSeg);
+    A(&v.kps, F * v.maxK);
+    A(&v.n_kp, F);
+    A(&v.desc, F * v.maxK * v.width);
+    A(&v.status, F);
+    A(&v.undecided, F);
+    v.frames = b->frames;
+    v.blurred = blurred;
+    if (rc != SLAMX_OK) {
+        slamx_batch_destroy(b);
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(v.n_kp, 0, F * sizeof(int), det->ctx->stream);
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(v.n_cand, 0, F * sizeof(int), det->ctx->stream);
+    }
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(v.status, 0, F * sizeof(int), det->ctx->stream);
+    }
+    if (e == hipSuccess) {
+        // pitch padding is read (never used) by the tile loaders: keep it defined
+        e = hipMemsetAsync(b->frames, 0, F * v.frame_stride + 64, det->ctx->stream);
+    }
+    if (e != hipSuccess) {
+        slamx_batch_destroy(b);
+        return fail(SLAMX_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return SLAMX_OK;
+}
+
+void slamx_batch_destroy(slamx_batch* b) {
+    if (b == nullptr) {
+        return;
+    }
+    if (b->det != nullptr) {
+        (void)hipSetDevice(b->det->ctx->device);
+        (void)hipStreamSynchronize(b->det->ctx->stream);
+    }
+    BatchView& v = b->v;
+    dev_free(b->frames);
+    dev_free(v.blurred);
+    dev_free(v.masks);
+    dev_free(v.wordoff);
+    dev_free(v.n_cand);
+    dev_free(v.cand_xy);
+    dev_free(v.keys);
+    dev_free(v.sorted);
+    dev_free(v.rank_of);
+    dev_free(v.state);
+    dev_free(v.segstart);
+    dev_free(v.seglist);
+    dev_free(v.kps);
+    dev_free(v.n_kp);
+    dev_free(v.desc);
+    dev_free(v.status);
+    dev_free(v.undecided);
+    dev_free(b->matches);
+    dev_free(b->n_matches);
+    dev_free(b->best);
+    dev_free(b->second);
+    for (auto& e : b->ev) {
+        if (e != nullptr) {
+            (void)hipEventDestroy(e);
+        }
+    }
+    delete b;
+}
+
+uint8_t* slamx_batch_frames(slamx_batch* b, size_t* pitch, size_t* frame_stride) {
+    if (pitch != nullptr) {
+        *pitch = static_cast<size_t>(b->v.pitch);
+    }
+    if (frame_stride != nullptr) {
+        *frame_stride = b->v.frame_stride;
+    }
+    return b->frames;
+}
+
+int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                       ptrdiff_t frame_stride) {
+    if (first < 0 || n < 0 || first + n > b->shape.max_frames || host == nullptr || stride < b->v.cols) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload range/stride invalid");
+    }
+    for (int f = 0; f < n; ++f) {
+        HIP_TRY(hipMemcpy2DAsync(b->frames + static_cast<size_t>(first + f) * b->v.frame_stride,
+                                 static_cast<size_t>(b->v.pitch), host + static_cast<ptrdiff_t>(f) * frame_stride,
+                                 static_cast<size_t>(stride), static_cast<size_t>(b->v.cols),
+                                 static_cast<size_t>(b->v.rows), hipMemcpyHostToDevice, b->det->ctx->stream));
+    }
+    return SLAMX_OK;
+}
+
+int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
+    if (nframes < 0 || nframes > b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
+    }
+    if (nframes == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    for (auto& ok : b->ev_valid) {
+        ok = false;
+    }
+    enqueue_detect(b, nframes);
+    enqueue_compute(b, nframes);
+    b->last_frames = nframes;
+    HIP_TRY(hipGetLastError());
+    return SLAMX_OK;
+}
+
+int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints) {
+    if (nframes < 0 || nframes > b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
+    }
+    if (m->cfg.distance_type != 0) {
+        return fail(SLAMX_ERR_RUNTIME, "L2 distance requires float descriptors. Use the float overload.");
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    const size_t F = static_cast<size_t>(b->shape.max_frames);
+    if (b->matches == nullptr) {
+        SLAMX_TRY(dev_alloc(&b->matches, F * b->v.maxK));
+        SLAMX_TRY(dev_alloc(&b->n_matches, F));
+        SLAMX_TRY(dev_alloc(&b->best, F * b->v.maxK));
+        SLAMX_TRY(dev_alloc(&b->second, F * b->v.maxK));
+        HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
+    }
+    MatchView mv{};
+    mv.desc = b->v.desc;
+    mv.kps = use_keypoints != 0 ? b->v.kps : nullptr;
+    mv.n_kp = b->v.n_kp;
+    mv.matches = b->matches;
+    mv.n_matches = b->n_matches;
+    mv.best = b->best;
+    mv.second = b->second;
+    mv.maxK = b->v.maxK;
+    mv.width = b->v.width;
+    mv.use_ratio = m->cfg.use_ratio_test;
+    mv.ratio = m->cfg.ratio_test_threshold;
+    if (!b->ev_valid[7]) {
+        record(b, 7);
+    }
+    launch_match_consecutive(mv, 1, nframes - 1, b->det->ctx->stream);
+    record(b, 8);
+    HIP_TRY(hipGetLastError());
+    return SLAMX_OK;
+}
+
+int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches) {
+    if (nframes < 0 || nframes > b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
+    }
+    hipStream_t s = b->det->ctx->stream;
+    std::vector<int> status(static_cast<size_t>(nframes));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(status.data(), b->v.status, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+    if (n_candidates != nullptr) {
+        HIP_TRY(hipMemcpy(n_candidates, b->v.n_cand, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+    }
+    if (n_keypoints != nullptr) {
+        HIP_TRY(hipMemcpy(n_keypoints, b->v.n_kp, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+    }
+    if (n_matches != nullptr) {
+        if (b->n_matches != nullptr) {
+            HIP_TRY(hipMemcpy(n_matches, b->n_matches, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+            if (nframes > 0) {
+                n_matches[0] = 0;  // frame 0 has no previous frame
+            }
+        } else {
+            std::memset(n_matches, 0, sizeof(int) * nframes);
+        }
+    }
+    for (int f = 0; f < nframes; ++f) {
+        SLAMX_TRY(status_to_error(status[static_cast<size_t>(f)], f));
+    }
+    return SLAMX_OK;
+}
+
+int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    if (frame < 0 || frame >= b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range");
+    }
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    int st = 0;
+    int cnt = 0;
+    HIP_TRY(hipMemcpy(&st, b->v.status + frame, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&cnt, b->v.n_kp + frame, sizeof(int), hipMemcpyDeviceToHost));
+    SLAMX_TRY(status_to_error(st, frame));
+    if (n != nullptr) {
+        *n = cnt;
+    }
+    if (cnt > cap) {
+        return fail(SLAMX_ERR_CAPACITY, "keypoint buffer too small");
+    }
+    if (kps != nullptr && cnt > 0) {
+        HIP_TRY(hipMemcpy(kps, b->v.kps + static_cast<size_t>(frame) * b->v.maxK, sizeof(slamx_keypoint) * cnt,
+                          hipMemcpyDeviceToHost));
+    }
+    if (desc != nullptr && cnt > 0) {
+        HIP_TRY(hipMemcpy(desc, b->v.desc + static_cast<size_t>(frame) * b->v.maxK * b->v.width,
+                          static_cast<size_t>(cnt) * b->v.width, hipMemcpyDeviceToHost));
+    }
+    return SLAMX_OK;
+}
+
+int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
+                                 int cap, int* n) {
+    if (frame < 1 || frame >= b->shape.max_frames || b->matches == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or no matches computed");
+    }
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    int cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, b->n_matches + frame, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<slamx_match> v(static_cast<size_t>(cnt));
+    if (cnt > 0) {
+        HIP_TRY(hipMemcpy(v.data(), b->matches + static_cast<size_t>(frame) * b->v.maxK, sizeof(slamx_match) * cnt,
+                          hipMemcpyDeviceToHost));
+    }
+    if (apply_filter != 0 && m != nullptr && m->cfg.filter_matches != 0) {
+        filter_and_sort(v, m->cfg.good_matches_count);
+    }
+    if (n != nullptr) {
+        *n = static_cast<int>(v.size());
+    }
+    if (static_cast<int>(v.size()) > cap) {
+        return fail(SLAMX_ERR_CAPACITY, "match buffer too small");
+    }
+    if (out != nullptr && !v.empty()) {
+        std::memcpy(out, v.data(), sizeof(slamx_match) * v.size());
+    }
+    return SLAMX_OK;
+}
+
+int slamx_batch_set_profiling(slamx_batch* b, int enable) {
+    b->profiling = enable != 0;
+    return SLAMX_OK;
+}
+
+int slamx_batch_stage_ms(slamx_batch* b, float* ms) {
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    // event i brackets: 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS|5|BLUR|6|DESCRIBE|7|MATCH|8
+    for (int s = 0; s < SLAMX_STAGE_COUNT; ++s) {
+        ms[s] = 0.0f;
+        if (b->ev_valid[s] && b->ev_valid[s + 1]) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, b->ev[s], b->ev[s + 1]) == hipSuccess) {
+                ms[s] = t;
+            }
+        }
+    }
+    return SLAMX_OK;
+}
+
+// ------------------------------------------------------------------ single-frame host API
+int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
+                 int cap, int* n) {
+    SLAMX_TRY(check_image(img, rows, cols, stride));
+    SLAMX_TRY(ensure_single(det, rows, cols, 0));
+    slamx_batch* b = det->single;
+    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+    for (auto& ok : b->ev_valid) {
+        ok = false;
+    }
+    enqueue_detect(b, 1);
+    HIP_TRY(hipGetLastError());
+    return slamx_batch_download(b, 0, kps, nullptr, cap, n);
+}
+
+int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
+                  int n, uint8_t* desc) {
+    if (n < 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "negative keypoint count");
+    }
+    if (n == 0) {
+        return SLAMX_OK;  // compute() on an empty vector yields a 0x0 matrix (feature_detector.cpp:22-25)
+    }
+    SLAMX_TRY(check_image(img, rows, cols, stride));
+    if (kps == nullptr || desc == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null keypoints/descriptors");
+    }
+    SLAMX_TRY(ensure_single(det, rows, cols, n));
+    slamx_batch* b = det->single;
+    hipStream_t s = det->ctx->stream;
+    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+    HIP_TRY(hipMemcpyAsync(b->v.kps, kps, sizeof(slamx_keypoint) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->v.n_kp, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));  // &n must stay alive until the copy is done
+    for (auto& ok : b->ev_valid) {
+        ok = false;
+    }
+    enqueue_compute(b, 1);
+    HIP_TRY(hipGetLastError());
+    int cnt = 0;
+    return slamx_batch_download(b, 0, kps, desc, n, &cnt);
+}
+
+int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                             slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    SLAMX_TRY(check_image(img, rows, cols, stride));
+    SLAMX_TRY(ensure_single(det, rows, cols, 0));
+    slamx_batch* b = det->single;
+    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+    SLAMX_TRY(slamx_batch_detect_and_compute(b, 1));
+    return slamx_batch_download(b, 0, kps, desc, cap, n);
+}
+
+int slamx_fast_candidates(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                          slamx_keypoint* kps, int cap, int* n) {
+    SLAMX_TRY(check_image(img, rows, cols, stride));
+    SLAMX_TRY(ensure_single(det, rows, cols, 0));
+    slamx_batch* b = det->single;
+    hipStream_t s = det->ctx->stream;
+    const DetectorParams p = params_of(det);
+    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+    launch_fast_detect(b->v, p, 1, s);
+    launch_scan(b->v, 1, s);
+    launch_expand(b->v, p, 1, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    int st = 0, m = 0;
+    HIP_TRY(hipMemcpy(&st, b->v.status, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&m, b->v.n_cand, sizeof(int), hipMemcpyDeviceToHost));
+    SLAMX_TRY(status_to_error(st, 0));
+    if (n != nullptr) {
+        *n = m;
+    }
+    if (m > cap) {
+        return fail(SLAMX_ERR_CAPACITY, "candidate buffer too small");
+    }
+    std::vector<uint32_t> xy(static_cast<size_t>(m)), keys(static_cast<size_t>(m));
+    if (m > 0) {
+        HIP_TRY(hipMemcpy(xy.data(), b->v.cand_xy, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(keys.data(), b->v.keys, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < m; ++i) {
+        kps[i].x = static_cast<float>(xy[static_cast<size_t>(i)] & 0xffffu);
+        kps[i].y = static_cast<float>(xy[static_cast<size_t>(i)] >> 16);
+        kps[i].size = 6.0f;
+        kps[i].angle = 0.0f;
+        kps[i].response = static_cast<float>(keys[static_cast<size_t>(i)] >> SCORE_SHIFT);
+    }
+    return SLAMX_OK;
+}
+
+int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, uint8_t* out) {
+    SLAMX_TRY(check_image(img, rows, cols, stride));
+    SLAMX_TRY(ensure_single(det, rows, cols, 0));
+    slamx_batch* b = det->single;
+    hipStream_t s = det->ctx->stream;
+    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+    launch_blur(b->v, det->weights_dev, 1, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(out, static_cast<size_t>(cols), b->v.blurred, static_cast<size_t>(b->v.pitch),
+                             static_cast<size_t>(cols), static_cast<size_t>(rows), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
+int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out) {
+    if (n < 0 || n > MAX_CANDIDATES_HARD) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "n out of range");
+    }
+    if (n == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> keys(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        if (scores[i] > 4095u) {
+            return fail(SLAMX_ERR_INVALID_ARGUMENT, "score above 4095");
+        }
+        keys[static_cast<size_t>(i)] = (scores[i] << SCORE_SHIFT) | static_cast<uint32_t>(i);
+    }
+    uint32_t *dk = nullptr, *ds = nullptr;
+    uint8_t* dseg = nullptr;
+    int2* dlist = nullptr;
+    int* dstatus = nullptr;
+    const int maxSeg = n / 16 + 16;
+    int rc = dev_alloc(&dk, n);
+    if (rc == SLAMX_OK) rc = dev_alloc(&ds, n);
+    if (rc == SLAMX_OK) rc = dev_alloc(&dseg, static_cast<size_t>(n) + 1);
+    if (rc == SLAMX_OK) rc = dev_alloc(&dlist, static_cast<size_t>(2) * maxSeg);
+    if (rc == SLAMX_OK) rc = dev_alloc(&dstatus, 1);
+    int st = 0;
+    hipError_t e = hipSuccess;
+    if (rc == SLAMX_OK) {
+        e = hipMemcpyAsync(dk, keys.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            launch_debug_sort(dk, ds, dseg, dlist, maxSeg, n, dstatus, ctx->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), ds, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&st, dstatus, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    dev_free(dk);
+    dev_free(ds);
+    dev_free(dseg);
+    dev_free(dlist);
+    dev_free(dstatus);
+    if (rc != SLAMX_OK) {
+        return rc;
+    }
+    if (e != hipSuccess) {
+        return fail(SLAMX_ERR_HIP, std::string("debug sort: ") + hipGetErrorString(e));
+    }
+    if (st != 0) {
+        return fail(SLAMX_ERR_CAPACITY, "sort segment list overflow");
+    }
+    for (int i = 0; i < n; ++i) {
+        perm_out[i] = keys[static_cast<size_t>(i)] & INDEX_MASK;
+    }
+    return SLAMX_OK;
+}
+
+int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, float* angle_deg, float* cos_out,
+                     float* sin_out) {
+    if (n <= 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    float* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = SLAMX_OK;
+    for (auto& p : d) {
+        if (rc == SLAMX_OK) rc = dev_alloc(&p, n);
+    }
+    hipError_t e = hipSuccess;
+    if (rc == SLAMX_OK) {
+        const size_t bytes = sizeof(float) * static_cast<size_t>(n);
+        e = hipMemcpyAsync(d[0], m01, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d[1], m10, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            launch_debug_trig(d[0], d[1], n, d[2], d[3], d[4], ctx->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(angle_deg, d[2], bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(cos_out, d[3], bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sin_out, d[4], bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    for (auto& p : d) {
+        dev_free(p);
+    }
+    if (rc != SLAMX_OK) {
+        return rc;
+    }
+    if (e != hipSuccess) {
+        return fail(SLAMX_ERR_HIP, std::string("debug trig: ") + hipGetErrorString(e));
+    }
+    return SLAMX_OK;
+}
+
+// ------------------------------------------------------------------ matcher
+int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out) {
+    if (ctx == nullptr || cfg == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    *out = nullptr;
+    // messages follow src/frontend/feature_matcher.cpp:27-57
+    if (cfg->distance_type != 0 && cfg->distance_type != 1) {
+        return fail(SLAMX_ERR_RUNTIME, "Invalid distance type. Must be 'HAMMING' or 'L2'.");
+    }
+    if (cfg->filter_matches != 0 && cfg->filter_matches != 1) {
+        return fail(SLAMX_ERR_RUNTIME, "FilterMatches must be either 0 (false) or 1 (true).");
+    }
+    if (cfg->filter_matches != 0 && cfg->good_matches_count <= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "GoodMatchesCount must be positive when filtering is enabled.");
+    }
+    if (cfg->use_ratio_test != 0 && cfg->use_ratio_test != 1) {
+        return fail(SLAMX_ERR_RUNTIME, "UseRatioTest must be either 0 (false) or 1 (true).");
+    }
+    if (cfg->ratio_test_threshold < 0.0F || cfg->ratio_test_threshold > 1.0F) {
+        return fail(SLAMX_ERR_RUNTIME, "RatioTestThreshold must be in the range [0, 1].");
+    }
+    auto* m = new slamx_matcher();
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    *out = m;
+    return SLAMX_OK;
+}
+
+void slamx_matcher_destroy(slamx_matcher* m) {
+    if (m == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(m->ctx->device);
+    dev_free(m->desc);
+    dev_free(m->kps);
+    dev_free(m->n_kp);
+    dev_free(m->matches);
+    dev_free(m->n_matches);
+    dev_free(m->best);
+    dev_free(m->second);
+    delete m;
+}
+
+int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1, const uint8_t* d2, int n2, int width2,
+                const slamx_keypoint* kp1, int nkp1, const slamx_keypoint* kp2, int nkp2, slamx_match* out, int cap,
+                int* n) {
+    if (n != nullptr) {
+        *n = 0;
+    }
+    // validateInputs, src/frontend/feature_matcher.cpp:97-111
+    if (n1 <= 0 || n2 <= 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "Empty descriptors provided.");
+    }
+    if (m->cfg.distance_type != 0) {
+        return fail(SLAMX_ERR_RUNTIME, "DescriptorMatrix (uint8_t) requires HAMMING distance.");
+    }
+    if (width1 != width2) {
+        return fail(SLAMX_ERR_RUNTIME, "Descriptor dimensions must match.");
+    }
+    if (width1 <= 0 || d1 == nullptr || d2 == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "descriptor pointer/width invalid");
+    }
+    const bool use_kp = nkp1 > 0 && nkp2 > 0;  // :150
+    if (use_kp && (nkp1 < n1 || nkp2 < n2 || kp1 == nullptr || kp2 == nullptr)) {
+        // the reference indexes keypoints1[i] / keypoints2[j] unchecked (UB when shorter)
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "keypoint vectors shorter than the descriptor sets");
+    }
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    const int need = std::max(n1, n2);
+    if (need > m->cap || width1 != m->width) {
+        dev_free(m->desc);
+        dev_free(m->kps);
+        dev_free(m->n_kp);
+        dev_free(m->matches);
+        dev_free(m->n_matches);
+        dev_free(m->best);
+        dev_free(m->second);
+        m->cap = 0;
+        const size_t c = static_cast<size_t>(need);
+        SLAMX_TRY(dev_alloc(&m->desc, 2 * c * width1 + 64));
+        SLAMX_TRY(dev_alloc(&m->kps, 2 * c));
+        SLAMX_TRY(dev_alloc(&m->n_kp, 2));
+        SLAMX_TRY(dev_alloc(&m->matches, 2 * c));
+        SLAMX_TRY(dev_alloc(&m->n_matches, 2));
+        SLAMX_TRY(dev_alloc(&m->best, 2 * c));
+        SLAMX_TRY(dev_alloc(&m->second, 2 * c));
+        m->cap = need;
+        m->width = width1;
+    }
+    const size_t c = static_cast<size_t>(m->cap);
+    const int counts[2] = {n2, n1};  // frame 0 = train, frame 1 = query
+    HIP_TRY(hipMemcpyAsync(m->desc, d2, static_cast<size_t>(n2) * width1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->desc + c * width1, d1, static_cast<size_t>(n1) * width1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->n_kp, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+    if (use_kp) {
+        HIP_TRY(hipMemcpyAsync(m->kps, kp2, sizeof(slamx_keypoint) * n2, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(m->kps + c, kp1, sizeof(slamx_keypoint) * n1, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // counts[] lives on this stack frame
+    MatchView mv{};
+    mv.desc = m->desc;
+    mv.kps = use_kp ? m->kps : nullptr;
+    mv.n_kp = m->n_kp;
+    mv.matches = m->matches;
+    mv.n_matches = m->n_matches;
+    mv.best = m->best;
+    mv.second = m->second;
+    mv.maxK = m->cap;
+    mv.width = width1;
+    mv.use_ratio = m->cfg.use_ratio_test;
+    mv.ratio = m->cfg.ratio_test_threshold;
+    launch_match_consecutive(mv, 1, 1, s);
+    HIP_TRY(hipGetLastError());
+    int cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, m->n_matches + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<slamx_match> v(static_cast<size_t>(cnt));
+    if (cnt > 0) {
+        HIP_TRY(hipMemcpy(v.data(), m->matches + c, sizeof(slamx_match) * cnt, hipMemcpyDeviceToHost));
+    }
+    if (m->cfg.filter_matches != 0) {
+        filter_and_sort(v, m->cfg.good_matches_count);
+    }
+    if (n != nullptr) {
+        *n = static_cast<int>(v.size());
+    }
+    if (static_cast<int>(v.size()) > cap) {
+        return fail(SLAMX_ERR_CAPACITY, "match buffer too small");
+    }
+    if (out != nullptr && !v.empty()) {
+        std::memcpy(out, v.data(), sizeof(slamx_match) * v.size());
+    }
+    return SLAMX_OK;
+}
+
+// ------------------------------------------------------------------ synthetic frames (host)
+int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max, uint8_t* out) {
+    if (rows <= 0 || cols <= 0 || out == nullptr || rect_min <= 0 || rect_max < rect_min || k < 0 || n_rect < 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "synthetic frame arguments invalid");
+    }
+    const int CW = cols + 64;
+    const int CH = rows + 32;
+    std::vector<uint8_t> canvas(static_cast<size_t>(CW) * CH, 96);
+    uint64_t s = seed;
+    for (int r = 0; r < n_rect; ++r) {
+        const int w = rect_min + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(rect_max - rect_min + 1));
+        const int h = rect_min + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(rect_max - rect_min + 1));
+        const int x0 = static_cast<int>(splitmix64(s) % static_cast<uint64_t>(CW));
+        const int y0 = static_cast<int>(splitmix64(s) % static_cast<uint64_t>(CH));
+        const int g = static_cast<int>(splitmix64(s) % 194ull);
+        const uint8_t level = static_cast<uint8_t>(g < 65 ? 16 + g : 112 + (g - 65));  // {16..80} U {112..240}
+        const int x1 = std::min(CW, x0 + w);
+        const int y1 = std::min(CH, y0 + h);
+        for (int y = y0; y < y1; ++y) {
+            std::memset(&canvas[static_cast<size_t>(y) * CW + x0], level, static_cast<size_t>(x1 - x0));
+        }
+    }
+    const int ox = (2 * k) % 64;
+    const int oy = k % 32;
+    uint64_t ns = seed ^ (0x9E3779B97F4A7C15ull * static_cast<uint64_t>(k + 1));
+    for (int y = 0; y < rows; ++y) {
+        for (int x = 0; x < cols; ++x) {
+            const int base = canvas[static_cast<size_t>(y + oy) * CW + (x + ox)];
+            const int noise = static_cast<int>(splitmix64(ns) % 9ull) - 4;
+            int val = base + noise;
+            val = val < 0 ? 0 : (val > 255 ? 255 : val);
+            out[static_cast<size_t>(y) * cols + x] = static_cast<uint8_t>(val);
+        }
+    }
+    return SLAMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// slamx_internal.h -- shared between the HIP kernels and the C-ABI host code.
+// gfx950 only: wave = 64 lanes everywhere in this code base.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/slamx.h"
+
+namespace slamx {
+
+constexpr int WAVE = 64;
+constexpr int SCORE_SHIFT = 20;            // key = score << 20 | raster index
+constexpr uint32_t INDEX_MASK = (1u << SCORE_SHIFT) - 1;
+constexpr int MAX_CANDIDATES_HARD = 1 << SCORE_SHIFT;
+constexpr int SORT_LEAF = 16;              // libstdc++ _S_threshold (bits/stl_algo.h)
+constexpr int MAX_PATTERN = 1024;          // NumBRIEFPairs upper bound held in constant memory
+
+// NMS states (by sorted rank)
+constexpr uint8_t NMS_UNDECIDED = 0;
+constexpr uint8_t NMS_KEPT = 1;
+constexpr uint8_t NMS_SUPPRESSED = 2;
+
+// per-frame status bits
+constexpr int STATUS_CAND_OVERFLOW = 1;
+constexpr int STATUS_KP_OVERFLOW = 2;
+constexpr int STATUS_SEG_OVERFLOW = 4;
+
+// Device view of a frame batch in HBM.  All per-frame arrays are [frame][capacity].
+struct BatchView {
+    const uint8_t* frames;   // [F][rows][pitch] uint8, pitch % 64 == 0
+    uint8_t* blurred;        // same layout
+    int rows, cols, pitch;
+    size_t frame_stride;     // bytes between frames
+    int nw;                  // 64-pixel words per row = ceil(cols/64)
+    unsigned long long* masks;  // [F][rows*nw]  FAST corner bitmap, bit l of word w = pixel 64w+l
+    uint32_t* wordoff;       // [F][rows*nw]  exclusive prefix of popcount(masks) in raster order
+    int* n_cand;             // [F]  M
+    uint32_t* cand_xy;       // [F][maxM]  y<<16|x, raster order
+    uint32_t* keys;          // [F][maxM]  score<<20|raster idx; permuted in place by the sort
+    uint32_t* sorted;        // [F][maxM]  keys in final std::sort order
+    uint32_t* rank_of;       // [F][maxM]  raster idx -> sorted position
+    uint8_t* state;          // [F][maxM]  NMS state by sorted position
+    uint8_t* segstart;       // [F][maxM+1] leaf-segment start flags
+    int2* seglist;           // [F][2][maxSeg] level-synchronous segment lists
+    slamx_keypoint* kps;     // [F][maxK]
+    int* n_kp;               // [F]
+    uint8_t* desc;           // [F][maxK][width]
+    int* status;             // [F]
+    int* undecided;          // [F] NMS scratch counter
+    int maxM, maxK, maxSeg, width;
+};
+
+struct DetectorParams {
+    int threshold, arc, nms, window, patch, npairs /*NumBRIEFPairs*/, pattern_len;
+};
+
+// blocks per frame for a grid-stride kernel: enough to cover `items`, capped so that a large
+// batch does not launch millions of empty workgroups (>= 8 per frame, ~8192 in total)
+inline int grid_x(int items, int per_block, int nframes) {
+    int blocks = (items + per_block - 1) / per_block;
+    int cap = 8192 / (nframes > 0 ? nframes : 1);
+    if (cap < 8) {
+        cap = 8;
+    }
+    if (blocks > cap) {
+        blocks = cap;
+    }
+    return blocks < 1 ? 1 : blocks;
+}
+
+// ---- launchers (each enqueues on `stream`, no synchronization) ----
+void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
+void launch_scan(const BatchView& v, int nframes, hipStream_t stream);
+void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
+void launch_sort(const BatchView& v, int nframes, hipStream_t stream);
+void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
+void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream);  // NonMaxSuppression: 0
+void launch_blur(const BatchView& v, const double* weights_dev, int nframes, hipStream_t stream);
+void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
+                     hipStream_t stream);
+
+struct MatchView {
+    // pair q: query = frame qf[q], train = frame tf[q] of the same batch layout
+    const uint8_t* desc;           // [F][maxK][width]
+    const slamx_keypoint* kps;     // [F][maxK]  (or nullptr: no jump penalty)
+    const int* n_kp;               // [F]
+    slamx_match* matches;          // [F][maxK]  matches of query frame f (vs f-1)
+    int* n_matches;                // [F]
+    int2* best;                    // [F][maxK] scratch: {best_dist, best_idx}
+    int* second;                   // [F][maxK] scratch: second best
+    int maxK, width;
+    int use_ratio;
+    float ratio;
+};
+void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, hipStream_t stream);
+
+void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
+                       int* status, hipStream_t stream);
+void launch_debug_trig(const float* m01, const float* m10, int n, float* deg, float* c, float* s, hipStream_t stream);
+
+}  // namespace slamx

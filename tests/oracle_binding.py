@@ -1,0 +1,147 @@
+"""ctypes binding of the CPU oracle (oracle/slam_oracle.cpp).  TEST INFRASTRUCTURE ONLY: imported
+from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_build", "libslam_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4")])
+MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("distance", "<f4")])
+
+
+class DetectorParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("intensityThreshold", "contiguousPixelsThreshold", "nonMaxSuppression",
+                                       "suppressionWindowSize", "patchSize", "numBRIEFPairs")]
+
+
+class MatcherParams(C.Structure):
+    _fields_ = [("filterMatches", C.c_int), ("goodMatchesCount", C.c_int), ("useRatioTest", C.c_int),
+                ("ratioTestThreshold", C.c_float)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.oracle_atan2f.restype = C.c_float
+        lib.oracle_atan2f.argtypes = [C.c_float, C.c_float]
+        lib.oracle_cosf.restype = C.c_float
+        lib.oracle_cosf.argtypes = [C.c_float]
+        lib.oracle_sinf.restype = C.c_float
+        lib.oracle_sinf.argtypes = [C.c_float]
+        lib.oracle_angle_deg.restype = C.c_float
+        lib.oracle_angle_deg.argtypes = [C.c_float, C.c_float]
+        lib.oracle_angle_cos_sin.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.oracle_const_bits.restype = C.c_uint32
+        lib.oracle_trig_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_sort_desc.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+
+    @staticmethod
+    def det_params(cfg):
+        """cfg: any object with the six DetectorConfig fields (slamx.DetectorConfig works)."""
+        return DetectorParams(cfg.intensity_threshold, cfg.contiguous_pixels_threshold, cfg.non_max_suppression,
+                              cfg.suppression_window_size, cfg.patch_size, cfg.num_brief_pairs)
+
+    @staticmethod
+    def match_params(cfg):
+        return MatcherParams(cfg.filter_matches, cfg.good_matches_count, cfg.use_ratio_test, cfg.ratio_test_threshold)
+
+    def brief_pattern(self, patch, npairs):
+        xy = np.zeros((npairs, 4), np.int32)
+        n = self.lib.oracle_brief_pattern(patch, npairs, _p(xy), npairs)
+        return xy[:n].copy()
+
+    def _kp_call(self, fn, img, P):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = max(1024, img.size // 8)
+        while True:
+            kps = np.empty(cap, KEYPOINT_DTYPE)
+            n = fn(_p(img), img.shape[0], img.shape[1], img.strides[0], C.byref(P), _p(kps), cap)
+            if n <= cap:
+                return kps[:n].copy()
+            cap = n
+
+    def fast_candidates(self, img, P):
+        return self._kp_call(self.lib.oracle_fast_candidates, img, P)
+
+    def detect(self, img, P):
+        return self._kp_call(self.lib.oracle_detect, img, P)
+
+    def gaussian_blur(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.empty(img.shape, np.uint8)
+        self.lib.oracle_gaussian_blur(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(out))
+        return out
+
+    def compute(self, img, kps, P, want_moments=False):
+        img = np.ascontiguousarray(img, np.uint8)
+        k = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        n = k.shape[0]
+        width = P.numBRIEFPairs // 8
+        desc = np.zeros((n, width), np.uint8)
+        mom = np.zeros((n, 2), np.float32)
+        self.lib.oracle_compute(_p(img), img.shape[0], img.shape[1], img.strides[0], C.byref(P), _p(k), n, _p(desc),
+                                _p(mom))
+        if n == 0:
+            desc = np.zeros((0, 0), np.uint8)
+        return (k, desc, mom) if want_moments else (k, desc)
+
+    def detect_and_compute(self, img, P):
+        k = self.detect(img, P)
+        return self.compute(img, k, P)
+
+    def _match_call(self, fn, d1, d2, k1, k2, P):
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        d2 = np.ascontiguousarray(d2, np.uint8)
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE) if k1 is not None else None
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE) if k2 is not None else None
+        n1, n2 = d1.shape[0], d2.shape[0]
+        out = np.empty(max(n1, 1), MATCH_DTYPE)
+        n = fn(_p(d1), n1, _p(d2), n2, d1.shape[1] if d1.ndim == 2 else 0, _p(k1), 0 if k1 is None else k1.shape[0],
+               _p(k2), 0 if k2 is None else k2.shape[0], C.byref(P), _p(out), out.shape[0])
+        if n < 0:
+            raise ValueError("Empty descriptors provided.")
+        return out[:n].copy()
+
+    def best_matches(self, d1, d2, k1, k2, P):
+        return self._match_call(self.lib.oracle_best_matches, d1, d2, k1, k2, P)
+
+    def match(self, d1, d2, k1, k2, P):
+        return self._match_call(self.lib.oracle_match, d1, d2, k1, k2, P)
+
+    def trig_chain(self, m01, m10):
+        a = np.ascontiguousarray(m01, np.float32)
+        b = np.ascontiguousarray(m10, np.float32)
+        deg, c, s = (np.empty_like(a) for _ in range(3))
+        self.lib.oracle_trig_chain(_p(a), _p(b), a.shape[0], _p(deg), _p(c), _p(s))
+        return deg, c, s
+
+    def antiqsort(self, n):
+        vals = np.empty(n, np.uint32)
+        self.lib.oracle_antiqsort(n, _p(vals))
+        return vals
+
+    def sort_desc(self, scores):
+        s = np.ascontiguousarray(scores, np.uint32)
+        perm = np.empty(s.shape[0], np.uint32)
+        self.lib.oracle_sort_desc(_p(s), s.shape[0], _p(perm))
+        return perm
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        _cached = Oracle(C.CDLL(LIB))
+    return _cached

@@ -1,0 +1,391 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Everything here is integer / byte / index work or float work that the reference defines
+operation by operation, so every comparison is exact equality (np.array_equal on the raw
+records), never a tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_gray
+
+pytestmark = pytest.mark.gpu
+
+REF_IMAGES = [
+    "images/0000000000.png",  # 1392x512 KITTI frame, the reference's test_feature_detector input
+    "images/0000000001.png",
+    "images_test_loop/0.png",  # 640x480
+    "images_test_loop/1.png",
+]
+
+
+def cfg_of(slamx, t=20, arc=12, nms=1, window=12, patch=31, pairs=256):
+    return slamx.DetectorConfig(t, arc, nms, window, patch, pairs)
+
+
+@pytest.fixture(scope="module")
+def det(slamx, ref_data):
+    return slamx.FeatureDetector(os.path.join(ref_data, "feature_detector.yml"))
+
+
+@pytest.fixture(scope="module")
+def P(slamx, oracle, det):
+    return oracle.det_params(det.cfg)
+
+
+def synth(slamx, k=0, rows=480, cols=640, n_rect=300, seed=0x5EED0051, rmin=16, rmax=64):
+    return slamx.synth_frame(seed, k, rows, cols, n_rect, rmin, rmax)
+
+
+def assert_records_equal(a, b, what):
+    assert a.shape == b.shape, "%s: count %s vs %s" % (what, a.shape, b.shape)
+    if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
+        bad = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
+        raise AssertionError("%s: %d records differ, first at %d: %s vs %s" % (what, len(bad), bad[0], a[bad[0]], b[bad[0]]))
+
+
+# ---------------------------------------------------------------- a1
+def test_pattern_matches_oracle(det, oracle):
+    pat = det.pattern()
+    ref = oracle.brief_pattern(31, 256)
+    assert pat.shape == (46, 4)
+    assert np.array_equal(pat, ref)
+
+
+# ---------------------------------------------------------------- a2 + score
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_fast_candidates_reference_images(det, oracle, P, ref_data, name):
+    img = load_gray(os.path.join(ref_data, name))
+    assert_records_equal(det.fast_candidates(img), oracle.fast_candidates(img, P), "candidates " + name)
+
+
+@pytest.mark.parametrize("shape", [(7, 7), (6, 40), (40, 6), (8, 70), (33, 129), (100, 64), (65, 191), (480, 640)])
+@pytest.mark.parametrize("arc,t", [(12, 20), (9, 10), (16, 5), (0, 30), (1, 40)])
+def test_fast_candidates_shapes_and_thresholds(slamx, oracle, shape, arc, t):
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 1000 + cols + arc)
+    base = synth(slamx, 0, max(rows, 8), max(cols, 8), 40, rmin=3, rmax=12)[:rows, :cols]
+    img = np.ascontiguousarray(np.where(rng.random((rows, cols)) < 0.05, rng.integers(0, 256, (rows, cols)), base).astype(np.uint8))
+    d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=arc))
+    Pp = oracle.det_params(d.cfg)
+    assert_records_equal(d.fast_candidates(img), oracle.fast_candidates(img, Pp), "candidates %s arc=%d t=%d" % (shape, arc, t))
+
+
+def test_fast_candidates_strided_input(det, oracle, P, slamx):
+    big = synth(slamx, 3, 200, 300, 120, rmin=8, rmax=30)
+    view = big[10:150, 17:260]  # non-contiguous rows
+    assert_records_equal(det.fast_candidates(view), oracle.fast_candidates(np.ascontiguousarray(view), P), "strided")
+
+
+# ---------------------------------------------------------------- std::sort emulation
+def _check_sort(gpu_ctx, oracle, scores):
+    scores = np.asarray(scores, np.uint32)
+    got = gpu_ctx.debug_sort_desc(scores)
+    ref = oracle.sort_desc(scores)
+    assert np.array_equal(got, ref), "introsort permutation differs (n=%d), first at %d" % (
+        len(scores), int(np.nonzero(got != ref)[0][0]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 18, 31, 32, 33, 63, 64, 65, 66, 100, 127, 128, 129, 130, 200, 255, 256,
+                               257, 500, 1000, 1023, 1024, 1025, 4097, 11329, 24576, 24577, 40000, 70000])
+def test_sort_random_with_ties(gpu_ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    for spread in (3, 40, 1600, 4081):
+        _check_sort(gpu_ctx, oracle, rng.integers(0, spread, n))
+
+
+@pytest.mark.parametrize("n", [17, 64, 65, 129, 1000, 5000, 30000])
+def test_sort_structured(gpu_ctx, oracle, n):
+    i = np.arange(n)
+    cases = [
+        np.zeros(n), np.full(n, 4080), i % 4096, (n - i) % 4096, (i // 7) % 4096, (i % 2) * 100, (i % 3 == 0) * 7,
+        np.minimum(i, n - 1 - i) % 4096, np.maximum(i, n - 1 - i) % 4096, (i * 2654435761 >> 7) % 11,
+    ]
+    for c in cases:
+        _check_sort(gpu_ctx, oracle, c)
+
+
+def test_sort_depth_limit_heapsort(gpu_ctx, oracle):
+    """McIlroy's adversary drives libstdc++'s introsort into its heapsort fallback
+    (std::__partial_sort at depth limit 0); the device replays the same heap code."""
+    for n in (100, 1000, 4096):
+        vals = oracle.antiqsort(n)  # a permutation of 0..n-1 that kills ascending std::sort
+        assert sorted(vals.tolist()) == list(range(n))
+        _check_sort(gpu_ctx, oracle, (n - 1) - vals)  # same comparison sequence under 'greater'
+        _check_sort(gpu_ctx, oracle, vals)
+        _check_sort(gpu_ctx, oracle, ((n - 1) - vals) // 3)  # with ties
+
+
+def test_sort_kitti_scores(gpu_ctx, oracle, det, P, ref_data):
+    img = load_gray(os.path.join(ref_data, "images/0000000000.png"))
+    cand = oracle.fast_candidates(img, P)
+    _check_sort(gpu_ctx, oracle, cand["response"].astype(np.uint32))
+
+
+# ---------------------------------------------------------------- a3/a7 detect
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_detect_reference_images(det, oracle, P, ref_data, name):
+    img = load_gray(os.path.join(ref_data, name))
+    assert_records_equal(det.detect(img), oracle.detect(img, P), "detect " + name)
+
+
+@pytest.mark.parametrize("window", [1, 2, 6, 8, 12, 25, 70])
+def test_detect_windows_synthetic(slamx, oracle, window):
+    d = slamx.FeatureDetector(cfg_of(slamx, window=window))
+    Pp = oracle.det_params(d.cfg)
+    for k, (rows, cols, nr) in enumerate([(480, 640, 400), (240, 333, 150), (128, 1000, 200)]):
+        img = synth(slamx, k, rows, cols, nr, rmin=8, rmax=40)
+        assert_records_equal(d.detect(img), oracle.detect(img, Pp), "detect window=%d %dx%d" % (window, rows, cols))
+
+
+def test_detect_without_nms(slamx, oracle):
+    d = slamx.FeatureDetector(cfg_of(slamx, nms=0))
+    img = synth(slamx, 1, 300, 400, 200)
+    assert_records_equal(d.detect(img), oracle.detect(img, oracle.det_params(d.cfg)), "detect nms=0")
+
+
+def test_detect_no_corners(det):
+    img = np.full((64, 96), 128, np.uint8)
+    assert det.detect(img).shape[0] == 0
+    kps, desc = det.detectAndCompute(img)
+    assert kps.shape[0] == 0 and desc.shape == (0, 0)  # DescriptorMatrix(0, 0)
+
+
+# ---------------------------------------------------------------- a4 blur
+@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[2:3])
+def test_blur_reference_images(det, oracle, ref_data, name):
+    img = load_gray(os.path.join(ref_data, name))
+    assert np.array_equal(det.gaussian_blur(img), oracle.gaussian_blur(img))
+
+
+@pytest.mark.parametrize("shape", [(5, 5), (4, 9), (9, 4), (6, 64), (17, 65), (70, 130), (480, 640)])
+def test_blur_shapes(det, oracle, shape):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(det.gaussian_blur(img), oracle.gaussian_blur(img))
+
+
+def test_blur_half_integer_candidates(det, oracle):
+    """Extreme / two-level images: sums land close to .5 boundaries far more often."""
+    rng = np.random.default_rng(5)
+    for levels in ((0, 255), (0, 1), (127, 128), (254, 255)):
+        img = rng.choice(np.array(levels, np.uint8), size=(256, 512))
+        assert np.array_equal(det.gaussian_blur(img), oracle.gaussian_blur(img))
+
+
+# ---------------------------------------------------------------- libm restatement
+def test_trig_integer_moment_grid(gpu_ctx, oracle):
+    rng = np.random.default_rng(11)
+    n = 400000
+    m01 = rng.integers(-1200000, 1200001, n).astype(np.float32)
+    m10 = rng.integers(-1200000, 1200001, n).astype(np.float32)
+    # axis-aligned and tiny cases (hard part 2: 0 / +-90 / 180 degrees)
+    special = np.array([(0, 1), (1, 0), (-1, 0), (0, -1), (1, 1), (0, 0), (-1, -1), (1, -1), (-1, 1), (5, 0), (0, -7),
+                        (1, 1000000), (1000000, 1), (-1, 1000000), (1000000, -1), (3, -4), (-0.0, 1), (0, -0.0)], np.float32)
+    m01[: len(special)] = special[:, 0]
+    m10[: len(special)] = special[:, 1]
+    small = rng.integers(-40, 41, (20000, 2)).astype(np.float32)
+    m01[1000:21000] = small[:, 0]
+    m10[1000:21000] = small[:, 1]
+    got = gpu_ctx.debug_trig(m01, m10)
+    ref = oracle.trig_chain(m01, m10)
+    for g, r, name in zip(got, ref, ("angle", "cos", "sin")):
+        bad = np.nonzero(g.view(np.uint32) != r.view(np.uint32))[0]
+        assert bad.size == 0, "%s differs from glibc at %d inputs, e.g. m01=%r m10=%r: %r vs %r" % (
+            name, bad.size, m01[bad[0]], m10[bad[0]], g[bad[0]], r[bad[0]])
+
+
+def test_trig_known_answers(gpu_ctx):
+    """SURVEY.md 8c known answers for the (m01, m10) -> deg -> cos, sin chain."""
+    m01 = np.array([0, 1, -1, 0, 1, 0], np.float32)
+    m10 = np.array([1, 0, 0, -1, 1, 0], np.float32)
+    deg, c, s = gpu_ctx.debug_trig(m01, m10)
+    assert deg.tolist() == [0.0, 90.0, -90.0, 180.0, 45.0, 0.0]
+    assert c.view(np.uint32).tolist() == [0x3F800000, 0xB33BBD2E, 0xB33BBD2E, 0xBF800000, 0x3F3504F3, 0x3F800000]
+    assert s.view(np.uint32).tolist()[:5] == [0x00000000, 0x3F800000, 0xBF800000, 0xB3BBBD2E, 0x3F3504F3]
+
+
+# ---------------------------------------------------------------- a5/a6/a7 compute
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_compute_reference_images(det, oracle, P, ref_data, name):
+    img = load_gray(os.path.join(ref_data, name))
+    kps = oracle.detect(img, P)
+    k_ref, d_ref = oracle.compute(img, kps, P)
+    k_got, d_got = det.compute(img, kps)
+    assert_records_equal(k_got, k_ref, "angles " + name)
+    assert np.array_equal(d_got, d_ref), "descriptors " + name
+
+
+def test_compute_border_keypoints(det, oracle, P, slamx):
+    """Keypoints 0..25 px from every border: patch-leaves-image zero rows and the
+    skipped-pair bit shifting of feature_detector.cpp:268-280."""
+    img = synth(slamx, 2, 120, 160, 80, rmin=6, rmax=30)
+    pts = [(x, y) for y in list(range(0, 26)) + list(range(94, 120)) for x in (0, 3, 14, 15, 16, 20, 80, 139, 143, 144, 145, 159)]
+    pts += [(x, y) for x in list(range(0, 26)) + list(range(134, 160)) for y in (0, 15, 16, 21, 60, 98, 103, 104, 119)]
+    kps = np.zeros(len(pts), slamx.KEYPOINT_DTYPE)
+    kps["x"] = [p[0] for p in pts]
+    kps["y"] = [p[1] for p in pts]
+    kps["size"] = 6.0
+    k_ref, d_ref = oracle.compute(img, kps, P)
+    k_got, d_got = det.compute(img, kps)
+    assert_records_equal(k_got, k_ref, "border angles")
+    assert np.array_equal(d_got, d_ref)
+    assert (d_ref.sum(axis=1) == 0).any() and (d_ref.sum(axis=1) != 0).any()
+
+
+def test_compute_fractional_coordinates(det, oracle, P, slamx):
+    img = synth(slamx, 4, 200, 200, 100)
+    rng = np.random.default_rng(3)
+    kps = np.zeros(300, slamx.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 200, 300).astype(np.float32)
+    kps["y"] = rng.uniform(0, 200, 300).astype(np.float32)
+    kps["angle"] = 123.0  # overwritten by compute
+    k_ref, d_ref = oracle.compute(img, kps, P)
+    k_got, d_got = det.compute(img, kps)
+    assert_records_equal(k_got, k_ref, "fractional angles")
+    assert np.array_equal(d_got, d_ref)
+
+
+@pytest.mark.parametrize("patch,pairs", [(31, 256), (15, 64), (7, 8), (51, 512), (31, 1024), (101, 256)])
+def test_compute_other_patterns(slamx, oracle, patch, pairs):
+    d = slamx.FeatureDetector(cfg_of(slamx, patch=patch, pairs=pairs, window=6))
+    Pp = oracle.det_params(d.cfg)
+    assert np.array_equal(d.pattern(), oracle.brief_pattern(patch, pairs))
+    img = synth(slamx, 5, 240, 320, 200, rmin=8, rmax=40)
+    kps = oracle.detect(img, Pp)
+    k_ref, d_ref = oracle.compute(img, kps, Pp)
+    k_got, d_got = d.compute(img, kps)
+    assert_records_equal(k_got, k_ref, "angles patch=%d" % patch)
+    assert np.array_equal(d_got, d_ref)
+
+
+@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[2:3])
+def test_detect_and_compute(det, oracle, P, ref_data, name):
+    img = load_gray(os.path.join(ref_data, name))
+    k_ref, d_ref = oracle.detect_and_compute(img, P)
+    k_got, d_got = det.detectAndCompute(img)
+    assert_records_equal(k_got, k_ref, "detectAndCompute kps")
+    assert np.array_equal(d_got, d_ref)
+
+
+# ---------------------------------------------------------------- a8-a10 match
+@pytest.fixture(scope="module")
+def kitti_pair(det, oracle, P, ref_data):
+    a = load_gray(os.path.join(ref_data, "images/0000000000.png"))
+    b = load_gray(os.path.join(ref_data, "images/0000000001.png"))
+    return oracle.detect_and_compute(a, P), oracle.detect_and_compute(b, P)
+
+
+def mcfg(slamx, filt=1, good=20, ratio_on=1, ratio=0.5):
+    return slamx.MatcherConfig(0, filt, good, ratio_on, ratio)
+
+
+@pytest.mark.parametrize("with_kp", [True, False])
+@pytest.mark.parametrize("filt,good,ratio_on,ratio", [(1, 20, 1, 0.5), (0, 1, 1, 0.5), (0, 1, 0, 0.0), (1, 5000, 1, 0.9),
+                                                       (1, 3, 0, 1.0), (0, 1, 1, 1.0), (0, 1, 1, 0.0)])
+def test_match_kitti_pair(slamx, oracle, kitti_pair, with_kp, filt, good, ratio_on, ratio):
+    (k1, d1), (k2, d2) = kitti_pair
+    m = slamx.FeatureMatcher(mcfg(slamx, filt, good, ratio_on, ratio))
+    mp = oracle.match_params(m.cfg)
+    got = m.match(d1, d2, k1 if with_kp else None, k2 if with_kp else None)
+    ref = oracle.match(d1, d2, k1 if with_kp else None, k2 if with_kp else None, mp)
+    assert_records_equal(got, ref, "matches")
+
+
+def test_match_shipped_config(slamx, oracle, kitti_pair, ref_data):
+    """test_feature_matcher.cpp: the shipped YAML, keypoints passed."""
+    (k1, d1), (k2, d2) = kitti_pair
+    m = slamx.FeatureMatcher(os.path.join(ref_data, "feature_matcher.yml"))
+    assert (m.cfg.filter_matches, m.cfg.good_matches_count, m.cfg.use_ratio_test) == (1, 20, 1)
+    got = m.match(d1, d2, k1, k2)
+    assert_records_equal(got, oracle.match(d1, d2, k1, k2, oracle.match_params(m.cfg)), "shipped matcher")
+    assert len(got) <= 20
+
+
+@pytest.mark.parametrize("width", [1, 3, 8, 16, 32, 33, 64])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (1, 300), (300, 1), (257, 255), (700, 513)])
+def test_match_random_descriptors(slamx, oracle, width, n1, n2):
+    rng = np.random.default_rng(width * 100000 + n1 * 1000 + n2)
+    d1 = rng.integers(0, 256, (n1, width), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (n2, width), dtype=np.uint8)
+    d2[rng.integers(0, n2, n2 // 3 + 1)] = d1[rng.integers(0, n1, n2 // 3 + 1)]  # exact duplicates -> ties
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.integers(0, 1920, len(k))
+        k["y"] = rng.integers(0, 1080, len(k))
+    for kp in (True, False):
+        for ratio_on, ratio in ((1, 0.8), (0, 0.5)):
+            m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, ratio_on, ratio))
+            a1, a2 = (k1, k2) if kp else (None, None)
+            assert_records_equal(m.match(d1, d2, a1, a2), oracle.match(d1, d2, a1, a2, oracle.match_params(m.cfg)),
+                                 "random match w=%d kp=%s" % (width, kp))
+
+
+def test_match_penalty_fractional_keypoints(slamx, oracle):
+    rng = np.random.default_rng(9)
+    d1 = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    k1 = np.zeros(400, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(500, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.uniform(0, 4000, len(k)).astype(np.float32)
+        k["y"] = rng.uniform(0, 3000, len(k)).astype(np.float32)
+    k2["x"][:50] = k1["x"][:50] + 300.0  # exactly 500 px away (3-4-5): boundary of '>'
+    k2["y"][:50] = k1["y"][:50] + 400.0
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 0, 0.5))
+    assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, oracle.match_params(m.cfg)), "penalty")
+
+
+def test_match_errors(slamx):
+    m = slamx.FeatureMatcher(mcfg(slamx))
+    d = np.zeros((4, 32), np.uint8)
+    with pytest.raises(ValueError):  # std::invalid_argument("Empty descriptors provided.")
+        m.match(np.zeros((0, 32), np.uint8), d)
+    with pytest.raises(ValueError):
+        m.match(d, np.zeros((0, 32), np.uint8))
+    with pytest.raises(RuntimeError):  # "Descriptor dimensions must match."
+        m.match(d, np.zeros((4, 16), np.uint8))
+    l2 = slamx.FeatureMatcher(slamx.MatcherConfig(1, 0, 1, 0, 0.5))
+    with pytest.raises(RuntimeError):  # L2 is refused by match()
+        l2.match(d, d)
+
+
+# ---------------------------------------------------------------- device-resident batches
+def test_batch_equals_single_frame(slamx, oracle):
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
+    mp = oracle.match_params(m.cfg)
+    n = 5
+    frames = np.stack([synth(slamx, k, 240, 320, 250, rmin=8, rmax=40) for k in range(n)])
+    b = slamx.Batch(d, 240, 320, n, max_candidates=20000, max_keypoints=8000)
+    b.upload(frames)
+    b.detect_and_compute(n)
+    b.match_consecutive(m, n, use_keypoints=True)
+    ncand, nkp, nm = b.counts(n)
+    prev = None
+    for k in range(n):
+        k_ref, d_ref = oracle.detect_and_compute(frames[k], Pp)
+        k_got, d_got = b.download(k)
+        assert nkp[k] == len(k_ref) and ncand[k] == len(oracle.fast_candidates(frames[k], Pp))
+        assert_records_equal(k_got, k_ref, "batch frame %d" % k)
+        assert np.array_equal(d_got, d_ref)
+        if prev is not None:
+            ref_m = oracle.match(d_ref, prev[1], k_ref, prev[0], mp)
+            assert_records_equal(b.download_matches(m, k), ref_m, "batch matches %d" % k)
+            assert nm[k] == len(ref_m)
+        prev = (k_ref, d_ref)
+    assert nm[0] == 0
+
+
+def test_batch_capacity_overflow_is_loud(slamx):
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6))
+    frame = synth(slamx, 0, 240, 320, 250, rmin=8, rmax=40)
+    b = slamx.Batch(d, 240, 320, 1, max_candidates=64, max_keypoints=64)
+    b.upload(frame)
+    b.detect_and_compute(1)
+    with pytest.raises(slamx.CapacityError):
+        b.counts(1)
