@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the frontend hot path (detect + describe + match-to-previous) on
+N MI355X, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_2k|c2|c3] [--batch B]
+
+A "step" is one pass of the hot path over one batch of B synthetic frames that are already
+resident in HBM: FAST detect -> exact std::sort order -> greedy NMS -> blur -> orientation +
+steered BRIEF -> brute-force Hamming match of every frame against its predecessor (frame 0 of
+the batch against the batch's last frame, standing in for the previous batch's last frame, so
+every one of the B frames is detected, described AND matched).
+
+Workloads (BASELINE.json): the metric is quoted on "1080p @ 2k feats/frame", which is the
+default; `c2` = configs[1] (640x480, ~2000 keypoints), `c3` = configs[2] (1080p, ~10k keypoints).
+The reference has no feature-count knob, so counts are reached through the synthetic corner
+density and SuppressionWindowSize; the realised candidates M / keypoints N are in the JSON.
+
+Multi-GPU: frames shard embarrassingly (one independent stream per rank, seed + rank), no
+data-path collective; one RCCL all_gather of the per-rank result summary at the end.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
+dominant kernel and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N == 1 only).
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+WORKLOADS = {
+    # name: rows, cols, window, n_rect, rect_min, rect_max, batch, max_candidates, max_keypoints
+    "1080p_2k": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=64, max_cand=32768, max_kp=4096,
+                     desc="1920x1080, ~2k keypoints/frame (shipped YAML: t=20 N=12 window=12), detect+describe+match-to-previous"),
+    "c2": dict(rows=480, cols=640, window=6, n_rect=5000, rmin=3, rmax=16, batch=256, max_cand=32768, max_kp=4096,
+               desc="640x480, ~2k keypoints/frame (SuppressionWindowSize 6), detect+describe+match-to-previous"),
+    "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=32, max_cand=131072, max_kp=16384,
+               desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
+}
+SEED = 0x5EED0051
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_INT_PEAK_GOPS = 256 * 4 * 32 * 2.4  # CUs x SIMDs x 32 lanes/clk x 2.4 GHz = 78.6 Tera lane-ops/s
+# (one full-rate int32 VALU op per lane per clock; SURVEY.md 8d quotes the same peak per
+#  wave-instruction slot as 256 x 64 x 2.4 GHz / 2 clocks-per-wave64-instruction)
+
+
+def load_product():
+    name = "slam_cin0051_amd"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "slam-cin0051_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def shard_seed(rank):
+    """One independent synthetic stream per rank."""
+    return SEED + rank
+
+
+def summarize(values):
+    return float(sum(values)) / max(1, len(values))
+
+
+def cpu_baseline(mod, wl, frames, budget_s=15.0):
+    """The restated reference CPU path (oracle/, single thread) on a bounded sample of the SAME
+    frames: detectAndCompute + match(frame k, frame k-1) with keypoints."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+
+    o = oracle_binding.load()
+    P = oracle_binding.DetectorParams(20, 12, 1, wl["window"], 31, 256)
+    M = oracle_binding.MatcherParams(0, 20, 1, 0.5)
+    t0 = time.perf_counter()
+    prev = o.detect_and_compute(frames[-1], P)  # predecessor of frame 0, not counted
+    t_first = time.perf_counter() - t0
+    n = int(max(2, min(len(frames), budget_s / max(t_first, 1e-3))))
+    t0 = time.perf_counter()
+    kps_total = 0
+    for k in range(n):
+        cur = o.detect_and_compute(frames[k], P)
+        o.match(cur[1], prev[1], cur[0], prev[0], M)
+        kps_total += len(cur[0])
+        prev = cur
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "%d frames of the same workload, CPU restatement of the reference path (oracle/slam_oracle.cpp, "
+                  "g++ -O3 -ffp-contract=off, 1 thread), %.1f s, %.0f keypoints/frame" % (n, dt, kps_total / n),
+        "matched_keypoints_per_s": kps_total / dt,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p_2k", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch  # loaded first: libslamx then binds to the HIP runtime already in the process
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+    n_gpus = world
+
+    mod = load_product()
+    import numpy as np
+
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    ctx = mod.Context(local_rank)  # no CPU fallback: raises without a HIP device
+    det = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), ctx)
+    matcher = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx)  # FilterMatches 0
+    seed = shard_seed(rank)
+    frames = np.stack([mod.synth_frame(seed, k, wl["rows"], wl["cols"], wl["n_rect"], wl["rmin"], wl["rmax"]) for k in range(B)])
+    batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
+    batch.upload(frames)
+    ctx.synchronize()
+
+    def step():
+        batch.detect_and_compute(B)
+        batch.match_consecutive(matcher, B, use_keypoints=True, first_train_frame=B - 1)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ncand, nkp, nmatch = batch.counts(B)  # also surfaces capacity overflows loudly
+
+    K = args.steps
+    batch.set_profiling(min(K, 256))  # hipEvents between the kernels of every timed step
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the one collective of the path: gather every rank's per-frame result summary
+        # (keypoints, matches); map points replace this payload once triangulation lands (8e)
+        mine = torch.tensor([float(nkp.sum()), float(nmatch.sum()), float(ncand.sum())], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        tot_kp = sum(float(g[0]) for g in gathered)
+        tot_match = sum(float(g[1]) for g in gathered)
+        tot_cand = sum(float(g[2]) for g in gathered)
+    else:
+        tot_kp, tot_match, tot_cand = float(nkp.sum()), float(nmatch.sum()), float(ncand.sum())
+
+    # per-stage device time, averaged over the timed steps (events on the kernels' own stream)
+    sets = min(K, 256)
+    stage = {s: 0.0 for s in mod.STAGES}
+    for i in range(sets):
+        ms = batch.stage_ms(i)
+        for s in mod.STAGES:
+            stage[s] += ms[s] / sets
+
+    if rank == 0:
+        frames_total = B * K * n_gpus
+        fps = frames_total / elapsed
+        M = tot_cand / (B * n_gpus)
+        N = tot_kp / (B * n_gpus)
+        px = wl["rows"] * wl["cols"]
+        # algorithmic work per launch (one launch = the whole batch of B frames), SURVEY.md 8d
+        bytes_per_frame = {"fast": px + px / 8.0, "blur": 2.0 * px, "describe": (961 + 2 * 46) * N + 52 * N,
+                           "expand": 8.0 * px / 64 + 17 * M + 8 * M, "scan": 12.0 * px / 64,
+                           "sort": 16.0 * M, "nms": 16.0 * M, "emit": 24.0 * N}
+        dom = max(stage, key=lambda s: stage[s])
+        if dom == "match":
+            ops = 16.0 * N * N * B  # 8 xor + 8 popcount-accumulate per 256-bit pair
+            achieved = ops / (stage[dom] * 1e-3) / 1e9
+            roof = {"kernel": "match_kernel<8>", "bound": "valu-int32 (neither hbm nor mfma: SURVEY.md 8d)",
+                    "achieved": achieved, "peak": VALU_INT_PEAK_GOPS, "unit": "Gop/s", "frac": achieved / VALU_INT_PEAK_GOPS,
+                    "algorithmic_per_launch": ops, "traffic": None}
+        else:
+            byts = bytes_per_frame[dom] * B
+            achieved = byts / (stage[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "algorithmic_per_launch": byts, "traffic": None}
+        roof["avg_launch_ms"] = stage[dom]
+        # the HBM-bound front-end as a whole: B_fe = 4WH + 16M + 52N bytes per frame
+        fe_ms = sum(stage[s] for s in ("fast", "scan", "expand", "sort", "nms", "blur", "describe"))
+        b_fe = (4.0 * px + 16.0 * M + 52.0 * N) * B
+        out = {
+            "metric": "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X",
+            "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["desc"], "name": args.workload, "frames_per_step_per_gpu": B,
+                       "candidates_per_frame": M, "keypoints_per_frame": N, "matches_per_frame": tot_match / (B * n_gpus),
+                       "parallelism": "frames sharded one stream per GPU (dp%d), no data-path collective" % n_gpus},
+            "matched_keypoints_per_s": N * fps,
+            "stage_ms_per_step": stage,
+            "roofline": roof,
+            "frontend_hbm": {"achieved": b_fe / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
+            "device": ctx.device_name,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mod, wl, frames)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,10 +157,13 @@ int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, pt
                        ptrdiff_t frame_stride);
 /* detectAndCompute on frames 0..nframes-1 (async on the context stream). */
 int slamx_batch_detect_and_compute(slamx_batch* b, int nframes);
-/* match(desc[k], desc[k-1], kps[k], kps[k-1]) for k = 1..nframes-1 (frame 0 has no previous
- * frame); use_keypoints selects the jump-radius penalty.  Results stay on the device in
- * query order, before filterAndSortMatches (async). */
-int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints);
+/* match(desc[k], desc[k-1], kps[k], kps[k-1]) for k = 1..nframes-1; frame 0 is matched against
+ * frame first_train_frame of the same batch (the slot a streaming caller keeps the previous
+ * batch's last frame in), or not at all when first_train_frame < 0.  use_keypoints selects the
+ * jump-radius penalty.  Results stay on the device in query order, before
+ * filterAndSortMatches (async). */
+int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints,
+                                  int first_train_frame);
 /* Synchronize and copy out.  A frame whose candidate/keypoint count exceeded the shape's
  * capacity makes these return SLAMX_ERR_CAPACITY. */
 int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches);
@@ -168,8 +171,11 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
 /* Matches of frame k against frame k-1, with the matcher's filter step applied on request. */
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
                                  int cap, int* n);
-/* Per-stage device time of the last batch call, from hipEvents recorded on the stream
- * (requires slamx_batch_set_profiling(b, 1); adds events, no synchronization). */
+/* Per-stage device time from hipEvents recorded on the context stream between the kernels (no
+ * synchronization is added).  slamx_batch_set_profiling(b, n_sets) keeps n_sets event sets
+ * (0 = off); the i-th detect_and_compute call after it records into set i % n_sets, and the
+ * match call that follows uses the same set.  slamx_batch_stage_ms synchronizes and reads one
+ * set.  Stage MATCH is the all-pairs kernel alone; EMIT is the ratio-test/compaction kernel. */
 #define SLAMX_STAGE_FAST 0
 #define SLAMX_STAGE_SCAN 1
 #define SLAMX_STAGE_EXPAND 2
@@ -178,9 +184,10 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
 #define SLAMX_STAGE_BLUR 5
 #define SLAMX_STAGE_DESCRIBE 6
 #define SLAMX_STAGE_MATCH 7
-#define SLAMX_STAGE_COUNT 8
-int slamx_batch_set_profiling(slamx_batch* b, int enable);
-int slamx_batch_stage_ms(slamx_batch* b, float* ms /* SLAMX_STAGE_COUNT entries */);
+#define SLAMX_STAGE_EMIT 8
+#define SLAMX_STAGE_COUNT 9
+int slamx_batch_set_profiling(slamx_batch* b, int n_sets);
+int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms /* SLAMX_STAGE_COUNT entries */);
 
 /* ---- deterministic synthetic frames, host side, for tests and bench ---- */
 /* Frame k of the sequence with the given seed: background 96, n_rect filled rectangles with

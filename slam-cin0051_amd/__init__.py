@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamx.so")
 
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE = range(6)
-STAGES = ("fast", "scan", "expand", "sort", "nms", "blur", "describe", "match")
+STAGES = ("fast", "scan", "expand", "sort", "nms", "blur", "describe", "match", "emit")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4")], align=False
@@ -130,12 +130,12 @@ def load_library():
     lib.slamx_batch_frames.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.slamx_batch_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
     lib.slamx_batch_detect_and_compute.argtypes = [vp, C.c_int]
-    lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     lib.slamx_batch_counts.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.slamx_batch_download.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
-    lib.slamx_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     lib.slamx_synth_frame.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     _lib = lib
     return lib
@@ -427,8 +427,9 @@ class Batch:
     def detect_and_compute(self, nframes):
         _check(self.lib.slamx_batch_detect_and_compute(self.h, nframes))
 
-    def match_consecutive(self, matcher, nframes, use_keypoints=True):
-        _check(self.lib.slamx_batch_match_consecutive(self.h, matcher.h, nframes, 1 if use_keypoints else 0))
+    def match_consecutive(self, matcher, nframes, use_keypoints=True, first_train_frame=-1):
+        _check(self.lib.slamx_batch_match_consecutive(self.h, matcher.h, nframes, 1 if use_keypoints else 0,
+                                                      first_train_frame))
 
     def counts(self, nframes):
         a, b, c = (np.zeros(nframes, np.int32) for _ in range(3))
@@ -459,10 +460,10 @@ class Batch:
                                                      out.shape[0], C.byref(n)))
         return out[: n.value].copy()
 
-    def set_profiling(self, enable=True):
-        _check(self.lib.slamx_batch_set_profiling(self.h, 1 if enable else 0))
+    def set_profiling(self, n_sets=1):
+        _check(self.lib.slamx_batch_set_profiling(self.h, n_sets))
 
-    def stage_ms(self):
+    def stage_ms(self, set_index=0):
         ms = (C.c_float * len(STAGES))()
-        _check(self.lib.slamx_batch_stage_ms(self.h, ms))
+        _check(self.lib.slamx_batch_stage_ms(self.h, set_index, ms))
         return dict(zip(STAGES, [float(x) for x in ms]))

@@ -25,11 +25,11 @@ constexpr int TILE = 256;
 constexpr float MAX_JUMP_RADIUS = 500.0f;  // uint32 500 converted to float in both comparisons
 
 template <int WORDS>
-__global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame) {
+__global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
     __shared__ uint32_t tdesc[TILE * WORDS];
     __shared__ float2 txy[TILE];
     const int qf = first_query_frame + blockIdx.y;
-    const int tf = qf - 1;
+    const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
     const int i = static_cast<int>(blockIdx.x) * TILE + static_cast<int>(threadIdx.x);
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
 
 // Any descriptor width (bytes): byte-wise popcount straight from global memory.  Correctness
 // path for widths that are not 8/16/32/64 bytes.
-__global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int first_query_frame) {
+__global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
     const int qf = first_query_frame + blockIdx.y;
-    const int tf = qf - 1;
+    const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
     const bool use_kp = mv.kps != nullptr;
@@ -146,12 +146,12 @@ __global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int fi
 }
 
 // Ratio test (feature_matcher.cpp:175-187) + emission in query order.  One workgroup per pair.
-__global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_query_frame) {
+__global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry;
     const int qf = first_query_frame + blockIdx.x;
     const int n1 = mv.n_kp[qf];
-    const int n2 = mv.n_kp[qf - 1];
+    const int n2 = mv.n_kp[qf == 0 ? first_train_frame : qf - 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
@@ -207,30 +207,34 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
 
 }  // namespace
 
-void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, hipStream_t stream) {
+void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
+                              hipStream_t stream, hipEvent_t ev_mid) {
     if (npairs <= 0) {
         return;
     }
     dim3 grid((mv.maxK + TILE - 1) / TILE, npairs);
     switch (mv.width) {
         case 8:
-            hipLaunchKernelGGL(match_kernel<2>, grid, dim3(256), 0, stream, mv, first_query_frame);
+            hipLaunchKernelGGL(match_kernel<2>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
             break;
         case 16:
-            hipLaunchKernelGGL(match_kernel<4>, grid, dim3(256), 0, stream, mv, first_query_frame);
+            hipLaunchKernelGGL(match_kernel<4>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
             break;
         case 32:
-            hipLaunchKernelGGL(match_kernel<8>, grid, dim3(256), 0, stream, mv, first_query_frame);
+            hipLaunchKernelGGL(match_kernel<8>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
             break;
         case 64:
-            hipLaunchKernelGGL(match_kernel<16>, grid, dim3(256), 0, stream, mv, first_query_frame);
+            hipLaunchKernelGGL(match_kernel<16>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
             break;
         default: {
             dim3 g(grid_x(mv.maxK, 256, npairs), npairs);
-            hipLaunchKernelGGL(match_generic_kernel, g, dim3(256), 0, stream, mv, first_query_frame);
+            hipLaunchKernelGGL(match_generic_kernel, g, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
         }
     }
-    hipLaunchKernelGGL(emit_kernel, dim3(npairs), dim3(1024), 0, stream, mv, first_query_frame);
+    if (ev_mid != nullptr) {
+        (void)hipEventRecord(ev_mid, stream);
+    }
+    hipLaunchKernelGGL(emit_kernel, dim3(npairs), dim3(1024), 0, stream, mv, first_query_frame, first_train_frame);
 }
 
 }  // namespace slamx

@@ -104,9 +104,14 @@ struct slamx_batch {
     int* n_matches = nullptr;
     int2* best = nullptr;
     int* second = nullptr;
-    bool profiling = false;
-    hipEvent_t ev[SLAMX_STAGE_COUNT + 2] = {};
-    bool ev_valid[SLAMX_STAGE_COUNT + 2] = {};
+    // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
+    // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS|5|BLUR|6|DESCRIBE|7|MATCH|8|EMIT|9
+    static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
+    int n_sets = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<char> ev_valid;
+    long long calls = 0;  // detect_and_compute calls since profiling was switched on
+    int cur_set = 0;
     int last_frames = 0;
 };
 
@@ -206,12 +211,22 @@ int status_to_error(int st, int frame) {
 }
 
 void record(slamx_batch* b, int idx) {
-    if (b->profiling) {
-        if (b->ev[idx] == nullptr) {
-            (void)hipEventCreate(&b->ev[idx]);
+    if (b->n_sets > 0) {
+        const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx;
+        (void)hipEventRecord(b->ev[k], b->det->ctx->stream);
+        b->ev_valid[k] = 1;
+    }
+}
+bool recorded(const slamx_batch* b, int idx) {
+    return b->n_sets > 0 && b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx] != 0;
+}
+void begin_set(slamx_batch* b) {
+    if (b->n_sets > 0) {
+        b->cur_set = static_cast<int>(b->calls % b->n_sets);
+        b->calls++;
+        for (int i = 0; i < slamx_batch::NEV; ++i) {
+            b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + i] = 0;
         }
-        (void)hipEventRecord(b->ev[idx], b->det->ctx->stream);
-        b->ev_valid[idx] = true;
     }
 }
 
@@ -242,7 +257,7 @@ void enqueue_detect(slamx_batch* b, int nframes) {
 void enqueue_compute(slamx_batch* b, int nframes) {
     hipStream_t s = b->det->ctx->stream;
     const DetectorParams p = params_of(b->det);
-    if (!b->ev_valid[5]) {
+    if (!recorded(b, 5)) {
         record(b, 5);
     }
     launch_blur(b->v, b->det->weights_dev, nframes, s);
@@ -631,9 +646,7 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
         return SLAMX_OK;
     }
     HIP_TRY(hipSetDevice(b->det->ctx->device));
-    for (auto& ok : b->ev_valid) {
-        ok = false;
-    }
+    begin_set(b);
     enqueue_detect(b, nframes);
     enqueue_compute(b, nframes);
     b->last_frames = nframes;
@@ -641,9 +654,10 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
     return SLAMX_OK;
 }
 
-int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints) {
-    if (nframes < 0 || nframes > b->shape.max_frames) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
+int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints,
+                                  int first_train_frame) {
+    if (nframes < 0 || nframes > b->shape.max_frames || first_train_frame >= b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes / first_train_frame out of range");
     }
     if (m->cfg.distance_type != 0) {
         return fail(SLAMX_ERR_RUNTIME, "L2 distance requires float descriptors. Use the float overload.");
@@ -669,11 +683,22 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     mv.width = b->v.width;
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
-    if (!b->ev_valid[7]) {
+    if (!recorded(b, 7)) {
         record(b, 7);
     }
-    launch_match_consecutive(mv, 1, nframes - 1, b->det->ctx->stream);
-    record(b, 8);
+    hipEvent_t mid = nullptr;
+    if (b->n_sets > 0) {
+        const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + 8;
+        mid = b->ev[k];
+        b->ev_valid[k] = 1;
+    }
+    if (first_train_frame >= 0) {
+        launch_match_consecutive(mv, 0, nframes, first_train_frame, b->det->ctx->stream, mid);
+    } else {
+        launch_match_consecutive(mv, 1, nframes - 1, -1, b->det->ctx->stream, mid);
+        HIP_TRY(hipMemsetAsync(b->n_matches, 0, sizeof(int), b->det->ctx->stream));
+    }
+    record(b, 9);
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
 }
@@ -695,9 +720,6 @@ int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32
     if (n_matches != nullptr) {
         if (b->n_matches != nullptr) {
             HIP_TRY(hipMemcpy(n_matches, b->n_matches, sizeof(int) * nframes, hipMemcpyDeviceToHost));
-            if (nframes > 0) {
-                n_matches[0] = 0;  // frame 0 has no previous frame
-            }
         } else {
             std::memset(n_matches, 0, sizeof(int) * nframes);
         }
@@ -737,7 +759,7 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
 
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
                                  int cap, int* n) {
-    if (frame < 1 || frame >= b->shape.max_frames || b->matches == nullptr) {
+    if (frame < 0 || frame >= b->shape.max_frames || b->matches == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or no matches computed");
     }
     HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
@@ -763,19 +785,39 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
     return SLAMX_OK;
 }
 
-int slamx_batch_set_profiling(slamx_batch* b, int enable) {
-    b->profiling = enable != 0;
+int slamx_batch_set_profiling(slamx_batch* b, int n_sets) {
+    if (n_sets < 0 || n_sets > 4096) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "n_sets out of range");
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    for (auto& e : b->ev) {
+        if (e != nullptr) {
+            (void)hipEventDestroy(e);
+        }
+    }
+    b->ev.assign(static_cast<size_t>(n_sets) * slamx_batch::NEV, nullptr);
+    b->ev_valid.assign(static_cast<size_t>(n_sets) * slamx_batch::NEV, 0);
+    b->n_sets = n_sets;
+    b->calls = 0;
+    b->cur_set = 0;
+    for (auto& e : b->ev) {
+        HIP_TRY(hipEventCreate(&e));
+    }
     return SLAMX_OK;
 }
 
-int slamx_batch_stage_ms(slamx_batch* b, float* ms) {
+int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms) {
+    if (set_index < 0 || set_index >= b->n_sets) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "profiling set out of range");
+    }
     HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
-    // event i brackets: 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS|5|BLUR|6|DESCRIBE|7|MATCH|8
+    const size_t base = static_cast<size_t>(set_index) * slamx_batch::NEV;
     for (int s = 0; s < SLAMX_STAGE_COUNT; ++s) {
         ms[s] = 0.0f;
-        if (b->ev_valid[s] && b->ev_valid[s + 1]) {
+        if (b->ev_valid[base + s] && b->ev_valid[base + s + 1]) {
             float t = 0.0f;
-            if (hipEventElapsedTime(&t, b->ev[s], b->ev[s + 1]) == hipSuccess) {
+            if (hipEventElapsedTime(&t, b->ev[base + s], b->ev[base + s + 1]) == hipSuccess) {
                 ms[s] = t;
             }
         }
@@ -790,9 +832,7 @@ int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, pt
     SLAMX_TRY(ensure_single(det, rows, cols, 0));
     slamx_batch* b = det->single;
     SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
-    for (auto& ok : b->ev_valid) {
-        ok = false;
-    }
+    begin_set(b);
     enqueue_detect(b, 1);
     HIP_TRY(hipGetLastError());
     return slamx_batch_download(b, 0, kps, nullptr, cap, n);
@@ -818,9 +858,7 @@ int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, p
     HIP_TRY(hipMemcpyAsync(b->v.n_kp, &n, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));  // &n must stay alive until the copy is done
-    for (auto& ok : b->ev_valid) {
-        ok = false;
-    }
+    begin_set(b);
     enqueue_compute(b, 1);
     HIP_TRY(hipGetLastError());
     int cnt = 0;
@@ -1096,7 +1134,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     mv.width = width1;
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
-    launch_match_consecutive(mv, 1, 1, s);
+    launch_match_consecutive(mv, 1, 1, -1, s, nullptr);
     HIP_TRY(hipGetLastError());
     int cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, m->n_matches + 1, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -93,7 +93,11 @@ struct MatchView {
     int use_ratio;
     float ratio;
 };
-void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, hipStream_t stream);
+// query frames first_query_frame .. first_query_frame+npairs-1; train = query-1, except that
+// query frame 0 uses first_train_frame.  ev_mid (optional) is recorded between the all-pairs
+// kernel and the emit kernel.
+void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
+                              hipStream_t stream, hipEvent_t ev_mid);
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream);

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/oracle_golden.npz: outputs of the CPU oracle (oracle/slam_oracle.cpp) on the
+reference's own input fixtures (gray PNGs + shipped YAML, copied under tests/golden/ref_data).
+
+The reference cannot be built in this image and holds no golden vectors of its own (SURVEY.md
+8c), so these vectors pin the ORACLE (libstdc++ GCC 11.4 / glibc 2.35 behaviour inherited through
+the same std:: / libm calls the reference makes); they guard against toolchain drift between this
+container and the GPU box and against accidental edits of the restatement.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_binding  # noqa: E402
+from conftest import load_gray  # noqa: E402
+
+IMAGES = ["images/0000000000.png", "images/0000000001.png", "images_test_loop/0.png", "images_test_loop/1.png",
+          "images_test_loop/2.png", "images_test_loop/3.png"]
+
+
+def build():
+    o = oracle_binding.load()
+    P = oracle_binding.DetectorParams(20, 12, 1, 12, 31, 256)       # test/data/feature_detector.yml
+    M = oracle_binding.MatcherParams(1, 20, 1, 0.5)                  # test/data/feature_matcher.yml
+    out = {"pattern": o.brief_pattern(31, 256)}
+    feats = {}
+    for name in IMAGES:
+        img = load_gray(os.path.join(HERE, "ref_data", name))
+        key = name.replace("/", "_").replace(".png", "")
+        cand = o.fast_candidates(img, P)
+        kps = o.detect(img, P)
+        kps2, desc, mom = o.compute(img, kps, P, want_moments=True)
+        out[key + "_cand_xys"] = np.stack([cand["x"], cand["y"], cand["response"]], 1).astype(np.uint16)
+        out[key + "_kps"] = kps2.view(np.uint8).reshape(len(kps2), 20)
+        out[key + "_desc"] = desc
+        out[key + "_moments"] = mom.astype(np.int32)
+        out[key + "_blur_sum"] = np.array([int(o.gaussian_blur(img).astype(np.uint64).sum())], np.uint64)
+        feats[name] = (kps2, desc)
+    for a, b, tag in [("images/0000000000.png", "images/0000000001.png", "kitti01"),
+                      ("images_test_loop/0.png", "images_test_loop/1.png", "loop01")]:
+        (k1, d1), (k2, d2) = feats[a], feats[b]
+        out[tag + "_match_kp"] = o.match(d1, d2, k1, k2, M).view(np.uint8).reshape(-1, 12)       # test_feature_matcher.cpp:62
+        out[tag + "_match_nokp"] = o.match(d1, d2, None, None, M).view(np.uint8).reshape(-1, 12)  # test_pose_estimator.cpp:138
+        M0 = oracle_binding.MatcherParams(0, 20, 1, 0.5)
+        out[tag + "_best_kp"] = o.match(d1, d2, k1, k2, M0).view(np.uint8).reshape(-1, 12)
+    return out
+
+
+if __name__ == "__main__":
+    data = build()
+    path = os.path.join(HERE, "oracle_golden.npz")
+    np.savez_compressed(path, **data)
+    print("wrote", path, os.path.getsize(path), "bytes;", {k: v.shape for k, v in data.items() if "kps" in k})
