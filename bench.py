@@ -61,8 +61,16 @@ def shard_seed(rank):
     return SEED + rank
 
 
-def summarize(values):
-    return float(sum(values)) / max(1, len(values))
+def gather_summary(dist, values, device):
+    """The one collective of the path: every rank contributes its result summary
+    [keypoints, matches, candidates] and receives everyone's (RCCL all_gather on the GPU box,
+    gloo in the CPU tests).  Returns the per-rank rows as a list of lists."""
+    import torch
+
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    return [[float(x) for x in g.tolist()] for g in gathered]
 
 
 def cpu_baseline(mod, wl, frames, budget_s=15.0):
@@ -162,12 +170,10 @@ def main():
         elapsed = float(t.item())
         # the one collective of the path: gather every rank's per-frame result summary
         # (keypoints, matches); map points replace this payload once triangulation lands (8e)
-        mine = torch.tensor([float(nkp.sum()), float(nmatch.sum()), float(ncand.sum())], dtype=torch.float64, device="cuda")
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        tot_kp = sum(float(g[0]) for g in gathered)
-        tot_match = sum(float(g[1]) for g in gathered)
-        tot_cand = sum(float(g[2]) for g in gathered)
+        rows = gather_summary(dist, [nkp.sum(), nmatch.sum(), ncand.sum()], "cuda")
+        tot_kp = sum(r[0] for r in rows)
+        tot_match = sum(r[1] for r in rows)
+        tot_cand = sum(r[2] for r in rows)
     else:
         tot_kp, tot_match, tot_cand = float(nkp.sum()), float(nmatch.sum()), float(ncand.sum())
 

@@ -1,0 +1,118 @@
+// slam/frontend/feature_detector.hpp -- drop-in facade for the reference's
+// include/slam/frontend/feature_detector.hpp: same namespace, type and method names, argument
+// meaning, output semantics and exception types; every method forwards to the C ABI (slamx.h),
+// which runs the HIP kernels.  No CPU implementation exists behind this class.
+#pragma once
+
+#include <cstdlib>
+#include <filesystem>
+#include <utility>
+#include <vector>
+
+#include <slam/common/common.hpp>
+#include <slam/frontend/slamx_runtime.hpp>
+
+namespace slam {
+
+namespace constants {
+constexpr int CIRCLE_PERIMETER = 16;
+constexpr int BRIEF_PAIRS = 8;
+constexpr int BLUR_KERNEL_SIZE = 5;
+constexpr float DEFAULT_KEYPOINT_SIZE = 6.0F;
+}  // namespace constants
+
+// feature_detector.hpp:28-38 -- identical layout to slamx_keypoint (5 floats).
+struct Keypoint {
+    float x{};
+    float y{};
+    float size{};
+    float angle{};
+    float response{};
+
+    Keypoint() = default;
+    Keypoint(float X, float Y, float size = constants::DEFAULT_KEYPOINT_SIZE) : x(X), y(Y), size(size) {}
+};
+static_assert(sizeof(Keypoint) == sizeof(slamx_keypoint), "Keypoint must match the C ABI layout");
+
+class FeatureDetector {
+public:
+    // feature_detector.hpp:53-107: reads the six YAML keys, validates, generates the BRIEF pattern.
+    explicit FeatureDetector(const std::filesystem::path& configPath) {
+        slamx_detector_config cfg{};
+        detail::check(slamx_detector_config_load(configPath.string().c_str(), &cfg));
+        detail::check(slamx_detector_create(detail::default_context(), &cfg, &m_handle));
+    }
+    ~FeatureDetector() { slamx_detector_destroy(m_handle); }
+    FeatureDetector(const FeatureDetector&) = delete;
+    FeatureDetector& operator=(const FeatureDetector&) = delete;
+
+    // feature_detector.cpp:8-18
+    void detect(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints) {
+        keypoints.clear();
+        run_sized(image, keypoints, nullptr);
+    }
+
+    // feature_detector.cpp:20-47 (angles are written back into `keypoints`)
+    void compute(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints, DescriptorMatrix& descriptors) {
+        if (keypoints.empty()) {
+            descriptors = DescriptorMatrix(0, 0);
+            return;
+        }
+        const int width = slamx_detector_descriptor_width(m_handle);
+        descriptors.resize(static_cast<std::ptrdiff_t>(keypoints.size()), width);
+        detail::check(slamx_compute(m_handle, image.data(), static_cast<int>(image.rows()), static_cast<int>(image.cols()),
+                                    static_cast<std::ptrdiff_t>(image.cols()),
+                                    reinterpret_cast<slamx_keypoint*>(keypoints.data()),
+                                    static_cast<int>(keypoints.size()), descriptors.data()));
+    }
+
+    // feature_detector.cpp:49-54
+    void detectAndCompute(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints,
+                          DescriptorMatrix& descriptors) {
+        keypoints.clear();
+        run_sized(image, keypoints, &descriptors);
+    }
+
+private:
+    // Capacity-checked output sizing over the two-call C ABI.
+    void run_sized(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints, DescriptorMatrix* descriptors) {
+        const int rows = static_cast<int>(image.rows());
+        const int cols = static_cast<int>(image.cols());
+        const int width = slamx_detector_descriptor_width(m_handle);
+        int cap = std::max(1024, rows * cols / 16);
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            keypoints.resize(static_cast<size_t>(cap));
+            std::vector<uint8_t> desc;
+            int n = 0;
+            int rc;
+            if (descriptors != nullptr) {
+                desc.resize(static_cast<size_t>(cap) * static_cast<size_t>(width));
+                rc = slamx_detect_and_compute(m_handle, image.data(), rows, cols, cols,
+                                              reinterpret_cast<slamx_keypoint*>(keypoints.data()), desc.data(), cap, &n);
+            } else {
+                rc = slamx_detect(m_handle, image.data(), rows, cols, cols,
+                                  reinterpret_cast<slamx_keypoint*>(keypoints.data()), cap, &n);
+            }
+            if (rc == SLAMX_ERR_CAPACITY && n > cap) {
+                cap = n;
+                continue;
+            }
+            detail::check(rc);
+            keypoints.resize(static_cast<size_t>(n));
+            if (descriptors != nullptr) {
+                if (n == 0) {
+                    *descriptors = DescriptorMatrix(0, 0);
+                } else {
+                    descriptors->resize(n, width);
+                    std::copy(desc.begin(), desc.begin() + static_cast<std::ptrdiff_t>(n) * width, descriptors->data());
+                }
+            }
+            return;
+        }
+        throw std::runtime_error("keypoint capacity negotiation failed");
+    }
+
+    slamx_detector* m_handle{};
+};
+
+}  // namespace slam

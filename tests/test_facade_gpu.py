@@ -1,0 +1,75 @@
+"""The C++17 facade (include/slam/...: the reference's class names over the C ABI) exercised by the
+counterparts of the reference's own test executables (tools/test_feature_*.cpp), on the same
+images and YAML files; results are dumped and compared bit for bit with the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_gray
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "tools", "bin")
+
+
+def _run(args):
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout.decode()
+
+
+def test_feature_detector_program(slamx, oracle, ref_data, tmp_path):
+    img_path = os.path.join(ref_data, "images", "0000000000.png")
+    out = str(tmp_path / "det.bin")
+    text = _run([os.path.join(BIN, "test_feature_detector"), os.path.join(ref_data, "feature_detector.yml"), img_path, out])
+    assert "Detected" in text and "DetectAndCompute" in text
+    img = load_gray(img_path)
+    P = oracle.det_params(slamx.load_detector_config(os.path.join(ref_data, "feature_detector.yml")))
+    k_ref, d_ref = oracle.detect_and_compute(img, P)
+    raw = open(out, "rb").read()
+    off = 0
+    for _ in range(2):  # detect+compute, then detectAndCompute
+        (n,) = struct.unpack_from("<i", raw, off)
+        off += 4
+        kps = np.frombuffer(raw, slamx.KEYPOINT_DTYPE, n, off)
+        off += 20 * n
+        assert kps.tobytes() == k_ref.tobytes()
+    for _ in range(2):
+        r, c = struct.unpack_from("<ii", raw, off)
+        off += 8
+        d = np.frombuffer(raw, np.uint8, r * c, off).reshape(r, c)
+        off += r * c
+        assert np.array_equal(d, d_ref)
+    assert off == len(raw)
+
+
+def test_feature_matcher_program(slamx, oracle, ref_data, tmp_path):
+    a = os.path.join(ref_data, "images", "0000000000.png")
+    b = os.path.join(ref_data, "images", "0000000001.png")
+    out = str(tmp_path / "match.bin")
+    text = _run([os.path.join(BIN, "test_feature_matcher"), os.path.join(ref_data, "feature_detector.yml"),
+                 os.path.join(ref_data, "feature_matcher.yml"), a, b, out])
+    assert "Found" in text
+    P = oracle.det_params(slamx.load_detector_config(os.path.join(ref_data, "feature_detector.yml")))
+    M = oracle.match_params(slamx.load_matcher_config(os.path.join(ref_data, "feature_matcher.yml")))
+    k1, d1 = oracle.detect_and_compute(load_gray(a), P)
+    k2, d2 = oracle.detect_and_compute(load_gray(b), P)
+    raw = open(out, "rb").read()
+    (ex,) = struct.unpack_from("<i", raw, 0)
+    assert ex == 3, "std::invalid_argument / std::runtime_error not raised as the reference does"
+    off = 4
+    for ref in (oracle.match(d1, d2, k1, k2, M), oracle.match(d1, d2, None, None, M)):
+        (n,) = struct.unpack_from("<i", raw, off)
+        off += 4
+        m = np.frombuffer(raw, slamx.MATCH_DTYPE, n, off)
+        off += 12 * n
+        assert m.tobytes() == ref.tobytes()
+
+
+def test_cli_runs_the_pipeline(ref_data):
+    text = _run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images_test_loop")])
+    lines = [l for l in text.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 4 and "59 keypoints" in lines[0]
+    assert _run([os.path.join(BIN, "cli"), "-h"]).startswith("cli -c")

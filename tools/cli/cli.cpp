@@ -1,0 +1,89 @@
+// cli -- keeps the reference's flag surface (tools/cli/cli.cpp:20: getopt "hv:c:") but, unlike the
+// reference's stub SLAMModel (src/model/model.cpp:5-7 is empty, run() is never defined), actually
+// drives the hot path: frame directory -> detectAndCompute -> match(frame k, frame k-1).
+//   cli -c <config dir with feature_detector.yml + feature_matcher.yml> -v <directory of PNG frames>
+#include <getopt.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <filesystem>
+#include <string>
+#include <vector>
+
+#include <slam/frontend/feature_detector.hpp>
+#include <slam/frontend/feature_matcher.hpp>
+
+#include "../png_gray.hpp"
+
+static void printHelp() {
+    std::printf("cli -c <config_dir> -v <stream_path>\n"
+                "  -c  directory holding feature_detector.yml and feature_matcher.yml\n"
+                "  -v  directory of 8-bit PNG frames (processed in lexical order)\n"
+                "  -h  this help\n");
+}
+
+int main(int argc, char** argv) {
+    int c{};
+    std::string streamPath{};
+    std::string configPath{};
+    while ((c = getopt(argc, argv, "hv:c:")) != -1) {
+        switch (c) {
+            case 'h':
+                printHelp();
+                return 0;
+            case 'v':
+                streamPath = optarg;
+                break;
+            case 'c':
+                configPath = optarg;
+                break;
+            default:
+                printHelp();
+                return 0;
+        }
+    }
+    if (streamPath.empty() || configPath.empty()) {
+        printHelp();
+        return 0;
+    }
+    try {
+        namespace fs = std::filesystem;
+        slam::FeatureDetector detector(fs::path(configPath) / "feature_detector.yml");
+        slam::FeatureMatcher matcher(fs::path(configPath) / "feature_matcher.yml");
+        // Preprocessor::prepareDirectory, src/preprocessing/preprocessor.cpp:24-41
+        std::vector<fs::path> files;
+        for (const auto& entry : fs::directory_iterator(streamPath)) {
+            if (entry.is_regular_file() && entry.path().extension() == ".png") {
+                files.push_back(entry.path());
+            }
+        }
+        std::sort(files.begin(), files.end());
+        std::vector<slam::Keypoint> prevKps;
+        slam::DescriptorMatrix prevDesc;
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t totalKps = 0, totalMatches = 0;
+        for (size_t i = 0; i < files.size(); ++i) {
+            slam::EigenGrayMatrix image = slamx_tools::read_png_gray(files[i].string());
+            std::vector<slam::Keypoint> kps;
+            slam::DescriptorMatrix desc;
+            detector.detectAndCompute(image, kps, desc);
+            std::vector<slam::Match> matches;
+            if (i > 0 && !kps.empty() && !prevKps.empty()) {
+                matcher.match(desc, prevDesc, matches, kps, prevKps);
+            }
+            std::printf("frame %zu %s: %zu keypoints, %zu matches to previous\n", i, files[i].filename().c_str(),
+                        kps.size(), matches.size());
+            totalKps += kps.size();
+            totalMatches += matches.size();
+            prevKps = std::move(kps);
+            prevDesc = std::move(desc);
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("%zu frames, %zu keypoints, %zu matches in %.3f s\n", files.size(), totalKps, totalMatches, dt);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "An error occurred: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
