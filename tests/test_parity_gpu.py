@@ -135,14 +135,14 @@ def test_detect_reference_images(det, oracle, P, ref_data, name):
 def test_detect_windows_synthetic(slamx, oracle, window):
     d = slamx.FeatureDetector(cfg_of(slamx, window=window))
     Pp = oracle.det_params(d.cfg)
-    for k, (rows, cols, nr) in enumerate([(480, 640, 400), (240, 333, 150), (128, 1000, 200)]):
-        img = synth(slamx, k, rows, cols, nr, rmin=8, rmax=40)
+    for k, (rows, cols, nr) in enumerate([(480, 640, 3000), (240, 333, 900), (128, 1000, 1500)]):
+        img = synth(slamx, k, rows, cols, nr, rmin=3, rmax=20)
         assert_records_equal(d.detect(img), oracle.detect(img, Pp), "detect window=%d %dx%d" % (window, rows, cols))
 
 
 def test_detect_without_nms(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, nms=0))
-    img = synth(slamx, 1, 300, 400, 200)
+    img = synth(slamx, 1, 300, 400, 1500, rmin=3, rmax=20)
     assert_records_equal(d.detect(img), oracle.detect(img, oracle.det_params(d.cfg)), "detect nms=0")
 
 
@@ -221,7 +221,7 @@ def test_compute_reference_images(det, oracle, P, ref_data, name):
 def test_compute_border_keypoints(det, oracle, P, slamx):
     """Keypoints 0..25 px from every border: patch-leaves-image zero rows and the
     skipped-pair bit shifting of feature_detector.cpp:268-280."""
-    img = synth(slamx, 2, 120, 160, 80, rmin=6, rmax=30)
+    img = synth(slamx, 2, 120, 160, 300, rmin=3, rmax=16)
     pts = [(x, y) for y in list(range(0, 26)) + list(range(94, 120)) for x in (0, 3, 14, 15, 16, 20, 80, 139, 143, 144, 145, 159)]
     pts += [(x, y) for x in list(range(0, 26)) + list(range(134, 160)) for y in (0, 15, 16, 21, 60, 98, 103, 104, 119)]
     kps = np.zeros(len(pts), slamx.KEYPOINT_DTYPE)
@@ -236,7 +236,7 @@ def test_compute_border_keypoints(det, oracle, P, slamx):
 
 
 def test_compute_fractional_coordinates(det, oracle, P, slamx):
-    img = synth(slamx, 4, 200, 200, 100)
+    img = synth(slamx, 4, 200, 200, 600, rmin=3, rmax=16)
     rng = np.random.default_rng(3)
     kps = np.zeros(300, slamx.KEYPOINT_DTYPE)
     kps["x"] = rng.uniform(0, 200, 300).astype(np.float32)
@@ -253,7 +253,7 @@ def test_compute_other_patterns(slamx, oracle, patch, pairs):
     d = slamx.FeatureDetector(cfg_of(slamx, patch=patch, pairs=pairs, window=6))
     Pp = oracle.det_params(d.cfg)
     assert np.array_equal(d.pattern(), oracle.brief_pattern(patch, pairs))
-    img = synth(slamx, 5, 240, 320, 200, rmin=8, rmax=40)
+    img = synth(slamx, 5, 240, 320, 1000, rmin=3, rmax=16)
     kps = oracle.detect(img, Pp)
     k_ref, d_ref = oracle.compute(img, kps, Pp)
     k_got, d_got = d.compute(img, kps)
@@ -360,7 +360,7 @@ def test_batch_equals_single_frame(slamx, oracle):
     m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
     mp = oracle.match_params(m.cfg)
     n = 5
-    frames = np.stack([synth(slamx, k, 240, 320, 250, rmin=8, rmax=40) for k in range(n)])
+    frames = np.stack([synth(slamx, k, 240, 320, 1200, rmin=3, rmax=16) for k in range(n)])
     b = slamx.Batch(d, 240, 320, n, max_candidates=20000, max_keypoints=8000)
     b.upload(frames)
     b.detect_and_compute(n)
@@ -383,7 +383,7 @@ def test_batch_equals_single_frame(slamx, oracle):
 
 def test_batch_capacity_overflow_is_loud(slamx):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
-    frame = synth(slamx, 0, 240, 320, 250, rmin=8, rmax=40)
+    frame = synth(slamx, 0, 240, 320, 1200, rmin=3, rmax=16)
     b = slamx.Batch(d, 240, 320, 1, max_candidates=64, max_keypoints=64)
     b.upload(frame)
     b.detect_and_compute(1)
