@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--workload", default="1080p_2k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-keypoints", action="store_true", help="diagnostic: match without the jump-radius penalty")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +144,7 @@ def main():
 
     def step():
         batch.detect_and_compute(B)
-        batch.match_consecutive(matcher, B, use_keypoints=True, first_train_frame=B - 1)
+        batch.match_consecutive(matcher, B, use_keypoints=not args.no_keypoints, first_train_frame=B - 1)
 
     for _ in range(args.warmup):
         step()

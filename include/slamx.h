@@ -135,6 +135,11 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
 int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, float* angle_deg, float* cos_out,
                      float* sin_out);
 
+/* The jump-radius penalty of findBestMatchesHamming (feature_matcher.cpp:161-170) for n
+ * (hamming distance, query xy, train xy) tuples: out[i] = the penalised integer distance. */
+int slamx_debug_penalty(slamx_ctx* ctx, const int32_t* dist, const float* qx, const float* qy, const float* tx,
+                        const float* ty, int n, int32_t* out);
+
 /* ---- slam::FeatureMatcher ---- */
 /* FeatureMatcher::FeatureMatcher, feature_matcher.cpp:18-69. */
 int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out);

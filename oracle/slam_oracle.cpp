@@ -510,6 +510,22 @@ int oracle_best_matches(const uint8_t* d1, int n1, const uint8_t* d2, int n2, in
     return n;
 }
 
+// The jump-radius penalty of feature_matcher.cpp:161-170 on its own (sqrtf / divide / truncation).
+void oracle_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,
+                    int* out) {
+    for (int i = 0; i < n; ++i) {
+        int d = dist[i];
+        const float dx = qx[i] - tx[i];
+        const float dy = qy[i] - ty[i];
+        const float imageDistance = std::sqrt(dx * dx + dy * dy);
+        if (imageDistance > MAX_JUMP_RADIUS) {
+            float penalty = 1.0f + (imageDistance / static_cast<float>(MAX_JUMP_RADIUS));
+            d = static_cast<int>(static_cast<float>(d) * penalty);
+        }
+        out[i] = d;
+    }
+}
+
 // a10 match (src/frontend/feature_matcher.cpp:71-95).  Returns the match count, or
 // -1 for the std::invalid_argument case (empty input, :99-102).
 int oracle_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int width, const Keypoint* kp1, int nkp1,

@@ -75,7 +75,7 @@ EXPORTS = [
     "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
     "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
-    "slamx_debug_trig", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
+    "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
     "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame",
@@ -121,6 +121,7 @@ def load_library():
     lib.slamx_gaussian_blur.argtypes = img + [vp]
     lib.slamx_debug_sort_desc.argtypes = [vp, vp, C.c_int, vp]
     lib.slamx_debug_trig.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+    lib.slamx_debug_penalty.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.slamx_matcher_create.argtypes = [vp, C.POINTER(MatcherConfig), C.POINTER(vp)]
     lib.slamx_matcher_destroy.argtypes = [vp]
     lib.slamx_matcher_match.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp,
@@ -233,6 +234,13 @@ class Context:
         perm = np.empty(s.shape[0], np.uint32)
         _check(self.lib.slamx_debug_sort_desc(self.h, _ptr(s), s.shape[0], _ptr(perm)))
         return perm
+
+    def debug_penalty(self, dist, qx, qy, tx, ty):
+        d = np.ascontiguousarray(dist, dtype=np.int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (qx, qy, tx, ty)]
+        out = np.empty_like(d)
+        _check(self.lib.slamx_debug_penalty(self.h, _ptr(d), *[_ptr(a) for a in arrs], d.shape[0], _ptr(out)))
+        return out
 
     def debug_trig(self, m01, m10):
         a = np.ascontiguousarray(m01, dtype=np.float32)

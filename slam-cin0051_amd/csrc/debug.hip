@@ -22,7 +22,24 @@ __global__ void trig_kernel(const float* m01, const float* m10, int n, float* de
     s[i] = glibc_sinf(a);
 }
 
+// the penalty arithmetic of match.hip (feature_matcher.cpp:161-170), one tuple per lane
+__global__ void penalty_kernel(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,
+                               int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    out[i] = penalised_distance(dist[i], qx[i], qy[i], tx[i], ty[i]);
+}
+
 }  // namespace
+
+void launch_debug_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,
+                          int* out, hipStream_t stream) {
+    if (n > 0) {
+        hipLaunchKernelGGL(penalty_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dist, qx, qy, tx, ty, n, out);
+    }
+}
 
 void launch_debug_trig(const float* m01, const float* m10, int n, float* deg, float* c, float* s, hipStream_t stream) {
     if (n <= 0) {

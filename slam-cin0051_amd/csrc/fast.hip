@@ -8,9 +8,9 @@
 //
 // MI355X design: integer-only, one image read.
 //   K1  fast_detect : one workgroup = 64 x 16 pixel tile, staged through LDS with a 3-px halo as
-//                     aligned dword loads; a wave owns a 64-pixel row segment, so the corner
-//                     predicate of a row segment is ONE 64-bit ballot = one word of a corner
-//                     bitmap.  The bitmap (W*H/8 bytes) is the only thing written.
+//                     aligned dword loads; pretests on every pixel, the segment test only on the
+//                     compacted survivors; the corner predicate of a 64-pixel row segment is one
+//                     64-bit word of a corner bitmap (W*H/8 bytes), the only thing written.
 //   K1b scan        : per frame, exclusive prefix sum of the bitmap popcounts in raster order
 //                     (row-major, word-major) -> the raster index of every corner is
 //                     wordoff[word] + popcount(bits below it).  This bitmap+prefix pair is also
@@ -58,8 +58,16 @@ __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
     return (rb | rd) != 0;
 }
 
+// Two phases per 64 x 16 tile.  Phase 1 runs only the reference's two pretests
+// (feature_detector.cpp:81-113: the four cardinal circle pixels) on every pixel and appends the
+// few survivors to an LDS list; phase 2 runs the 16-pixel segment test densely on that list, so
+// the expensive part is not paid by the ~95 % of lanes that the pretests reject (a wave only
+// skips work if ALL of its lanes fail, which almost never happens on textured frames).
 __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
+    __shared__ uint16_t survivors[TILE_W * TILE_H];
+    __shared__ uint32_t row_mask[TILE_H][2];
+    __shared__ int n_survivors;
     const int wx = blockIdx.x;
     const int ty = blockIdx.y;
     const int f = blockIdx.z;
@@ -77,38 +85,83 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         }
         tile[i] = val;
     }
+    if (threadIdx.x < TILE_H * 2) {
+        row_mask[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+    }
+    if (threadIdx.x == 0) {
+        n_survivors = 0;
+    }
     __syncthreads();
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+    constexpr int RS = LDS_ROW_DW * 4;  // LDS row stride in bytes
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int x = wx * TILE_W + lane;
-    unsigned long long* masks = v.masks + static_cast<size_t>(f) * v.rows * v.nw;
+    const bool x_ok = x >= HALO && x < v.cols - HALO;
+    // ---- phase 1: pretests
 #pragma unroll
     for (int k = 0; k < TILE_H / 4; ++k) {
         const int ry = wave * (TILE_H / 4) + k;
         const int y = ty * TILE_H + ry;
-        if (y >= v.rows) {
-            break;  // wave-uniform
-        }
-        bool corner = false;
-        if (x >= HALO && x < v.cols - HALO && y >= HALO && y < v.rows - HALO) {
-            const uint8_t* p = t8 + (ry + HALO) * (LDS_ROW_DW * 4) + (lane + 4);
+        bool pass = false;
+        if (x_ok && y >= HALO && y < v.rows - HALO) {
+            const uint8_t* p = t8 + (ry + HALO) * RS + (lane + 4);
             const int c = p[0];
             const int hi = c + threshold;
             const int lo = c - threshold;
-            uint32_t B = 0;
-            uint32_t D = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = p[CIRC_DY[q] * (LDS_ROW_DW * 4) + CIRC_DX[q]];
-                B |= static_cast<uint32_t>(n > hi) << q;
-                D |= static_cast<uint32_t>(n < lo) << q;
-            }
-            corner = segment_test(B, D, arc);
+            const int n0 = p[-3 * RS];  // circle pixel 0  (0,-3)
+            const int n8 = p[3 * RS];   // circle pixel 8  (0,+3)
+            const int n4 = p[3];        // circle pixel 4  (+3,0)
+            const int n12 = p[-3];      // circle pixel 12 (-3,0)
+            const int b0 = n0 > hi, b8 = n8 > hi, b4 = n4 > hi, b12 = n12 > hi;
+            const int d0 = n0 < lo, d8 = n8 < lo, d4 = n4 < lo, d12 = n12 < lo;
+            const bool passA = (b0 | b8 | d0 | d8) != 0;
+            const bool passB = (b0 + b8 + b4 + b12) >= 3 || (d0 + d8 + d4 + d12) >= 3;
+            pass = passA && passB;
         }
-        const unsigned long long m = __ballot(corner);
-        if (lane == 0) {
-            masks[static_cast<size_t>(y) * v.nw + wx] = m;
+        const unsigned long long m = __ballot(pass);
+        if (m != 0) {
+            int base = 0;
+            if (lane == 0) {
+                base = atomicAdd(&n_survivors, __popcll(m));
+            }
+            base = __shfl(base, 0);
+            if (pass) {
+                survivors[base + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>((ry << 6) | lane);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: full segment test on the survivors
+    const int total = n_survivors;
+    for (int s = threadIdx.x; s < total; s += 256) {
+        const int e = survivors[s];
+        const int ry = e >> 6;
+        const int col = e & 63;
+        const uint8_t* p = t8 + (ry + HALO) * RS + (col + 4);
+        const int c = p[0];
+        const int hi = c + threshold;
+        const int lo = c - threshold;
+        uint32_t B = 0;
+        uint32_t D = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = p[CIRC_DY[q] * RS + CIRC_DX[q]];
+            B |= static_cast<uint32_t>(n > hi) << q;
+            D |= static_cast<uint32_t>(n < lo) << q;
+        }
+        if (segment_test(B, D, arc)) {
+            atomicOr(&row_mask[ry][col >> 5], 1u << (col & 31));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TILE_H) {
+        const int y = ty * TILE_H + static_cast<int>(threadIdx.x);
+        if (y < v.rows) {
+            unsigned long long* masks = v.masks + static_cast<size_t>(f) * v.rows * v.nw;
+            masks[static_cast<size_t>(y) * v.nw + wx] =
+                static_cast<unsigned long long>(row_mask[threadIdx.x][0]) |
+                (static_cast<unsigned long long>(row_mask[threadIdx.x][1]) << 32);
         }
     }
 }

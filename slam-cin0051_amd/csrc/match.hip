@@ -22,80 +22,153 @@ namespace slamx {
 namespace {
 
 constexpr int TILE = 256;
-constexpr float MAX_JUMP_RADIUS = 500.0f;  // uint32 500 converted to float in both comparisons
 
-template <int WORDS>
-__global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
+// WORDS = 32-bit words compared per descriptor (the "live" prefix: words that can be non-zero in
+// either set; the all-zero tail contributes popcount(0^0) = 0 and is skipped -- exact).
+// STRIDE words separate consecutive descriptors in memory.  QPL = queries per lane.
+//
+// A pair can only change (best, second) if its distance is < second, and the jump penalty only
+// ever increases the distance, so the Hamming distance alone filters: raw >= second => skip the
+// penalty arithmetic (correctly-rounded sqrt and divide) entirely.  Exact, order-preserving.
+template <int WORDS, int QPL>
+__global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame,
+                                                    int stride) {
     __shared__ uint32_t tdesc[TILE * WORDS];
     __shared__ float2 txy[TILE];
     const int qf = first_query_frame + blockIdx.y;
     const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
-    const int i = static_cast<int>(blockIdx.x) * TILE + static_cast<int>(threadIdx.x);
-    if (static_cast<int>(blockIdx.x) * TILE >= n1) {
+    const int block_first = static_cast<int>(blockIdx.x) * TILE * QPL;
+    if (block_first >= n1) {
         return;  // whole workgroup idle (uniform)
     }
     const bool use_kp = mv.kps != nullptr;
     const uint32_t* qd = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(qf) * mv.maxK * mv.width);
     const uint32_t* td = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(tf) * mv.maxK * mv.width);
-    uint32_t q[WORDS];
-    float qx = 0.0f, qy = 0.0f;
-    if (i < n1) {
+    uint32_t q[QPL][WORDS];
+    float qx[QPL], qy[QPL];
+    int best[QPL], second[QPL], best_idx[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int i = block_first + u * TILE + static_cast<int>(threadIdx.x);
+        qx[u] = 0.0f;
+        qy[u] = 0.0f;
+        best[u] = 0x7fffffff;
+        second[u] = 0x7fffffff;
+        best_idx[u] = -1;
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) {
-            q[w] = qd[static_cast<size_t>(i) * WORDS + w];
+            q[u][w] = i < n1 ? qd[static_cast<size_t>(i) * stride + w] : 0u;
         }
-        if (use_kp) {
+        if (use_kp && i < n1) {
             const slamx_keypoint k = mv.kps[static_cast<size_t>(qf) * mv.maxK + i];
-            qx = k.x;
-            qy = k.y;
-        }
-    } else {
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) {
-            q[w] = 0;
+            qx[u] = k.x;
+            qy[u] = k.y;
         }
     }
-    int best = 0x7fffffff;
-    int second = 0x7fffffff;
-    int best_idx = -1;
-    for (int t0 = 0; t0 < n2; t0 += TILE) {
-        const int tn = min(TILE, n2 - t0);
+    constexpr int JB = 4;
+    int t0 = 0;
+    // one (query u, train t0+j) pair through the reference's update (feature_matcher.cpp:132-141)
+    auto update = [&](int dist, int j, int u) {
+        if (dist < second[u]) {
+            if (use_kp) {
+                const float2 p = txy[j];
+                // Cheap exact rejection before the sqrt/divide: d = sqrtf(dx^2+dy^2) >= max(|dx|,|dy|)
+                // holds in IEEE float, every step of the penalty is monotone in d, and the three
+                // roundings of the reference expression move it by < 4e-7 relative; so if even the
+                // lower bound dist*(1+m/500), shrunk by 1e-5, reaches `second`, the penalised
+                // distance cannot be < second and the pair changes nothing.
+                const float m = fmaxf(fabsf(__fsub_rn(qx[u], p.x)), fabsf(__fsub_rn(qy[u], p.y)));
+                if (m > 500.0f) {
+                    const float lower = static_cast<float>(dist) * (1.0f + m * 0.002f) * 0.99999f;
+                    if (lower >= static_cast<float>(second[u])) {
+                        return;
+                    }
+                }
+                dist = penalised_distance(dist, qx[u], qy[u], p.x, p.y);
+            }
+            const bool lt = dist < best[u];
+            second[u] = lt ? best[u] : min(second[u], dist);
+            best_idx[u] = lt ? (t0 + j) : best_idx[u];
+            best[u] = lt ? dist : best[u];
+        }
+    };
+    // this workgroup scans train chunk blockIdx.z of mv.nsplit (merged in order by emit_kernel)
+    const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
+    const int t_begin = static_cast<int>(blockIdx.z) * chunk;
+    const int t_end = min(n2, t_begin + chunk);
+    for (t0 = t_begin; t0 < t_end; t0 += TILE) {
+        const int tn = min(TILE, t_end - t0);
         __syncthreads();
         for (int e = threadIdx.x; e < tn * WORDS; e += 256) {
-            tdesc[e] = td[static_cast<size_t>(t0) * WORDS + e];
+            const int j = e / WORDS;
+            const int w = e - j * WORDS;
+            tdesc[e] = td[static_cast<size_t>(t0 + j) * stride + w];
         }
         if (use_kp && static_cast<int>(threadIdx.x) < tn) {
             const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + t0 + threadIdx.x];
             txy[threadIdx.x] = make_float2(k.x, k.y);
         }
         __syncthreads();
-        for (int j = 0; j < tn; ++j) {
-            int dist = 0;
+        // groups of JB train descriptors: all LDS reads first, then all popcounts, and only if
+        // some distance can still matter (dist < second, tested against the value before the
+        // group, which is an upper bound of the value inside it) the in-order update path
+        int j = 0;
+        for (; j + JB <= tn; j += JB) {
+            uint32_t t[JB][WORDS];
 #pragma unroll
-            for (int w = 0; w < WORDS; ++w) {
-                dist += __popc(q[w] ^ tdesc[j * WORDS + w]);
-            }
-            if (use_kp) {
-                const float2 t = txy[j];
-                const float dx = __fsub_rn(qx, t.x);
-                const float dy = __fsub_rn(qy, t.y);
-                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-                if (d > MAX_JUMP_RADIUS) {
-                    const float penalty = __fadd_rn(1.0f, __fdiv_rn(d, MAX_JUMP_RADIUS));
-                    dist = static_cast<int>(__fmul_rn(static_cast<float>(dist), penalty));
+            for (int k = 0; k < JB; ++k) {
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) {
+                    t[k][w] = tdesc[(j + k) * WORDS + w];
                 }
             }
-            const bool lt = dist < best;
-            second = lt ? best : min(second, dist);
-            best_idx = lt ? (t0 + j) : best_idx;
-            best = lt ? dist : best;
+            int d[JB][QPL];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < JB; ++k) {
+#pragma unroll
+                for (int u = 0; u < QPL; ++u) {
+                    int dist = 0;
+#pragma unroll
+                    for (int w = 0; w < WORDS; ++w) {
+                        dist += __popc(q[u][w] ^ t[k][w]);
+                    }
+                    d[k][u] = dist;
+                    any = any || dist < second[u];
+                }
+            }
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < JB; ++k) {
+#pragma unroll
+                    for (int u = 0; u < QPL; ++u) {
+                        update(d[k][u], j + k, u);
+                    }
+                }
+            }
+        }
+        for (; j < tn; ++j) {
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) {
+                int dist = 0;
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) {
+                    dist += __popc(q[u][w] ^ tdesc[j * WORDS + w]);
+                }
+                update(dist, j, u);
+            }
         }
     }
-    if (i < n1) {
-        mv.best[static_cast<size_t>(qf) * mv.maxK + i] = make_int2(best, best_idx);
-        mv.second[static_cast<size_t>(qf) * mv.maxK + i] = second;
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int i = block_first + u * TILE + static_cast<int>(threadIdx.x);
+        if (i < n1) {
+            const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + blockIdx.z) * mv.maxK + i;
+            mv.best[slot] = make_int2(best[u], best_idx[u]);
+            mv.second[slot] = second[u];
+        }
     }
 }
 
@@ -127,21 +200,18 @@ __global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int fi
             }
             if (use_kp) {
                 const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + j];
-                const float dx = __fsub_rn(qx, k.x);
-                const float dy = __fsub_rn(qy, k.y);
-                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-                if (d > MAX_JUMP_RADIUS) {
-                    const float penalty = __fadd_rn(1.0f, __fdiv_rn(d, MAX_JUMP_RADIUS));
-                    dist = static_cast<int>(__fmul_rn(static_cast<float>(dist), penalty));
-                }
+                dist = penalised_distance(dist, qx, qy, k.x, k.y);
             }
             const bool lt = dist < best;
             second = lt ? best : min(second, dist);
             best_idx = lt ? j : best_idx;
             best = lt ? dist : best;
         }
-        mv.best[static_cast<size_t>(qf) * mv.maxK + i] = make_int2(best, best_idx);
-        mv.second[static_cast<size_t>(qf) * mv.maxK + i] = second;
+        for (int c = 0; c < mv.nsplit; ++c) {  // the generic path scans everything as chunk 0
+            const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + c) * mv.maxK + i;
+            mv.best[slot] = c == 0 ? make_int2(best, best_idx) : make_int2(0x7fffffff, -1);
+            mv.second[slot] = c == 0 ? second : 0x7fffffff;
+        }
     }
 }
 
@@ -165,8 +235,27 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
             bool good = false;
             int2 b = make_int2(0, -1);
             if (i < n1) {
-                b = mv.best[static_cast<size_t>(qf) * mv.maxK + i];
-                const int second = mv.second[static_cast<size_t>(qf) * mv.maxK + i];
+                // merge the per-chunk (best, idx, second) in ascending train order through the
+                // same update rule: the two smallest of the union, lowest index on ties
+                int best = 0x7fffffff;
+                int second = 0x7fffffff;
+                int best_idx = -1;
+                for (int c = 0; c < mv.nsplit; ++c) {
+                    const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + c) * mv.maxK + i;
+                    const int2 pb = mv.best[slot];
+                    const int ps = mv.second[slot];
+                    if (pb.x < best) {
+                        second = best;
+                        best = pb.x;
+                        best_idx = pb.y;
+                    } else if (pb.x < second) {
+                        second = pb.x;
+                    }
+                    if (ps < second) {
+                        second = ps;
+                    }
+                }
+                b = make_int2(best, best_idx);
                 good = true;
                 if (mv.use_ratio != 0) {
                     if (static_cast<float>(b.x) >= __fmul_rn(mv.ratio, static_cast<float>(second))) {
@@ -205,6 +294,14 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
     }
 }
 
+template <int WORDS>
+void launch_words(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame, hipStream_t stream) {
+    constexpr int QPL = 2;
+    dim3 grid((mv.maxK + TILE * QPL - 1) / (TILE * QPL), npairs, mv.nsplit);
+    hipLaunchKernelGGL((match_kernel<WORDS, QPL>), grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame,
+                       mv.width / 4);
+}
+
 }  // namespace
 
 void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
@@ -212,24 +309,23 @@ void launch_match_consecutive(const MatchView& mv, int first_query_frame, int np
     if (npairs <= 0) {
         return;
     }
-    dim3 grid((mv.maxK + TILE - 1) / TILE, npairs);
-    switch (mv.width) {
-        case 8:
-            hipLaunchKernelGGL(match_kernel<2>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
-            break;
-        case 16:
-            hipLaunchKernelGGL(match_kernel<4>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
-            break;
-        case 32:
-            hipLaunchKernelGGL(match_kernel<8>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
-            break;
-        case 64:
-            hipLaunchKernelGGL(match_kernel<16>, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
-            break;
-        default: {
-            dim3 g(grid_x(mv.maxK, 256, npairs), npairs);
-            hipLaunchKernelGGL(match_generic_kernel, g, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
+    const int stride = mv.width / 4;
+    if (mv.width % 4 == 0 && stride <= 16) {
+        int live = mv.live_words > 0 && mv.live_words < stride ? mv.live_words : stride;
+        switch (live) {
+            case 1: launch_words<1>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            case 2: launch_words<2>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            case 3: launch_words<3>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            case 4: launch_words<4>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            case 5:
+            case 6: launch_words<6>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            case 7:
+            case 8: launch_words<8>(mv, first_query_frame, npairs, first_train_frame, stream); break;
+            default: launch_words<16>(mv, first_query_frame, npairs, first_train_frame, stream); break;
         }
+    } else {
+        dim3 g(grid_x(mv.maxK, 256, npairs), npairs);
+        hipLaunchKernelGGL(match_generic_kernel, g, dim3(256), 0, stream, mv, first_query_frame, first_train_frame);
     }
     if (ev_mid != nullptr) {
         (void)hipEventRecord(ev_mid, stream);

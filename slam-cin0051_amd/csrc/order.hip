@@ -1,4 +1,5 @@
-// order.hip -- the two order-defining steps of applyNonMaxSuppression, bit-exact on the GPU.
+// order.hip -- the std::sort of applyNonMaxSuppression, bit-exact on the GPU (the greedy
+// suppression that consumes its order is in nms.hip).
 //
 // Reference: src/frontend/feature_detector.cpp:147-188
 //   :160-161  std::sort(keypoints, response descending)   -- UNSTABLE; with ~97 % of the
@@ -461,223 +462,6 @@ __global__ __launch_bounds__(256) void debug_sort_kernel(uint32_t* keys, uint32_
     }
 }
 
-// ------------------------------ greedy radius suppression ------------------------------
-// One thread per sorted rank.  Returns the new state of rank r given the current states.
-__device__ uint8_t nms_decide(const BatchView& v, int f, int r, int window, const uint32_t* sorted,
-                              const uint32_t* xy, const uint32_t* rank_of, const volatile uint8_t* state) {
-    const uint32_t key = sorted[r];
-    const uint32_t idx = key & INDEX_MASK;
-    const uint32_t pxy = xy[idx];
-    const int x = static_cast<int>(pxy & 0xffffu);
-    const int y = static_cast<int>(pxy >> 16);
-    const float fx = static_cast<float>(x);
-    const float fy = static_cast<float>(y);
-    const float fw = static_cast<float>(window);
-    const int n = v.rows * v.nw;
-    const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
-    const uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
-    const int reach = window - 1;  // |d| >= window can never be < window
-    const int ylo = max(0, y - reach);
-    const int yhi = min(v.rows - 1, y + reach);
-    const int xlo = max(0, x - reach);
-    const int xhi = min(v.cols - 1, x + reach);
-    const int w0 = xlo >> 6;
-    const int w1 = xhi >> 6;
-    bool all_decided = true;
-    for (int yy = ylo; yy <= yhi; ++yy) {
-        const float dy = fy - static_cast<float>(yy);
-        for (int w = w0; w <= w1; ++w) {
-            const unsigned long long full = masks[static_cast<size_t>(yy) * v.nw + w];
-            if (full == 0) {
-                continue;
-            }
-            const int bl = max(xlo - w * 64, 0);
-            const int bh = min(xhi - w * 64, 63);
-            unsigned long long m = full & (low_mask(bh + 1) & ~low_mask(bl));
-            if (m == 0) {
-                continue;
-            }
-            const uint32_t base = off[static_cast<size_t>(yy) * v.nw + w];
-            while (m != 0) {
-                const int b = __ffsll(static_cast<long long>(m)) - 1;
-                m &= m - 1;
-                const uint32_t nidx = base + static_cast<uint32_t>(__popcll(full & low_mask(b)));
-                const uint32_t r2 = rank_of[nidx];
-                if (r2 >= static_cast<uint32_t>(r)) {
-                    continue;  // later in sorted order (or myself)
-                }
-                // feature_detector.cpp:177-181, same float operations
-                const float dx = fx - static_cast<float>(w * 64 + b);
-                const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-                if (dist < fw) {
-                    const uint8_t s = state[r2];
-                    if (s == NMS_KEPT) {
-                        return NMS_SUPPRESSED;
-                    }
-                    if (s == NMS_UNDECIDED) {
-                        all_decided = false;
-                    }
-                }
-            }
-        }
-    }
-    return all_decided ? NMS_KEPT : NMS_UNDECIDED;
-}
-
-// Massively parallel rounds: grid (chunks, frames); states are monotone, so reading a state that
-// another workgroup is deciding in the same launch is harmless (stale = UNDECIDED = wait).
-__global__ __launch_bounds__(256) void nms_round_kernel(BatchView v, int window, int round) {
-    (void)round;
-    const int f = blockIdx.y;
-    const int n = v.n_cand[f];
-    uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        if (state[r] != NMS_UNDECIDED) {
-            continue;
-        }
-        const uint8_t s = nms_decide(v, f, r, window, sorted, xy, rank_of, state);
-        if (s != NMS_UNDECIDED) {
-            state[r] = s;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void nms_clear_kernel(BatchView v) {
-    const int f = blockIdx.y;
-    const int n = v.n_cand[f];
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        v.state[static_cast<size_t>(f) * v.maxM + r] = NMS_UNDECIDED;
-    }
-}
-
-// One workgroup per frame: finish the remaining rounds, then emit the kept keypoints in sorted
-// order (feature_detector.cpp:170, :187).
-__global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int window) {
-    __shared__ int pending;
-    __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry;
-    const int f = blockIdx.x;
-    const int n = v.n_cand[f];
-    if (n == 0) {
-        return;
-    }
-    uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
-    // every round decides at least the lowest-ranked undecided candidate, so n rounds bound the
-    // loop; the bound only guards the GPU against a corrupted rank table
-    for (int iter = 0; iter <= n; ++iter) {
-        if (threadIdx.x == 0) {
-            pending = 0;
-        }
-        __syncthreads();
-        int mine = 0;
-        for (int r = threadIdx.x; r < n; r += blockDim.x) {
-            if (state[r] == NMS_UNDECIDED) {
-                const uint8_t s = nms_decide(v, f, r, window, sorted, xy, rank_of, state);
-                if (s != NMS_UNDECIDED) {
-                    state[r] = s;
-                } else {
-                    mine++;
-                }
-            }
-        }
-        if (mine != 0) {
-            atomicAdd(&pending, mine);
-        }
-        __threadfence_block();
-        __syncthreads();
-        const int p = pending;
-        __syncthreads();
-        if (p == 0) {
-            break;
-        }
-    }
-    // compaction of KEPT in rank order
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        carry = 0;
-    }
-    __syncthreads();
-    slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
-    for (int base = 0; base < n; base += 1024) {
-        const int r = base + threadIdx.x;
-        const bool keep = r < n && state[r] == NMS_KEPT;
-        const unsigned long long bm = __ballot(keep);
-        const uint32_t c = static_cast<uint32_t>(__popcll(bm));
-        if (lane == 0) {
-            wave_sums[wave] = c;
-        }
-        __syncthreads();
-        uint32_t wbase = carry;
-        for (int w = 0; w < wave; ++w) {
-            wbase += wave_sums[w];
-        }
-        if (keep) {
-            const uint32_t pos = wbase + static_cast<uint32_t>(__popcll(bm & low_mask(lane)));
-            if (pos < static_cast<uint32_t>(v.maxK)) {
-                const uint32_t key = sorted[r];
-                const uint32_t pxy = xy[key & INDEX_MASK];
-                slamx_keypoint kp;
-                kp.x = static_cast<float>(pxy & 0xffffu);
-                kp.y = static_cast<float>(pxy >> 16);
-                kp.size = 6.0f;  // constants::DEFAULT_KEYPOINT_SIZE
-                kp.angle = 0.0f;
-                kp.response = static_cast<float>(key >> SCORE_SHIFT);
-                kps[pos] = kp;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            carry = wbase + c;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int total = static_cast<int>(carry);
-        if (total > v.maxK) {
-            atomicOr(&v.status[f], STATUS_KP_OVERFLOW);
-            total = 0;
-        }
-        v.n_kp[f] = total;
-    }
-}
-
-// NonMaxSuppression: 0 -> detect() returns the raster-ordered candidates with response 0
-// (feature_detector.cpp:13-15, :64).
-__global__ __launch_bounds__(256) void passthrough_kernel(BatchView v) {
-    const int f = blockIdx.y;
-    const int n = v.n_cand[f];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n > v.maxK) {
-            atomicOr(&v.status[f], STATUS_KP_OVERFLOW);
-            v.n_kp[f] = 0;
-        } else {
-            v.n_kp[f] = n;
-        }
-    }
-    if (n > v.maxK) {
-        return;
-    }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t pxy = v.cand_xy[static_cast<size_t>(f) * v.maxM + i];
-        slamx_keypoint kp;
-        kp.x = static_cast<float>(pxy & 0xffffu);
-        kp.y = static_cast<float>(pxy >> 16);
-        kp.size = 6.0f;
-        kp.angle = 0.0f;
-        kp.response = 0.0f;
-        v.kps[static_cast<size_t>(f) * v.maxK + i] = kp;
-    }
-}
-
-constexpr int NMS_PARALLEL_ROUNDS = 4;
-
 int lds_keys_for(int maxM) {
     // keys kept in LDS while they fit ~96 KiB (leaves room for a second workgroup per CU on
     // small frames); larger frames fall back to global memory inside the same kernel
@@ -696,20 +480,6 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream) {
     (void)once;
     const int lds_keys = lds_keys_for(v.maxM);
     hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(256), static_cast<size_t>(lds_keys) * 4, stream, v, lds_keys);
-}
-
-void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
-    dim3 grid(grid_x(v.maxM, 256, nframes), nframes);
-    hipLaunchKernelGGL(nms_clear_kernel, grid, dim3(256), 0, stream, v);
-    for (int r = 0; r < NMS_PARALLEL_ROUNDS; ++r) {
-        hipLaunchKernelGGL(nms_round_kernel, grid, dim3(256), 0, stream, v, p.window, r + 1);
-    }
-    hipLaunchKernelGGL(nms_finish_kernel, dim3(nframes), dim3(1024), 0, stream, v, p.window);
-}
-
-void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream) {
-    dim3 grid(grid_x(v.maxM, 256, nframes), nframes);
-    hipLaunchKernelGGL(passthrough_kernel, grid, dim3(256), 0, stream, v);
 }
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,

@@ -314,6 +314,20 @@ void filter_and_sort(std::vector<slamx_match>& m, int good_matches_count) {
     }
 }
 
+// Train-set split of the matcher: enough workgroups for ~8 waves per SIMD (256 CUs x 4 SIMDs),
+// 512 queries per 4-wave workgroup.
+int match_split_for(int npairs, int maxK) {
+    const long long waves = static_cast<long long>(npairs > 0 ? npairs : 1) * ((maxK + 511) / 512) * 4;
+    long long s = (8192 + waves - 1) / waves;
+    if (s < 1) {
+        s = 1;
+    }
+    if (s > MATCH_MAX_SPLIT) {
+        s = MATCH_MAX_SPLIT;
+    }
+    return static_cast<int>(s);
+}
+
 uint64_t splitmix64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -550,7 +564,8 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&v.n_kp, F);
     A(&v.desc, F * v.maxK * v.width);
     A(&v.status, F);
-    A(&v.undecided, F);
+    A(&v.nbr_cnt, F * v.maxM);
+    A(&v.nbr, F * v.maxM * NBR_CAP);
     v.frames = b->frames;
     v.blurred = blurred;
     if (rc != SLAMX_OK) {
@@ -601,7 +616,8 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.n_kp);
     dev_free(v.desc);
     dev_free(v.status);
-    dev_free(v.undecided);
+    dev_free(v.nbr_cnt);
+    dev_free(v.nbr);
     dev_free(b->matches);
     dev_free(b->n_matches);
     dev_free(b->best);
@@ -667,8 +683,8 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     if (b->matches == nullptr) {
         SLAMX_TRY(dev_alloc(&b->matches, F * b->v.maxK));
         SLAMX_TRY(dev_alloc(&b->n_matches, F));
-        SLAMX_TRY(dev_alloc(&b->best, F * b->v.maxK));
-        SLAMX_TRY(dev_alloc(&b->second, F * b->v.maxK));
+        SLAMX_TRY(dev_alloc(&b->best, F * MATCH_MAX_SPLIT * b->v.maxK));
+        SLAMX_TRY(dev_alloc(&b->second, F * MATCH_MAX_SPLIT * b->v.maxK));
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
     }
     MatchView mv{};
@@ -681,6 +697,9 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     mv.second = b->second;
     mv.maxK = b->v.maxK;
     mv.width = b->v.width;
+    // descriptors of a batch come from describe_kernel: bits >= pattern_len are never set
+    mv.live_words = std::max(1, (static_cast<int>(b->det->pattern.size() / 4) + 31) / 32);
+    mv.nsplit = match_split_for(nframes, b->v.maxK);
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
     if (!recorded(b, 7)) {
@@ -1021,6 +1040,38 @@ int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, 
     return SLAMX_OK;
 }
 
+int slamx_debug_penalty(slamx_ctx* ctx, const int32_t* dist, const float* qx, const float* qy, const float* tx,
+                        const float* ty, int n, int32_t* out) {
+    if (n <= 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    void* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void* src[5] = {dist, qx, qy, tx, ty};
+    const size_t bytes = 4 * static_cast<size_t>(n);
+    hipError_t e = hipSuccess;
+    for (auto& p : d) {
+        if (e == hipSuccess) e = hipMalloc(&p, bytes);
+    }
+    for (int k = 0; k < 5 && e == hipSuccess; ++k) {
+        e = hipMemcpyAsync(d[k], src[k], bytes, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        launch_debug_penalty(static_cast<int*>(d[0]), static_cast<float*>(d[1]), static_cast<float*>(d[2]),
+                             static_cast<float*>(d[3]), static_cast<float*>(d[4]), n, static_cast<int*>(d[5]), ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d[5], bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    for (auto& p : d) {
+        if (p != nullptr) (void)hipFree(p);
+    }
+    if (e != hipSuccess) {
+        return fail(SLAMX_ERR_HIP, std::string("debug penalty: ") + hipGetErrorString(e));
+    }
+    return SLAMX_OK;
+}
+
 // ------------------------------------------------------------------ matcher
 int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out) {
     if (ctx == nullptr || cfg == nullptr || out == nullptr) {
@@ -1107,8 +1158,8 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
         SLAMX_TRY(dev_alloc(&m->n_kp, 2));
         SLAMX_TRY(dev_alloc(&m->matches, 2 * c));
         SLAMX_TRY(dev_alloc(&m->n_matches, 2));
-        SLAMX_TRY(dev_alloc(&m->best, 2 * c));
-        SLAMX_TRY(dev_alloc(&m->second, 2 * c));
+        SLAMX_TRY(dev_alloc(&m->best, 2 * MATCH_MAX_SPLIT * c));
+        SLAMX_TRY(dev_alloc(&m->second, 2 * MATCH_MAX_SPLIT * c));
         m->cap = need;
         m->width = width1;
     }
@@ -1132,6 +1183,29 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     mv.second = m->second;
     mv.maxK = m->cap;
     mv.width = width1;
+    mv.nsplit = match_split_for(1, m->cap);
+    mv.live_words = 0;
+    if (width1 % 4 == 0) {
+        // highest 32-bit word that is non-zero in any descriptor of either set
+        int live = 1;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint8_t* d = s2 == 0 ? d1 : d2;
+            const int cnt = s2 == 0 ? n1 : n2;
+            const int words = width1 / 4;
+            for (int i = 0; i < cnt; ++i) {
+                const uint32_t* row = reinterpret_cast<const uint32_t*>(d + static_cast<size_t>(i) * width1);
+                for (int w = words - 1; w >= live; --w) {
+                    uint32_t val;
+                    std::memcpy(&val, row + w, 4);
+                    if (val != 0) {
+                        live = w + 1;
+                        break;
+                    }
+                }
+            }
+        }
+        mv.live_words = live;
+    }
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
     launch_match_consecutive(mv, 1, 1, -1, s, nullptr);

@@ -20,6 +20,9 @@ constexpr int MAX_PATTERN = 1024;          // NumBRIEFPairs upper bound held in 
 constexpr uint8_t NMS_UNDECIDED = 0;
 constexpr uint8_t NMS_KEPT = 1;
 constexpr uint8_t NMS_SUPPRESSED = 2;
+constexpr int MATCH_MAX_SPLIT = 8;
+constexpr int NBR_CAP = 16;            // cached earlier-ranked neighbours per candidate
+constexpr uint8_t NBR_OVERFLOW = 255;  // more than NBR_CAP: re-enumerate every round
 
 // per-frame status bits
 constexpr int STATUS_CAND_OVERFLOW = 1;
@@ -40,20 +43,65 @@ struct BatchView {
     uint32_t* keys;          // [F][maxM]  score<<20|raster idx; permuted in place by the sort
     uint32_t* sorted;        // [F][maxM]  keys in final std::sort order
     uint32_t* rank_of;       // [F][maxM]  raster idx -> sorted position
-    uint8_t* state;          // [F][maxM]  NMS state by sorted position
+    uint8_t* state;          // [F][maxM]  NMS state by raster index
+    uint8_t* nbr_cnt;        // [F][maxM]  number of cached earlier neighbours (NBR_OVERFLOW = too many)
+    uint32_t* nbr;           // [F][maxM][NBR_CAP] raster indices of the earlier-ranked neighbours in radius
     uint8_t* segstart;       // [F][maxM+1] leaf-segment start flags
     int2* seglist;           // [F][2][maxSeg] level-synchronous segment lists
     slamx_keypoint* kps;     // [F][maxK]
     int* n_kp;               // [F]
     uint8_t* desc;           // [F][maxK][width]
     int* status;             // [F]
-    int* undecided;          // [F] NMS scratch counter
     int maxM, maxK, maxSeg, width;
 };
 
 struct DetectorParams {
     int threshold, arc, nms, window, patch, npairs /*NumBRIEFPairs*/, pattern_len;
 };
+
+// Correctly rounded float sqrt.  NOTE: HIP's __fsqrt_rn() is __ocml_native_sqrt_f32 (1 ulp,
+// v_sqrt_f32 alone) unless OCML_BASIC_ROUNDED_OPERATIONS is defined; plain sqrtf is expanded to the
+// IEEE-correct sequence under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt, which is
+// what the reference's std::sqrt(float) needs.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float sqrtf_rn(float x) { return __builtin_sqrtf(x); }
+
+// findBestMatchesHamming's jump-radius penalty, src/frontend/feature_matcher.cpp:161-170, with the
+// reference's float operations (MAX_JUMP_RADIUS = 500 converted to float in both places).
+__device__ __forceinline__ int penalised_distance_exact(int dist, float dx, float dy) {
+    const float d = sqrtf_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    if (d > 500.0f) {
+        const float penalty = __fadd_rn(1.0f, __fdiv_rn(d, 500.0f));
+        dist = static_cast<int>(__fmul_rn(static_cast<float>(dist), penalty));
+    }
+    return dist;
+}
+// Same value, usually without the correctly-rounded sqrt and divide (~40 instructions): evaluate
+// the expression with the 1-ulp hardware sqrt and a multiply by 0.002f (total relative error
+// < 1e-6), and accept its integer part only when the value is farther than 4e-6*x (+1e-6) from
+// an integer boundary and d is farther than 0.01 from the 500 px threshold; otherwise (a few in
+// 1e5 pairs) fall back to the exact expression.  The result is ALWAYS the reference's value.
+__device__ __forceinline__ int penalised_distance(int dist, float qx, float qy, float tx, float ty) {
+    const float dx = __fsub_rn(qx, tx);
+    const float dy = __fsub_rn(qy, ty);
+    const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+    const float da = __builtin_amdgcn_sqrtf(d2);  // v_sqrt_f32, 1 ulp
+    if (fabsf(da - 500.0f) < 0.01f || !(da < 3.0e37f)) {
+        return penalised_distance_exact(dist, dx, dy);
+    }
+    if (da <= 500.0f || dist == 0) {
+        return dist;
+    }
+    const float x = static_cast<float>(dist) * (1.0f + da * 0.002f);
+    const int k = static_cast<int>(x);
+    const float fr = x - static_cast<float>(k);
+    const float tol = x * 4.0e-6f + 1.0e-6f;
+    if (fr > tol && fr < 1.0f - tol && x < 1.0e9f) {
+        return k;
+    }
+    return penalised_distance_exact(dist, dx, dy);
+}
+#endif
 
 // blocks per frame for a grid-stride kernel: enough to cover `items`, capped so that a large
 // batch does not launch millions of empty workgroups (>= 8 per frame, ~8192 in total)
@@ -87,9 +135,11 @@ struct MatchView {
     const int* n_kp;               // [F]
     slamx_match* matches;          // [F][maxK]  matches of query frame f (vs f-1)
     int* n_matches;                // [F]
-    int2* best;                    // [F][maxK] scratch: {best_dist, best_idx}
-    int* second;                   // [F][maxK] scratch: second best
+    int2* best;                    // [F][nsplit][maxK] scratch: {best_dist, best_idx} per train chunk
+    int* second;                   // [F][nsplit][maxK] scratch: second best per train chunk
+    int nsplit;                    // train set split into this many chunks (more workgroups)
     int maxK, width;
+    int live_words;  // 32-bit words that can be non-zero in any descriptor (0 = unknown: all)
     int use_ratio;
     float ratio;
 };
@@ -101,6 +151,8 @@ void launch_match_consecutive(const MatchView& mv, int first_query_frame, int np
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream);
+void launch_debug_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,
+                          int* out, hipStream_t stream);
 void launch_debug_trig(const float* m01, const float* m10, int n, float* deg, float* c, float* s, hipStream_t stream);
 
 }  // namespace slamx

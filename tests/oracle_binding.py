@@ -123,6 +123,13 @@ class Oracle:
         self.lib.oracle_trig_chain(_p(a), _p(b), a.shape[0], _p(deg), _p(c), _p(s))
         return deg, c, s
 
+    def penalty(self, dist, qx, qy, tx, ty):
+        d = np.ascontiguousarray(dist, np.int32)
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (qx, qy, tx, ty)]
+        out = np.empty_like(d)
+        self.lib.oracle_penalty(_p(d), *[_p(a) for a in arrs], d.shape[0], _p(out))
+        return out
+
     def antiqsort(self, n):
         vals = np.empty(n, np.uint32)
         self.lib.oracle_antiqsort(n, _p(vals))

@@ -339,6 +339,28 @@ def test_match_penalty_fractional_keypoints(slamx, oracle):
     assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, oracle.match_params(m.cfg)), "penalty")
 
 
+def test_penalty_arithmetic_exact(gpu_ctx, oracle):
+    """sqrtf, divide, multiply and truncation of feature_matcher.cpp:161-170 on 2M random tuples
+    (correctly rounded sqrt/divide are required: a 1-ulp sqrt flips truncations)."""
+    rng = np.random.default_rng(21)
+    n = 2_000_000
+    dist = rng.integers(0, 257, n).astype(np.int32)
+    qx, tx = (rng.uniform(0, 4096, n).astype(np.float32) for _ in range(2))
+    qy, ty = (rng.uniform(0, 2200, n).astype(np.float32) for _ in range(2))
+    # integer-pixel coordinates and exact-boundary cases (distance exactly 500)
+    qx[: n // 2] = np.round(qx[: n // 2])
+    qy[: n // 2] = np.round(qy[: n // 2])
+    tx[: n // 2] = np.round(tx[: n // 2])
+    ty[: n // 2] = np.round(ty[: n // 2])
+    tx[:1000] = qx[:1000] + 300.0
+    ty[:1000] = qy[:1000] + 400.0
+    got = gpu_ctx.debug_penalty(dist, qx, qy, tx, ty)
+    ref = oracle.penalty(dist, qx, qy, tx, ty)
+    bad = np.nonzero(got != ref)[0]
+    assert bad.size == 0, "penalty differs at %d tuples, e.g. %r" % (bad.size, (dist[bad[0]], qx[bad[0]], qy[bad[0]], tx[bad[0]], ty[bad[0]], got[bad[0]], ref[bad[0]]))
+    assert (ref > dist).mean() > 0.3  # the penalty branch is well exercised
+
+
 def test_match_errors(slamx):
     m = slamx.FeatureMatcher(mcfg(slamx))
     d = np.zeros((4, 32), np.uint8)
