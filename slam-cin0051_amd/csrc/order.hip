@@ -303,41 +303,234 @@ __device__ int wave_partition(uint32_t* a, int first, int last, int lane) {
     return cut;
 }
 
-// Sort n keys descending by score exactly as std::sort does.  One workgroup (256 threads).
-//   a        : n keys (LDS or global), permuted in place by the introsort loop
-//   out      : final order (global)
-//   segstart : n+1 flags (global or LDS); seglist: 2*maxSeg entries
-// Returns 0 or STATUS_SEG_OVERFLOW.
-__device__ int block_sort_desc(uint32_t* a, uint32_t* out, uint8_t* segstart, int2* seglist, int maxSeg, int n,
-                               int* lds_counters /* >= 4 ints */) {
+// ---------------- whole workgroup: pivot + Hoare partition of a LARGE segment ----------------
+// Same closed form as wave_partition (L_k / R_k stoppers over ORIGINAL values, swap while
+// L_k < R_k, cut = min(L_K, R_{K-1})), evaluated with two block-wide passes: every wave owns a
+// contiguous slice, ballots give the stopper ranks, an L stopper of 0-based rank k is swapped iff
+// at least k+1 R stoppers lie to its right (and symmetrically), swapped positions are listed by
+// rank in `scratch` and exchanged in a third pass.  scratch: >= (last-first) words, global.
+struct SortShared {
+    int counters[4];
+    uint32_t wave_l[16];
+    uint32_t wave_r[16];
+    int cut_l;   // lowest unswapped L stopper
+    int cut_r;   // lowest swapped R stopper
+    int n_swap;  // K
+    uint32_t pivot;
+    int2 big[2][32];  // large segments of the current / next level (n <= 24576 keys => at most 12)
+    int n_big[2];
+};
+
+__device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int last, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    for (int i = tid; i <= n; i += blockDim.x) {
-        segstart[i] = (i == 0 || i == n) ? 1 : 0;
-    }
-    int depth = 0;
-    if (n > 1) {
-        depth = 2 * (31 - __clz(n));  // std::__lg(n) * 2
-    }
     if (tid == 0) {
-        lds_counters[0] = n > SORT_LEAF ? 1 : 0;  // current level count
-        lds_counters[1] = 0;                      // next level count
-        lds_counters[2] = 0;                      // overflow flag
-        if (n > SORT_LEAF) {
-            seglist[0] = make_int2(0, n);
+        // __move_median_to_first(first, first+1, mid, last-1)
+        const int ia = first + 1;
+        const int ib = first + (last - first) / 2;
+        const int ic = last - 1;
+        const uint32_t vf = a[first], va = a[ia], vb = a[ib], vc = a[ic];
+        int im;
+        uint32_t vm;
+        if (comp(va, vb)) {
+            if (comp(vb, vc)) {
+                im = ib, vm = vb;
+            } else if (comp(va, vc)) {
+                im = ic, vm = vc;
+            } else {
+                im = ia, vm = va;
+            }
+        } else if (comp(va, vc)) {
+            im = ia, vm = va;
+        } else if (comp(vb, vc)) {
+            im = ic, vm = vc;
+        } else {
+            im = ib, vm = vb;
+        }
+        a[first] = vm;
+        a[im] = vf;
+        sh.pivot = score_of(vm);
+        sh.cut_l = 0x7fffffff;
+        sh.cut_r = 0x7fffffff;
+        sh.n_swap = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t p = sh.pivot;
+    const int lo = first + 1;
+    const int hi = last;
+    const int n = hi - lo;
+    const int per_wave = ((n + nwaves - 1) / nwaves + 63) & ~63;  // slice length, multiple of 64
+    const int w_lo = min(hi, lo + wave * per_wave);
+    const int w_hi = min(hi, w_lo + per_wave);
+    // pass 1: stoppers per wave slice
+    uint32_t nl = 0, nr = 0;
+    for (int base = w_lo; base < w_hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < w_hi;
+        const uint32_t sc = in ? score_of(a[i]) : 0u;
+        nl += static_cast<uint32_t>(__popcll(__ballot(in && sc <= p)));
+        nr += static_cast<uint32_t>(__popcll(__ballot(in && sc >= p)));
+    }
+    if (lane == 0) {
+        sh.wave_l[wave] = nl;
+        sh.wave_r[wave] = nr;
+    }
+    __syncthreads();
+    uint32_t l_before = 0;  // L stoppers in slices to the left
+    uint32_t r_after = 0;   // R stoppers in slices to the right
+    for (int w = 0; w < nwaves; ++w) {
+        l_before += w < wave ? sh.wave_l[w] : 0u;
+        r_after += w > wave ? sh.wave_r[w] : 0u;
+    }
+    uint32_t* lpos = scratch;
+    uint32_t* rpos = scratch + (n / 2 + 1);
+    // pass 2: classify
+    uint32_t run_l = 0, run_r = 0;  // stoppers of this slice in earlier steps
+    int my_swaps = 0;
+    int min_unswapped_l = 0x7fffffff;
+    int min_swapped_r = 0x7fffffff;
+    for (int base = w_lo; base < w_hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < w_hi;
+        const uint32_t sc = in ? score_of(a[i]) : 0u;
+        const bool is_l = in && sc <= p;
+        const bool is_r = in && sc >= p;
+        const unsigned long long ml = __ballot(is_l);
+        const unsigned long long mr = __ballot(is_r);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t l_left = l_before + run_l + static_cast<uint32_t>(__popcll(ml & below));  // L at positions < i
+        const uint32_t r_le = run_r + static_cast<uint32_t>(__popcll(mr & (below | (1ull << lane))));
+        const uint32_t r_right = r_after + (nr - r_le);  // R at positions > i
+        if (is_l) {
+            // 0-based rank l_left; partner R_{l_left} exists to the right iff r_right >= l_left + 1
+            if (r_right >= l_left + 1u && l_left < static_cast<uint32_t>(n / 2 + 1)) {
+                lpos[l_left] = static_cast<uint32_t>(i);
+                ++my_swaps;
+            } else {
+                min_unswapped_l = min(min_unswapped_l, i);
+            }
+        }
+        if (is_r) {
+            // 0-based rank from the right r_right; partner L_{r_right} lies to the left iff l_left >= r_right + 1
+            if (l_left >= r_right + 1u && r_right < static_cast<uint32_t>(n / 2 + 1)) {
+                rpos[r_right] = static_cast<uint32_t>(i);
+                min_swapped_r = min(min_swapped_r, i);
+            }
+        }
+        run_l += static_cast<uint32_t>(__popcll(ml));
+        run_r += static_cast<uint32_t>(__popcll(mr));
+    }
+    // wave reductions, then one LDS atomic per wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_swaps += __shfl_xor(my_swaps, d);
+        min_unswapped_l = min(min_unswapped_l, __shfl_xor(min_unswapped_l, d));
+        min_swapped_r = min(min_swapped_r, __shfl_xor(min_swapped_r, d));
+    }
+    if (lane == 0) {
+        atomicAdd(&sh.n_swap, my_swaps);
+        atomicMin(&sh.cut_l, min_unswapped_l);
+        atomicMin(&sh.cut_r, min_swapped_r);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int K = sh.n_swap;
+    // pass 3: exchange the K pairs
+    for (int k = tid; k < K; k += blockDim.x) {
+        const uint32_t i = lpos[k];
+        const uint32_t j = rpos[k];
+        const uint32_t vi = a[i];
+        const uint32_t vj = a[j];
+        a[i] = vj;
+        a[j] = vi;
+    }
+    const int cut = min(sh.cut_l, sh.cut_r);
+    __threadfence_block();
+    __syncthreads();
+    return cut;
+}
+
+constexpr int SORT_BLOCK_MIN = 2048;  // segments at least this long are partitioned by the whole workgroup
+
+// The introsort loop of std::sort on a[0, len) (LDS or global), level by level: large segments by
+// the whole workgroup one after another, the rest one wave per segment.  Leaf boundaries are
+// recorded in segbits at bit (bit_base + position).  lists: two arrays of maxSeg int2 (global).
+__device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int depth, uint32_t* segbits, int bit_base,
+                                 int2* lists, int maxSeg, SortShared& sh) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    if (tid == 0) {
+        sh.counters[0] = 0;
+        sh.counters[1] = 0;
+        sh.n_big[0] = 0;
+        sh.n_big[1] = 0;
+        if (len >= SORT_BLOCK_MIN) {
+            sh.big[0][0] = make_int2(0, len);
+            sh.n_big[0] = 1;
+        } else if (len > SORT_LEAF) {
+            lists[0] = make_int2(0, len);
+            sh.counters[0] = 1;
         }
     }
+    __threadfence_block();
     __syncthreads();
     int cur = 0;
     while (true) {
-        const int count = lds_counters[0];
-        if (count == 0) {
+        const int count = sh.counters[0];
+        const int nbig = sh.n_big[cur];
+        if (count == 0 && nbig == 0) {
             break;
         }
-        int2* src = seglist + cur * maxSeg;
-        int2* dst = seglist + (cur ^ 1) * maxSeg;
+        int2* src = lists + cur * maxSeg;
+        int2* dst = lists + (cur ^ 1) * maxSeg;
+        auto emit_children = [&](int first, int cut, int last) {  // one lane
+            const int bit = bit_base + cut;
+            atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+            const int2 child[2] = {make_int2(cut, last), make_int2(first, cut)};
+            for (int c = 0; c < 2; ++c) {
+                const int size = child[c].y - child[c].x;
+                if (size >= SORT_BLOCK_MIN) {
+                    const int slot = atomicAdd(&sh.n_big[cur ^ 1], 1);
+                    if (slot < 32) {
+                        sh.big[cur ^ 1][slot] = child[c];
+                    } else {
+                        sh.counters[2] = 1;
+                    }
+                } else if (size > SORT_LEAF) {
+                    const int slot = atomicAdd(&sh.counters[1], 1);
+                    if (slot < maxSeg) {
+                        dst[slot] = child[c];
+                    } else {
+                        sh.counters[2] = 1;
+                    }
+                }
+            }
+        };
+        // large segments: whole workgroup, one after another (uniform control flow)
+        for (int s = 0; s < nbig; ++s) {
+            const int2 seg = sh.big[cur][s];
+            if (depth == 0) {
+                if (tid == 0) {
+                    heap_sort_(a + seg.x, seg.y - seg.x);
+                }
+                __threadfence_block();
+                __syncthreads();
+                for (int i = seg.x + tid; i < seg.y; i += blockDim.x) {
+                    const int bit = bit_base + i;
+                    atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+                }
+                continue;
+            }
+            const int cut = block_partition(a, scratch, seg.x, seg.y, sh);
+            if (tid == 0) {
+                emit_children(seg.x, cut, seg.y);
+            }
+        }
         for (int s = wave; s < count; s += nwaves) {
             const int2 seg = src[s];
             const int first = seg.x;
@@ -350,55 +543,177 @@ __device__ int block_sort_desc(uint32_t* a, uint32_t* out, uint8_t* segstart, in
                 }
                 wave_mem_fence();
                 for (int i = first + lane; i < last; i += 64) {
-                    segstart[i] = 1;
+                    const int bit = bit_base + i;
+                    atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
                 }
                 continue;
             }
             const int cut = wave_partition(a, first, last, lane);
             if (lane == 0) {
-                segstart[cut] = 1;
-                // right child [cut,last) first, then left [first,cut): any order is fine, the
-                // children are independent
-                if (last - cut > SORT_LEAF) {
-                    const int slot = atomicAdd(&lds_counters[1], 1);
-                    if (slot < maxSeg) {
-                        dst[slot] = make_int2(cut, last);
-                    } else {
-                        lds_counters[2] = 1;
-                    }
-                }
-                if (cut - first > SORT_LEAF) {
-                    const int slot = atomicAdd(&lds_counters[1], 1);
-                    if (slot < maxSeg) {
-                        dst[slot] = make_int2(first, cut);
-                    } else {
-                        lds_counters[2] = 1;
-                    }
-                }
+                emit_children(first, cut, last);
             }
         }
         __threadfence_block();
         __syncthreads();
         if (tid == 0) {
-            lds_counters[0] = min(lds_counters[1], maxSeg);
-            lds_counters[1] = 0;
+            sh.counters[0] = min(sh.counters[1], maxSeg);
+            sh.counters[1] = 0;
+            sh.n_big[cur] = 0;
+            sh.n_big[cur ^ 1] = min(sh.n_big[cur ^ 1], 32);
         }
         depth = depth > 0 ? depth - 1 : 0;
         cur ^= 1;
         __syncthreads();
     }
-    const int overflow = lds_counters[2];
+}
+
+// Sort n keys descending by score exactly as std::sort does.  One workgroup.
+//   gkeys    : n keys in global memory, permuted in place by the introsort loop
+//   out      : final order (global); doubles as scratch for the workgroup-wide partitions
+//   lds      : lds_keys words of LDS for the keys + the words behind them for leaf flags
+//   gsegbits : global leaf-flag words, used when (n+32)/32 words do not fit behind the LDS keys
+//   lists    : 3 * maxSeg int2 (global): two level lists + the list of LDS-sized segments
+// Segments longer than lds_keys are partitioned in global memory by the whole workgroup until
+// they fit; every remaining segment is then sorted in LDS.  Returns 0 or STATUS_SEG_OVERFLOW.
+__device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* gsegbits,
+                               int2* lists, int maxSeg, int n, SortShared& sh) {
+    const int tid = threadIdx.x;
+    const int nwords = (n + 32) / 32;  // bits 0..n
+    uint32_t* segbits = nwords <= lds_keys / 32 + 2 ? lds + lds_keys : gsegbits;
+    for (int i = tid; i < nwords; i += blockDim.x) {
+        uint32_t wbits = 0;
+        if (i == 0) {
+            wbits |= 1u;
+        }
+        if (i == (n >> 5)) {
+            wbits |= 1u << (n & 31);
+        }
+        segbits[i] = wbits;
+    }
+    if (tid == 0) {
+        sh.counters[2] = 0;  // overflow flag
+        sh.counters[3] = 0;  // number of LDS-sized segments
+    }
+    __syncthreads();
+    int depth0 = 0;
+    if (n > 1) {
+        depth0 = 2 * (31 - __clz(n));  // std::__lg(n) * 2
+    }
+    int2* ready = lists + 2 * maxSeg;  // {first, last | depth << 24}
+    if (n <= lds_keys) {
+        if (tid == 0 && n > SORT_LEAF) {
+            ready[0] = make_int2(0, n | (depth0 << 24));
+            sh.counters[3] = 1;
+        }
+    } else {
+        // phase A: global-memory levels for segments that do not fit LDS
+        if (tid == 0) {
+            lists[0] = make_int2(0, n);
+            sh.counters[0] = 1;
+            sh.counters[1] = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        int cur = 0;
+        int depth = depth0;
+        while (true) {
+            const int count = sh.counters[0];
+            if (count == 0) {
+                break;
+            }
+            int2* src = lists + cur * maxSeg;
+            int2* dst = lists + (cur ^ 1) * maxSeg;
+            for (int s = 0; s < count; ++s) {
+                const int2 seg = src[s];
+                if (depth == 0) {
+                    if (tid == 0) {
+                        heap_sort_(gkeys + seg.x, seg.y - seg.x);
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    for (int i = seg.x + tid; i < seg.y; i += blockDim.x) {
+                        atomicOr(&segbits[i >> 5], 1u << (i & 31));
+                    }
+                    continue;
+                }
+                const int cut = block_partition(gkeys, out, seg.x, seg.y, sh);
+                if (tid == 0) {
+                    atomicOr(&segbits[cut >> 5], 1u << (cut & 31));
+                    const int2 child[2] = {make_int2(cut, seg.y), make_int2(seg.x, cut)};
+                    for (int c = 0; c < 2; ++c) {
+                        const int size = child[c].y - child[c].x;
+                        if (size <= SORT_LEAF) {
+                            continue;
+                        }
+                        if (size <= lds_keys) {
+                            const int slot = sh.counters[3]++;
+                            if (slot < maxSeg) {
+                                ready[slot] = make_int2(child[c].x, child[c].y | ((depth - 1) << 24));
+                            } else {
+                                sh.counters[2] = 1;
+                            }
+                        } else {
+                            const int slot = sh.counters[1]++;
+                            if (slot < maxSeg) {
+                                dst[slot] = child[c];
+                            } else {
+                                sh.counters[2] = 1;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) {
+                sh.counters[0] = min(sh.counters[1], maxSeg);
+                sh.counters[1] = 0;
+            }
+            depth = depth > 0 ? depth - 1 : 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // phase B: every LDS-sized segment: load, introsort levels in LDS, store back
+    const int n_ready = min(sh.counters[3], maxSeg);
+    for (int r = 0; r < n_ready; ++r) {
+        const int2 seg = ready[r];
+        const int first = seg.x;
+        const int last = seg.y & 0xffffff;
+        const int depth = seg.y >> 24;
+        const int len = last - first;
+        for (int i = tid; i < len; i += blockDim.x) {
+            lds[i] = gkeys[first + i];
+        }
+        __syncthreads();
+        introsort_levels(lds, out, len, depth, segbits, first, lists, maxSeg, sh);
+        for (int i = tid; i < len; i += blockDim.x) {
+            gkeys[first + i] = lds[i];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int overflow = sh.counters[2];
     __syncthreads();
     // __final_insertion_sort == stable sort inside each leaf: rank counting, one lane per element
+    const uint32_t* a = gkeys;
     for (int i = tid; i < n; i += blockDim.x) {
-        int s = i;
-        while (segstart[s] == 0) {
-            --s;
+        // leaf start s: highest flag <= i; leaf end e: lowest flag > i (flags 0 and n always set)
+        int wi = i >> 5;
+        uint32_t wbits = segbits[wi] & (0xffffffffu >> (31 - (i & 31)));
+        while (wbits == 0) {
+            wbits = segbits[--wi];
         }
-        int e = i + 1;
-        while (segstart[e] == 0) {
-            ++e;
+        const int s = wi * 32 + (31 - __clz(wbits));
+        wi = (i + 1) >> 5;
+        wbits = segbits[wi] & (0xffffffffu << ((i + 1) & 31));
+        while (wbits == 0) {
+            wbits = segbits[++wi];
         }
+        const int e = wi * 32 + (__ffs(wbits) - 1);
         const uint32_t me = a[i];
         const uint32_t sc = score_of(me);
         int pos = s;
@@ -415,8 +730,10 @@ __device__ int block_sort_desc(uint32_t* a, uint32_t* out, uint8_t* segstart, in
 
 extern __shared__ uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(256) void sort_kernel(BatchView v, int lds_keys) {
-    __shared__ int counters[4];
+constexpr int SORT_THREADS = 1024;
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds_keys) {
+    __shared__ SortShared sh;
     const int f = blockIdx.x;
     const int n = v.n_cand[f];
     if (n == 0) {
@@ -424,17 +741,9 @@ __global__ __launch_bounds__(256) void sort_kernel(BatchView v, int lds_keys) {
     }
     uint32_t* gkeys = v.keys + static_cast<size_t>(f) * v.maxM;
     uint32_t* out = v.sorted + static_cast<size_t>(f) * v.maxM;
-    uint8_t* segstart = v.segstart + static_cast<size_t>(f) * (v.maxM + 1);
-    int2* seglist = v.seglist + static_cast<size_t>(f) * 2 * v.maxSeg;
-    uint32_t* a = gkeys;
-    if (n <= lds_keys) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            dyn_lds[i] = gkeys[i];
-        }
-        a = dyn_lds;
-        __syncthreads();
-    }
-    const int st = block_sort_desc(a, out, segstart, seglist, v.maxSeg, n, counters);
+    uint32_t* gsegbits = reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
+    int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
+    const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh);
     uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         rank_of[out[r] & INDEX_MASK] = static_cast<uint32_t>(r);
@@ -444,42 +753,39 @@ __global__ __launch_bounds__(256) void sort_kernel(BatchView v, int lds_keys) {
     }
 }
 
-__global__ __launch_bounds__(256) void debug_sort_kernel(uint32_t* keys, uint32_t* sorted, uint8_t* segstart,
-                                                         int2* seglist, int maxSeg, int n, int* status,
-                                                         int lds_keys) {
-    __shared__ int counters[4];
-    uint32_t* a = keys;
-    if (n <= lds_keys) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            dyn_lds[i] = keys[i];
-        }
-        a = dyn_lds;
-        __syncthreads();
-    }
-    const int st = block_sort_desc(a, sorted, segstart, seglist, maxSeg, n, counters);
+__global__ __launch_bounds__(SORT_THREADS) void debug_sort_kernel(uint32_t* keys, uint32_t* sorted, uint8_t* segstart,
+                                                                  int2* seglist, int maxSeg, int n, int* status,
+                                                                  int lds_keys) {
+    __shared__ SortShared sh;
+    const int st = block_sort_desc(keys, sorted, dyn_lds, lds_keys, reinterpret_cast<uint32_t*>(segstart), seglist,
+                                   maxSeg, n, sh);
     if (threadIdx.x == 0) {
         *status = st;
     }
 }
 
+
 int lds_keys_for(int maxM) {
-    // keys kept in LDS while they fit ~96 KiB (leaves room for a second workgroup per CU on
-    // small frames); larger frames fall back to global memory inside the same kernel
-    int cap = 24576;
-    return maxM < cap ? maxM : cap;
+    // keys kept in LDS while they fit ~96 KiB; longer arrays are first split in global memory by
+    // the workgroup-wide partition until every piece fits
+    const int cap = 24576;
+    return maxM < cap ? (maxM < 64 ? 64 : maxM) : cap;
+}
+
+size_t sort_lds_bytes(int lds_keys) {
+    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4;  // keys + leaf-flag words
+}
+void allow_big_lds(const void* fn) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(24576)));
 }
 
 }  // namespace
-
-void allow_big_lds(const void* fn) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
-}
 
 void launch_sort(const BatchView& v, int nframes, hipStream_t stream) {
     static const bool once = (allow_big_lds(reinterpret_cast<const void*>(sort_kernel)), true);
     (void)once;
     const int lds_keys = lds_keys_for(v.maxM);
-    hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(256), static_cast<size_t>(lds_keys) * 4, stream, v, lds_keys);
+    hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys);
 }
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
@@ -487,7 +793,7 @@ void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2
     static const bool once = (allow_big_lds(reinterpret_cast<const void*>(debug_sort_kernel)), true);
     (void)once;
     const int lds_keys = lds_keys_for(n);
-    hipLaunchKernelGGL(debug_sort_kernel, dim3(1), dim3(256), static_cast<size_t>(lds_keys) * 4, stream, keys, sorted,
+    hipLaunchKernelGGL(debug_sort_kernel, dim3(1), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, keys, sorted,
                        segstart, seglist, maxSeg, n, status, lds_keys);
 }
 

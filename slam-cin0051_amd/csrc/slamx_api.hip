@@ -558,8 +558,9 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&v.sorted, F * v.maxM);
     A(&v.rank_of, F * v.maxM);
     A(&v.state, F * v.maxM);
-    A(&v.segstart, F * (static_cast<size_t>(v.maxM) + 1));
-    A(&v.seglist, F * 2 * v.maxSeg);
+    v.segstart_stride = ((static_cast<size_t>(v.maxM) + 32) / 32 + 1) * 4;
+    A(&v.segstart, F * v.segstart_stride);
+    A(&v.seglist, F * 3 * v.maxSeg);
     A(&v.kps, F * v.maxK);
     A(&v.n_kp, F);
     A(&v.desc, F * v.maxK * v.width);
@@ -968,8 +969,8 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
     const int maxSeg = n / 16 + 16;
     int rc = dev_alloc(&dk, n);
     if (rc == SLAMX_OK) rc = dev_alloc(&ds, n);
-    if (rc == SLAMX_OK) rc = dev_alloc(&dseg, static_cast<size_t>(n) + 1);
-    if (rc == SLAMX_OK) rc = dev_alloc(&dlist, static_cast<size_t>(2) * maxSeg);
+    if (rc == SLAMX_OK) rc = dev_alloc(&dseg, (static_cast<size_t>(n) + 32) / 32 * 4 + 8);
+    if (rc == SLAMX_OK) rc = dev_alloc(&dlist, static_cast<size_t>(3) * maxSeg);
     if (rc == SLAMX_OK) rc = dev_alloc(&dstatus, 1);
     int st = 0;
     hipError_t e = hipSuccess;

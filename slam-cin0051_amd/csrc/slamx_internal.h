@@ -46,8 +46,9 @@ struct BatchView {
     uint8_t* state;          // [F][maxM]  NMS state by raster index
     uint8_t* nbr_cnt;        // [F][maxM]  number of cached earlier neighbours (NBR_OVERFLOW = too many)
     uint32_t* nbr;           // [F][maxM][NBR_CAP] raster indices of the earlier-ranked neighbours in radius
-    uint8_t* segstart;       // [F][maxM+1] leaf-segment start flags
-    int2* seglist;           // [F][2][maxSeg] level-synchronous segment lists
+    uint8_t* segstart;       // [F][segstart_stride] leaf-start bitmask scratch (used when it does not fit LDS)
+    size_t segstart_stride;  // bytes per frame, multiple of 4, >= (maxM+32)/8
+    int2* seglist;           // [F][3][maxSeg] two level lists + the list of LDS-sized segments
     slamx_keypoint* kps;     // [F][maxK]
     int* n_kp;               // [F]
     uint8_t* desc;           // [F][maxK][width]
