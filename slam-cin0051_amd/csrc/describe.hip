@@ -196,6 +196,211 @@ __global__ __launch_bounds__(256) void describe_kernel(BatchView v, DetectorPara
     }  // keypoint loop
 }
 
+// ---- fast path for PatchSize <= 31 (radius <= 15, rotated BRIEF offsets within +-21) ----
+// Three kernels so that the serial glibc trig chain (~300 dependent instructions) runs one
+// keypoint per LANE instead of once per 64-lane wave:
+//   moments_kernel : wave per keypoint; the 31-row neighbourhood is staged into LDS with coalesced
+//                    aligned dword loads, the 709 disc offsets come from a table built once per
+//                    workgroup (no divide per pixel); exact integer m01, m10.
+//   trig_kernel    : lane per keypoint; atan2f -> degrees (written to Keypoint::angle) -> cosf,
+//                    sinf (glibc_trig.h).
+//   brief_kernel   : wave per keypoint; the 43 x 48-byte neighbourhood staged into LDS, lane per
+//                    pattern pair, ballot packing.
+constexpr int TILE_HALF = 21;
+constexpr int TILE_ROWS = 2 * TILE_HALF + 1;  // 43
+constexpr int TILE_DW = 12;                   // 48 bytes: columns [x0a, x0a+48), x0a = (x-21) & ~3
+constexpr int MOM_HALF = 15;
+constexpr int MOM_ROWS = 2 * MOM_HALF + 1;    // 31
+constexpr int MOM_DW = 9;                     // 36 bytes: columns [x0a, x0a+36), x0a = (x-15) & ~3
+constexpr int MAX_DISC = 716;                 // pixels of the radius-15 disc (709) rounded up
+
+__global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParams P, int2* __restrict__ moments) {
+    __shared__ uint32_t tile[4][MOM_ROWS * MOM_DW];
+    __shared__ uint16_t disc[MAX_DISC];
+    __shared__ int disc_count;
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = v.n_kp[f];
+    const int radius = P.patch / 2;
+    if (threadIdx.x == 0) {
+        disc_count = 0;
+    }
+    __syncthreads();
+    {
+        // disc offsets (u,v) with u^2+v^2 <= r^2, any order (the integer moments are order-free)
+        const int side = 2 * radius + 1;
+        for (int t = threadIdx.x; t < side * side; t += 256) {
+            const int vv = t / side - radius;
+            const int uu = t - (vv + radius) * side - radius;
+            if (uu * uu + vv * vv <= radius * radius) {
+                const int slot = atomicAdd(&disc_count, 1);
+                disc[slot] = static_cast<uint16_t>(((vv + 128) << 8) | (uu + 128));
+            }
+        }
+    }
+    __syncthreads();
+    const int ndisc = disc_count;
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
+        const slamx_keypoint* kp = v.kps + static_cast<size_t>(f) * v.maxK + i;
+        const int x = static_cast<int>(kp->x);
+        const int y = static_cast<int>(kp->y);
+        const bool inside = !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
+        int m01 = 0;
+        int m10 = 0;
+        if (inside) {  // wave-uniform
+            const int x0a = (x - MOM_HALF) & ~3;
+            const int y0 = y - MOM_HALF;
+            for (int e = lane; e < MOM_ROWS * MOM_DW; e += 64) {
+                const int r = e / MOM_DW;
+                const int c = e - r * MOM_DW;
+                const int yy = y0 + r;
+                const int xx = x0a + c * 4;
+                uint32_t val = 0;
+                if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
+                    val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+                }
+                tile[wave][e] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cx = x - x0a;
+            for (int t = lane; t < ndisc; t += 64) {
+                const int d = disc[t];
+                const int vv = (d >> 8) - 128;
+                const int uu = (d & 0xff) - 128;
+                const int I = t8[(vv + MOM_HALF) * (MOM_DW * 4) + cx + uu];
+                m01 += vv * I;
+                m10 += uu * I;
+            }
+            m01 = wave_sum(m01);
+            m10 = wave_sum(m10);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            moments[static_cast<size_t>(f) * v.maxK + i] = make_int2(m01, inside ? m10 : 0x7fffffff);
+        }
+    }
+}
+
+// lane per keypoint: (m01, m10) -> angle -> cos, sin.  m10 == INT_MAX marks "patch leaves the
+// image": angle 0 and an all-zero descriptor (feature_detector.cpp:211-214, :242-245).
+__global__ __launch_bounds__(256) void trig_kernel(BatchView v, const int2* __restrict__ moments,
+                                                   float2* __restrict__ cs) {
+    const int f = blockIdx.y;
+    const int n = v.n_kp[f];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 m = moments[static_cast<size_t>(f) * v.maxK + i];
+        float angle = 0.0f;
+        float2 r = make_float2(0.0f, 0.0f);
+        if (m.y != 0x7fffffff) {
+            angle = __fmul_rn(glibc_atan2f(static_cast<float>(m.x), static_cast<float>(m.y)), rad_to_deg());
+            const float a = __fmul_rn(angle, deg_to_rad());
+            r = make_float2(glibc_cosf(a), glibc_sinf(a));
+        } else {
+            r.x = __uint_as_float(0x7fc00000u);  // NaN cos marks "outside" for brief_kernel
+        }
+        v.kps[static_cast<size_t>(f) * v.maxK + i].angle = angle;  // feature_detector.cpp:37-38
+        cs[static_cast<size_t>(f) * v.maxK + i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
+                                                    const float2* __restrict__ cs) {
+    __shared__ uint32_t tile[4][TILE_ROWS * TILE_DW];
+    __shared__ unsigned long long dbuf[4][DESC_WORDS];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = v.n_kp[f];
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
+        const slamx_keypoint* kp = v.kps + static_cast<size_t>(f) * v.maxK + i;
+        uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
+        const int x = static_cast<int>(kp->x);
+        const int y = static_cast<int>(kp->y);
+        const float2 r = cs[static_cast<size_t>(f) * v.maxK + i];
+        const bool inside = r.x == r.x;  // not NaN
+        const int words = (v.width + 7) / 8;
+        if (lane < words) {
+            dbuf[wave][lane] = 0ull;
+        }
+        if (inside) {  // wave-uniform
+            const int x0a = (x - TILE_HALF) & ~3;
+            const int y0 = y - TILE_HALF;
+            for (int e = lane; e < TILE_ROWS * TILE_DW; e += 64) {
+                const int rr = e / TILE_DW;
+                const int c = e - rr * TILE_DW;
+                const int yy = y0 + rr;
+                const int xx = x0a + c * 4;
+                uint32_t val = 0;
+                if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
+                    val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+                }
+                tile[wave][e] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cx = x - x0a;  // pixel (x+du, y+dv) lives at t8[(dv + 21) * 48 + cx + du]
+            const float ca = r.x;
+            const float sa = r.y;
+            int bitIndex = 0;
+            for (int base = 0; base < P.pattern_len; base += 64) {
+                const int pi = base + lane;
+                bool valid = false;
+                bool bit = false;
+                if (pi < P.pattern_len) {
+                    const float p1x = static_cast<float>(pattern[4 * pi + 0]);
+                    const float p1y = static_cast<float>(pattern[4 * pi + 1]);
+                    const float p2x = static_cast<float>(pattern[4 * pi + 2]);
+                    const float p2y = static_cast<float>(pattern[4 * pi + 3]);
+                    const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(p1x, ca), __fmul_rn(p1y, sa)));
+                    const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(p1x, sa), __fmul_rn(p1y, ca)));
+                    const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(p2x, ca), __fmul_rn(p2y, sa)));
+                    const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(p2x, sa), __fmul_rn(p2y, ca)));
+                    const int x1 = dx1 + x, y1 = dy1 + y, x2 = dx2 + x, y2 = dy2 + y;
+                    valid = x1 >= 0 && x1 < v.cols && y1 >= 0 && y1 < v.rows && x2 >= 0 && x2 < v.cols && y2 >= 0 &&
+                            y2 < v.rows;
+                    if (valid) {
+                        const uint8_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
+                        const uint8_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
+                        bit = I1 < I2;
+                    }
+                }
+                const unsigned long long vm = __ballot(valid);
+                const unsigned long long bm = __ballot(valid && bit);
+                const int cnt = __popcll(vm);
+                bool outbit = false;
+                if (lane < cnt) {
+                    outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                }
+                const unsigned long long packed = __ballot(outbit);
+                if (lane == 0 && cnt > 0) {
+                    const int w = bitIndex >> 6;
+                    const int sh = bitIndex & 63;
+                    dbuf[wave][w] |= packed << sh;
+                    if (sh != 0 && sh + cnt > 64) {
+                        dbuf[wave][w + 1] |= packed >> (64 - sh);
+                    }
+                }
+                bitIndex += cnt;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* d8 = reinterpret_cast<const uint8_t*>(dbuf[wave]);
+        for (int b = lane; b < v.width; b += 64) {
+            desc[b] = d8[b];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
@@ -213,7 +418,14 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     }
     const int exact_int = (255LL * sum_abs < (1LL << 24)) ? 1 : 0;
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, exact_int);
+    if (radius <= 15 && exact_int != 0 && v.moments != nullptr) {
+        hipLaunchKernelGGL(moments_kernel, grid, dim3(256), 0, stream, v, p, v.moments);
+        hipLaunchKernelGGL(trig_kernel, dim3(grid_x(v.maxK, 256, nframes), nframes), dim3(256), 0, stream, v, v.moments,
+                           v.cos_sin);
+        hipLaunchKernelGGL(brief_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, v.cos_sin);
+    } else {
+        hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, exact_int);
+    }
 }
 
 }  // namespace slamx

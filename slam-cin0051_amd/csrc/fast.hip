@@ -15,7 +15,7 @@
 //                     (row-major, word-major) -> the raster index of every corner is
 //                     wordoff[word] + popcount(bits below it).  This bitmap+prefix pair is also
 //                     the spatial index the NMS kernel uses, so no cell grid is ever built.
-//   K1c expand      : one wave per non-empty word; lanes = set bits; writes (x,y) and the
+//   K1c expand      : one lane per bitmap word walks its set bits; writes (x,y) and the
 //                     sort key score<<20|rasterIndex in raster order.
 #include "slamx_internal.h"
 
@@ -222,7 +222,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
     }
 }
 
-// One wave per bitmap word (grid-stride); lanes = set bits.
+// One lane per bitmap word (coalesced 8-byte loads; ~half of the words hold a corner, usually
+// one): the lane walks its set bits and writes (x,y) and the sort key of each corner.
 __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
     const int f = blockIdx.y;
     const int m_total = v.n_cand[f];
@@ -230,24 +231,24 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
         return;
     }
     const int n = v.rows * v.nw;
-    const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
-    const uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
-    const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
+    const unsigned long long* __restrict__ masks = v.masks + static_cast<size_t>(f) * n;
+    const uint32_t* __restrict__ off = v.wordoff + static_cast<size_t>(f) * n;
+    const uint8_t* __restrict__ img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * 4;
-    for (int w = wave_global; w < n; w += n_waves) {
-        const unsigned long long m = masks[w];
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+        unsigned long long m = masks[w];
         if (m == 0) {
-            continue;  // wave-uniform
+            continue;
         }
-        if ((m >> lane) & 1ull) {
-            const int row = w / v.nw;
-            const int x = (w - row * v.nw) * 64 + lane;
-            const uint32_t idx = off[w] + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-            const uint8_t* p = img + static_cast<size_t>(row) * v.pitch + x;
+        const int row = w / v.nw;
+        const int x0 = (w - row * v.nw) * 64;
+        uint32_t idx = off[w];
+        const uint8_t* prow = img + static_cast<size_t>(row) * v.pitch + x0;
+        while (m != 0) {
+            const int b = __ffsll(static_cast<long long>(m)) - 1;
+            m &= m - 1;
+            const uint8_t* p = prow + b;
             const int c = p[0];
             int score = 0;
 #pragma unroll
@@ -255,8 +256,9 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
                 const int nb = p[CIRC_DY[q] * v.pitch + CIRC_DX[q]];
                 score += abs(nb - c);
             }
-            xy[idx] = (static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x);
+            xy[idx] = (static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x0 + b);
             keys[idx] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | idx;
+            ++idx;
         }
     }
 }
@@ -275,11 +277,7 @@ void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {
 void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
     (void)p;
     const int n = v.rows * v.nw;
-    int blocks = (n + 4 * 8 - 1) / (4 * 8);  // ~8 words per wave
-    if (blocks < 1) {
-        blocks = 1;
-    }
-    hipLaunchKernelGGL(expand_kernel, dim3(blocks, nframes), dim3(256), 0, stream, v);
+    hipLaunchKernelGGL(expand_kernel, dim3(grid_x(n, 256, nframes), nframes), dim3(256), 0, stream, v);
 }
 
 }  // namespace slamx

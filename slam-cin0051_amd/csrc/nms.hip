@@ -13,11 +13,12 @@
 //                      FAST corner bitmap rows y-(w-1)..y+(w-1) and its prefix sums (fast.hip)
 //                      -- no cell grid -- and the earlier-ranked ones inside the radius are
 //                      cached (up to NBR_CAP raster indices); no earlier neighbour => KEPT.
-//   nms_round_kernel : re-evaluates the undecided candidates from their cached lists (a list
-//                      that overflowed falls back to re-enumeration).
-//   nms_finish_kernel: one workgroup per frame loops to the fix-point (dependency chains can be
-//                      long on straight edges), then emits the kept keypoints in rank order
-//                      (feature_detector.cpp:170, :187).
+//   nms_round_kernel : two fully parallel rounds from the cached lists (stored transposed, so
+//                      the reads are coalesced).
+//   nms_finish_kernel: one workgroup per frame copies the states into LDS and loops rounds to the
+//                      fix-point from the cached lists (a list that overflowed falls back to
+//                      re-enumeration; dependency chains can be long on straight edges), then
+//                      emits the kept keypoints in rank order (feature_detector.cpp:170, :187).
 #include "slamx_internal.h"
 
 #pragma clang fp contract(off)
@@ -84,6 +85,9 @@ __device__ __forceinline__ void for_each_earlier_neighbour(const BatchView& v, i
     }
 }
 
+// One lane per candidate, candidates in RASTER order: neighbouring lanes probe the same bitmap
+// rows, so the loads of a wave hit a handful of cache lines.  The cached list is stored
+// TRANSPOSED (entry k of candidate i at nbr[k * maxM + i]) so that later rounds read it coalesced.
 __global__ __launch_bounds__(256) void nms_build_kernel(BatchView v, int window) {
     const int f = blockIdx.y;
     const int n = v.n_cand[f];
@@ -99,10 +103,9 @@ __global__ __launch_bounds__(256) void nms_build_kernel(BatchView v, int window)
         me.y = static_cast<int>(pxy >> 16);
         me.rank = rank_of[i];
         int cnt = 0;
-        uint32_t* mine = nbr + static_cast<size_t>(i) * NBR_CAP;
         for_each_earlier_neighbour(v, f, me, window, rank_of, [&](uint32_t nidx) {
             if (cnt < NBR_CAP) {
-                mine[cnt] = nidx;
+                nbr[static_cast<size_t>(cnt) * v.maxM + i] = nidx;
             }
             ++cnt;
             return true;
@@ -119,9 +122,8 @@ __device__ __forceinline__ uint8_t nms_decide(const BatchView& v, int f, int i, 
     const int cnt = nbr_cnt[i];
     bool all_decided = true;
     if (cnt != NBR_OVERFLOW) {
-        const uint32_t* mine = nbr + static_cast<size_t>(i) * NBR_CAP;
         for (int k = 0; k < cnt; ++k) {
-            const uint8_t s = state[mine[k]];
+            const uint8_t s = state[nbr[static_cast<size_t>(k) * v.maxM + i]];
             if (s == NMS_KEPT) {
                 return NMS_SUPPRESSED;
             }
@@ -150,6 +152,8 @@ __device__ __forceinline__ uint8_t nms_decide(const BatchView& v, int f, int i, 
     return all_decided ? NMS_KEPT : NMS_UNDECIDED;
 }
 
+// One fully parallel round on the global states (most candidates are decided in the first two
+// rounds: "has a KEPT earlier neighbour"); the per-frame finisher below runs the long tail.
 __global__ __launch_bounds__(256) void nms_round_kernel(BatchView v, int window) {
     const int f = blockIdx.y;
     const int n = v.n_cand[f];
@@ -169,7 +173,9 @@ __global__ __launch_bounds__(256) void nms_round_kernel(BatchView v, int window)
     }
 }
 
-__global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int window) {
+extern __shared__ uint8_t lds_state[];
+
+__global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int window, int lds_cap) {
     __shared__ int pending;
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry;
@@ -178,12 +184,22 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int windo
     if (n == 0) {
         return;
     }
-    uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;
+    uint8_t* gstate = v.state + static_cast<size_t>(f) * v.maxM;
     const uint32_t* sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
     const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     const uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
     const uint8_t* nbr_cnt = v.nbr_cnt + static_cast<size_t>(f) * v.maxM;
     const uint32_t* nbr = v.nbr + static_cast<size_t>(f) * v.maxM * NBR_CAP;
+    // all rounds run on a copy of the state in LDS when it fits (it always does below 128 Ki
+    // candidates); the fix-point is the same wherever the bytes live
+    uint8_t* state = gstate;
+    if (n <= lds_cap) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            lds_state[i] = gstate[i];
+        }
+        state = lds_state;
+        __syncthreads();
+    }
     // every round decides at least the lowest-ranked undecided candidate, so n rounds bound the
     // loop; the bound only guards the GPU against a corrupted rank table
     for (int iter = 0; iter <= n; ++iter) {
@@ -296,17 +312,23 @@ __global__ __launch_bounds__(256) void passthrough_kernel(BatchView v) {
     }
 }
 
-constexpr int NMS_PARALLEL_ROUNDS = 3;
+constexpr int NMS_PARALLEL_ROUNDS = 2;
 
 }  // namespace
 
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
+    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
+                              true);
+    (void)once;
     dim3 grid(grid_x(v.maxM, 256, nframes), nframes);
     hipLaunchKernelGGL(nms_build_kernel, grid, dim3(256), 0, stream, v, p.window);
     for (int r = 0; r < NMS_PARALLEL_ROUNDS; ++r) {
         hipLaunchKernelGGL(nms_round_kernel, grid, dim3(256), 0, stream, v, p.window);
     }
-    hipLaunchKernelGGL(nms_finish_kernel, dim3(nframes), dim3(1024), 0, stream, v, p.window);
+    const int lds_cap = v.maxM < 131072 ? (v.maxM + 15) / 16 * 16 : 131072;
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(nframes), dim3(1024), static_cast<size_t>(lds_cap), stream, v, p.window,
+                       lds_cap);
 }
 
 void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream) {

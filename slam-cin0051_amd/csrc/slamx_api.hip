@@ -564,6 +564,8 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&v.kps, F * v.maxK);
     A(&v.n_kp, F);
     A(&v.desc, F * v.maxK * v.width);
+    A(&v.moments, F * v.maxK);
+    A(&v.cos_sin, F * v.maxK);
     A(&v.status, F);
     A(&v.nbr_cnt, F * v.maxM);
     A(&v.nbr, F * v.maxM * NBR_CAP);
@@ -616,6 +618,8 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.kps);
     dev_free(v.n_kp);
     dev_free(v.desc);
+    dev_free(v.moments);
+    dev_free(v.cos_sin);
     dev_free(v.status);
     dev_free(v.nbr_cnt);
     dev_free(v.nbr);

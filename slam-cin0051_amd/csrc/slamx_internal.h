@@ -52,6 +52,8 @@ struct BatchView {
     slamx_keypoint* kps;     // [F][maxK]
     int* n_kp;               // [F]
     uint8_t* desc;           // [F][maxK][width]
+    int2* moments;           // [F][maxK] {m01, m10} scratch of the describe stage
+    float2* cos_sin;         // [F][maxK] {cos, sin} scratch of the describe stage
     int* status;             // [F]
     int maxM, maxK, maxSeg, width;
 };
