@@ -214,6 +214,42 @@ constexpr int MOM_ROWS = 2 * MOM_HALF + 1;    // 31
 constexpr int MOM_DW = 9;                     // 36 bytes: columns [x0a, x0a+36), x0a = (x-15) & ~3
 constexpr int MAX_DISC = 716;                 // pixels of the radius-15 disc (709) rounded up
 
+// Both wave-per-keypoint kernels below are latency chains (keypoint -> tile -> result), so each
+// wave (1) fetches the coordinates of up to 64 of its keypoints with ONE coalesced load and hands
+// them out with readlane, and (2) issues the global loads of the NEXT keypoint's tile into
+// registers before it computes on the current one, committing them to LDS afterwards.
+template <int ROWS, int DW, int HALF>
+struct TilePrefetch {
+    static constexpr int PER_LANE = (ROWS * DW + 63) / 64;
+    uint32_t reg[PER_LANE];
+    __device__ __forceinline__ void issue(const BatchView& v, const uint8_t* img, int x, int y, int lane) {
+        const int x0a = (x - HALF) & ~3;
+        const int y0 = y - HALF;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            const int r = e / DW;
+            const int c = e - r * DW;
+            const int yy = y0 + r;
+            const int xx = x0a + c * 4;
+            uint32_t val = 0;
+            if (e < ROWS * DW && yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
+                val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+            }
+            reg[k] = val;
+        }
+    }
+    __device__ __forceinline__ void commit(uint32_t* tile, int lane) const {
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            if (e < ROWS * DW) {
+                tile[e] = reg[k];
+            }
+        }
+    }
+};
+
 __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParams P, int2* __restrict__ moments) {
     __shared__ uint32_t tile[4][MOM_ROWS * MOM_DW];
     __shared__ uint16_t disc[MAX_DISC];
@@ -243,45 +279,63 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
     const int ndisc = disc_count;
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
-    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
-        const slamx_keypoint* kp = v.kps + static_cast<size_t>(f) * v.maxK + i;
-        const int x = static_cast<int>(kp->x);
-        const int y = static_cast<int>(kp->y);
-        const bool inside = !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
-        int m01 = 0;
-        int m10 = 0;
-        if (inside) {  // wave-uniform
-            const int x0a = (x - MOM_HALF) & ~3;
-            const int y0 = y - MOM_HALF;
-            for (int e = lane; e < MOM_ROWS * MOM_DW; e += 64) {
-                const int r = e / MOM_DW;
-                const int c = e - r * MOM_DW;
-                const int yy = y0 + r;
-                const int xx = x0a + c * 4;
-                uint32_t val = 0;
-                if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
-                    val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
-                }
-                tile[wave][e] = val;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int cx = x - x0a;
-            for (int t = lane; t < ndisc; t += 64) {
-                const int d = disc[t];
-                const int vv = (d >> 8) - 128;
-                const int uu = (d & 0xff) - 128;
-                const int I = t8[(vv + MOM_HALF) * (MOM_DW * 4) + cx + uu];
-                m01 += vv * I;
-                m10 += uu * I;
-            }
-            m01 = wave_sum(m01);
-            m10 = wave_sum(m10);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+    const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const int stride = gridDim.x * 4;
+    const int i0 = blockIdx.x * 4 + wave;
+    TilePrefetch<MOM_ROWS, MOM_DW, MOM_HALF> pf;
+    for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
+        // lane j holds the coordinates of this wave's (chunk + j)-th keypoint
+        const int mine = i0 + (chunk + lane) * stride;
+        int kx = 0, ky = 0;
+        if (mine < n) {
+            kx = static_cast<int>(kps[mine].x);
+            ky = static_cast<int>(kps[mine].y);
         }
-        if (lane == 0) {
-            moments[static_cast<size_t>(f) * v.maxK + i] = make_int2(m01, inside ? m10 : 0x7fffffff);
+        const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
+        auto is_inside = [&](int x, int y) {
+            return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
+        };
+        int x = __shfl(kx, 0);
+        int y = __shfl(ky, 0);
+        if (is_inside(x, y)) {
+            pf.issue(v, img, x, y, lane);
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const int i = i0 + (chunk + k) * stride;
+            const bool inside = is_inside(x, y);  // wave-uniform
+            if (inside) {
+                pf.commit(tile[wave], lane);
+            }
+            const int cx = x - ((x - MOM_HALF) & ~3);
+            // prefetch the next keypoint's tile while this one is reduced
+            const int xn = __shfl(kx, (k + 1) & 63);
+            const int yn = __shfl(ky, (k + 1) & 63);
+            if (k + 1 < cnt && is_inside(xn, yn)) {
+                pf.issue(v, img, xn, yn, lane);
+            }
+            int m01 = 0;
+            int m10 = 0;
+            if (inside) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int t = lane; t < ndisc; t += 64) {
+                    const int d = disc[t];
+                    const int vv = (d >> 8) - 128;
+                    const int uu = (d & 0xff) - 128;
+                    const int I = t8[(vv + MOM_HALF) * (MOM_DW * 4) + cx + uu];
+                    m01 += vv * I;
+                    m10 += uu * I;
+                }
+                m01 = wave_sum(m01);
+                m10 = wave_sum(m10);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) {
+                moments[static_cast<size_t>(f) * v.maxK + i] = make_int2(m01, inside ? m10 : 0x7fffffff);
+            }
+            x = xn;
+            y = yn;
         }
     }
 }
@@ -318,86 +372,118 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     const int n = v.n_kp[f];
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
-    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
-        const slamx_keypoint* kp = v.kps + static_cast<size_t>(f) * v.maxK + i;
-        uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
-        const int x = static_cast<int>(kp->x);
-        const int y = static_cast<int>(kp->y);
-        const float2 r = cs[static_cast<size_t>(f) * v.maxK + i];
-        const bool inside = r.x == r.x;  // not NaN
-        const int words = (v.width + 7) / 8;
-        if (lane < words) {
-            dbuf[wave][lane] = 0ull;
+    const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const float2* csf = cs + static_cast<size_t>(f) * v.maxK;
+    const int stride = gridDim.x * 4;
+    const int i0 = blockIdx.x * 4 + wave;
+    const int words = (v.width + 7) / 8;
+    // this lane's pattern pair of the first 64-pair chunk (loop invariant)
+    float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f;
+    if (lane < P.pattern_len) {
+        q1x = static_cast<float>(pattern[4 * lane + 0]);
+        q1y = static_cast<float>(pattern[4 * lane + 1]);
+        q2x = static_cast<float>(pattern[4 * lane + 2]);
+        q2y = static_cast<float>(pattern[4 * lane + 3]);
+    }
+    TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
+    for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
+        const int mine = i0 + (chunk + lane) * stride;
+        int kx = 0, ky = 0;
+        float kc = 0.0f, ks = 0.0f;
+        if (mine < n) {
+            kx = static_cast<int>(kps[mine].x);
+            ky = static_cast<int>(kps[mine].y);
+            const float2 r = csf[mine];
+            kc = r.x;
+            ks = r.y;
         }
-        if (inside) {  // wave-uniform
-            const int x0a = (x - TILE_HALF) & ~3;
-            const int y0 = y - TILE_HALF;
-            for (int e = lane; e < TILE_ROWS * TILE_DW; e += 64) {
-                const int rr = e / TILE_DW;
-                const int c = e - rr * TILE_DW;
-                const int yy = y0 + rr;
-                const int xx = x0a + c * 4;
-                uint32_t val = 0;
-                if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
-                    val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+        const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
+        int x = __shfl(kx, 0);
+        int y = __shfl(ky, 0);
+        float ca = __shfl(kc, 0);
+        float sa = __shfl(ks, 0);
+        if (ca == ca) {
+            pf.issue(v, img, x, y, lane);
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const int i = i0 + (chunk + k) * stride;
+            uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
+            const bool inside = ca == ca;  // NaN cos marks "patch leaves the image" (wave-uniform)
+            if (lane < words) {
+                dbuf[wave][lane] = 0ull;
+            }
+            if (inside) {
+                pf.commit(tile[wave], lane);
+            }
+            const int xn = __shfl(kx, (k + 1) & 63);
+            const int yn = __shfl(ky, (k + 1) & 63);
+            const float can = __shfl(kc, (k + 1) & 63);
+            const float san = __shfl(ks, (k + 1) & 63);
+            if (k + 1 < cnt && can == can) {
+                pf.issue(v, img, xn, yn, lane);
+            }
+            if (inside) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int cx = x - ((x - TILE_HALF) & ~3);  // pixel (x+du, y+dv) at t8[(dv+21)*48 + cx + du]
+                int bitIndex = 0;
+                for (int base = 0; base < P.pattern_len; base += 64) {
+                    const int pi = base + lane;
+                    bool valid = false;
+                    bool bit = false;
+                    if (pi < P.pattern_len) {
+                        float p1x = q1x, p1y = q1y, p2x = q2x, p2y = q2y;
+                        if (base != 0) {
+                            p1x = static_cast<float>(pattern[4 * pi + 0]);
+                            p1y = static_cast<float>(pattern[4 * pi + 1]);
+                            p2x = static_cast<float>(pattern[4 * pi + 2]);
+                            p2y = static_cast<float>(pattern[4 * pi + 3]);
+                        }
+                        const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(p1x, ca), __fmul_rn(p1y, sa)));
+                        const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(p1x, sa), __fmul_rn(p1y, ca)));
+                        const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(p2x, ca), __fmul_rn(p2y, sa)));
+                        const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(p2x, sa), __fmul_rn(p2y, ca)));
+                        const int x1 = dx1 + x, y1 = dy1 + y, x2 = dx2 + x, y2 = dy2 + y;
+                        valid = x1 >= 0 && x1 < v.cols && y1 >= 0 && y1 < v.rows && x2 >= 0 && x2 < v.cols &&
+                                y2 >= 0 && y2 < v.rows;
+                        if (valid) {
+                            const uint8_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
+                            const uint8_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
+                            bit = I1 < I2;
+                        }
+                    }
+                    const unsigned long long vm = __ballot(valid);
+                    const unsigned long long bm = __ballot(valid && bit);
+                    const int c2 = __popcll(vm);
+                    bool outbit = false;
+                    if (lane < c2) {
+                        outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                    }
+                    const unsigned long long packed = __ballot(outbit);
+                    if (lane == 0 && c2 > 0) {
+                        const int w = bitIndex >> 6;
+                        const int sh = bitIndex & 63;
+                        dbuf[wave][w] |= packed << sh;
+                        if (sh != 0 && sh + c2 > 64) {
+                            dbuf[wave][w + 1] |= packed >> (64 - sh);
+                        }
+                    }
+                    bitIndex += c2;
                 }
-                tile[wave][e] = val;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int cx = x - x0a;  // pixel (x+du, y+dv) lives at t8[(dv + 21) * 48 + cx + du]
-            const float ca = r.x;
-            const float sa = r.y;
-            int bitIndex = 0;
-            for (int base = 0; base < P.pattern_len; base += 64) {
-                const int pi = base + lane;
-                bool valid = false;
-                bool bit = false;
-                if (pi < P.pattern_len) {
-                    const float p1x = static_cast<float>(pattern[4 * pi + 0]);
-                    const float p1y = static_cast<float>(pattern[4 * pi + 1]);
-                    const float p2x = static_cast<float>(pattern[4 * pi + 2]);
-                    const float p2y = static_cast<float>(pattern[4 * pi + 3]);
-                    const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(p1x, ca), __fmul_rn(p1y, sa)));
-                    const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(p1x, sa), __fmul_rn(p1y, ca)));
-                    const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(p2x, ca), __fmul_rn(p2y, sa)));
-                    const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(p2x, sa), __fmul_rn(p2y, ca)));
-                    const int x1 = dx1 + x, y1 = dy1 + y, x2 = dx2 + x, y2 = dy2 + y;
-                    valid = x1 >= 0 && x1 < v.cols && y1 >= 0 && y1 < v.rows && x2 >= 0 && x2 < v.cols && y2 >= 0 &&
-                            y2 < v.rows;
-                    if (valid) {
-                        const uint8_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
-                        const uint8_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
-                        bit = I1 < I2;
-                    }
-                }
-                const unsigned long long vm = __ballot(valid);
-                const unsigned long long bm = __ballot(valid && bit);
-                const int cnt = __popcll(vm);
-                bool outbit = false;
-                if (lane < cnt) {
-                    outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
-                }
-                const unsigned long long packed = __ballot(outbit);
-                if (lane == 0 && cnt > 0) {
-                    const int w = bitIndex >> 6;
-                    const int sh = bitIndex & 63;
-                    dbuf[wave][w] |= packed << sh;
-                    if (sh != 0 && sh + cnt > 64) {
-                        dbuf[wave][w + 1] |= packed >> (64 - sh);
-                    }
-                }
-                bitIndex += cnt;
+            const uint8_t* d8 = reinterpret_cast<const uint8_t*>(dbuf[wave]);
+            for (int b = lane; b < v.width; b += 64) {
+                desc[b] = d8[b];
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            x = xn;
+            y = yn;
+            ca = can;
+            sa = san;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint8_t* d8 = reinterpret_cast<const uint8_t*>(dbuf[wave]);
-        for (int b = lane; b < v.width; b += 64) {
-            desc[b] = d8[b];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
