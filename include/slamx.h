@@ -194,6 +194,36 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
 int slamx_batch_set_profiling(slamx_batch* b, int n_sets);
 int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms /* SLAMX_STAGE_COUNT entries */);
 
+/* ---- small dense pose solves (src/backend/loop_closure.cpp, src/frontend/simple_pose_recover.cpp) ----
+ * Host pointers, double precision, row-major 3x3 / 3x4 matrices.  The reference delegates these
+ * to Eigen::JacobiSVD / cv::SVD (third-party, sign conventions unpinned): results agree with a
+ * double-precision SVD to ~1e-12; singular-vector signs are this implementation's own. */
+/* LoopClosure::solvePnP (loop_closure.cpp:238-274) for n_hyp independent point sets of n_points
+ * (>= 6, <= 32) each: p3d [n_hyp][n_points][3], p2d [n_hyp][n_points][2] -> R [n_hyp][9],
+ * t [n_hyp][3]; nullvec (optional) [n_hyp][12] = the DLT null vector.  The 2n x 12 system is
+ * contracted on the FP64 matrix cores. */
+int slamx_pnp_dlt_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n_points, int n_hyp, double* R,
+                        double* t, double* nullvec);
+/* Inlier count of n_hyp poses over n correspondences (loop_closure.cpp:201-215). */
+int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
+                              const double* R, const double* t, int n_hyp, double threshold, int32_t* counts);
+/* The RANSAC loop of verifyGeometricConsistency (loop_closure.cpp:173-222) with an explicit seed
+ * (the reference seeds std::mt19937 from std::random_device): sampling with the same
+ * std::mt19937 / std::uniform_int_distribution calls on the host, all solves and counts in two
+ * GPU launches, first maximum wins.  max_inliers == 0 leaves R = I, t = 0 as the reference does. */
+int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, int iterations,
+                     double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers);
+/* simpleRecoverPose (simple_pose_recover.cpp:35-98): E 3x3, pts1/pts2 n x 2 float (normalised
+ * points as PoseEstimator::estimate passes them), K 3x3 -> R 3x3, t 3; front (optional) gets the
+ * four cheirality counts. */
+int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
+                       double* R, double* t, int32_t* front);
+/* slam::triangulate + the conversion loop of PoseEstimator::triangulatePoints (common.hpp:201-221,
+ * pose_estimator.cpp:94-101): P1, P2 3x4, pts n x 2 float pixel coordinates -> x4 (optional)
+ * n x 4 float homogeneous, xyz n x 3 double. */
+int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
+                      float* x4, double* xyz);
+
 /* ---- deterministic synthetic frames, host side, for tests and bench ---- */
 /* Frame k of the sequence with the given seed: background 96, n_rect filled rectangles with
  * sides in [rect_min, rect_max], per-pixel noise in [-4,4], translated by (2k mod 64, k mod 32). */

@@ -78,7 +78,8 @@ EXPORTS = [
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame",
+    "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
+    "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_recover_pose", "slamx_triangulate",
 ]
 
 _lib = None
@@ -137,6 +138,11 @@ def load_library():
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    lib.slamx_pnp_dlt_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.slamx_count_inliers_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, vp]
+    lib.slamx_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, C.POINTER(C.c_int32)]
+    lib.slamx_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.slamx_synth_frame.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     _lib = lib
     return lib
@@ -234,6 +240,64 @@ class Context:
         perm = np.empty(s.shape[0], np.uint32)
         _check(self.lib.slamx_debug_sort_desc(self.h, _ptr(s), s.shape[0], _ptr(perm)))
         return perm
+
+    # ---- small dense pose solves (rows a11-a14) ----
+    def pnp_dlt_batch(self, p3d, p2d):
+        """LoopClosure::solvePnP for a batch: p3d [H, n, 3], p2d [H, n, 2] -> R [H,3,3], t [H,3], null [H,12]."""
+        a = np.ascontiguousarray(p3d, dtype=np.float64)
+        b = np.ascontiguousarray(p2d, dtype=np.float64)
+        H, n = a.shape[0], a.shape[1]
+        R = np.empty((H, 3, 3))
+        t = np.empty((H, 3))
+        nv = np.empty((H, 12))
+        _check(self.lib.slamx_pnp_dlt_batch(self.h, _ptr(a), _ptr(b), n, H, _ptr(R), _ptr(t), _ptr(nv)))
+        return R, t, nv
+
+    def count_inliers_batch(self, p3d, p2d, K, R, t, threshold):
+        a = np.ascontiguousarray(p3d, dtype=np.float64)
+        b = np.ascontiguousarray(p2d, dtype=np.float64)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        Rc = np.ascontiguousarray(R, dtype=np.float64)
+        tc = np.ascontiguousarray(t, dtype=np.float64)
+        H = Rc.shape[0]
+        counts = np.zeros(H, np.int32)
+        _check(self.lib.slamx_count_inliers_batch(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(Rc), _ptr(tc), H,
+                                                  float(threshold), _ptr(counts)))
+        return counts
+
+    def pnp_ransac(self, p3d, p2d, K, iterations, threshold, seed):
+        a = np.ascontiguousarray(p3d, dtype=np.float64)
+        b = np.ascontiguousarray(p2d, dtype=np.float64)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        R = np.empty((3, 3))
+        t = np.empty(3)
+        best = C.c_int32()
+        _check(self.lib.slamx_pnp_ransac(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), iterations, float(threshold),
+                                         seed, _ptr(R), _ptr(t), C.byref(best)))
+        return R, t, best.value
+
+    def recover_pose(self, E, pts1, pts2, K):
+        Ec = np.ascontiguousarray(E, dtype=np.float64)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        a = np.ascontiguousarray(pts1, dtype=np.float32)
+        b = np.ascontiguousarray(pts2, dtype=np.float32)
+        R = np.empty((3, 3))
+        t = np.empty(3)
+        front = np.zeros(4, np.int32)
+        _check(self.lib.slamx_recover_pose(self.h, _ptr(Ec), _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(R), _ptr(t),
+                                           _ptr(front)))
+        return R, t, front
+
+    def triangulate(self, P1, P2, pts1, pts2):
+        A = np.ascontiguousarray(P1, dtype=np.float64)
+        B = np.ascontiguousarray(P2, dtype=np.float64)
+        a = np.ascontiguousarray(pts1, dtype=np.float32)
+        b = np.ascontiguousarray(pts2, dtype=np.float32)
+        n = a.shape[0]
+        x4 = np.empty((n, 4), np.float32)
+        xyz = np.empty((n, 3))
+        _check(self.lib.slamx_triangulate(self.h, _ptr(A), _ptr(B), _ptr(a), _ptr(b), n, _ptr(x4), _ptr(xyz)))
+        return x4, xyz
 
     def debug_penalty(self, dist, qx, qy, tx, ty):
         d = np.ascontiguousarray(dist, dtype=np.int32)

@@ -1237,6 +1237,217 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     return SLAMX_OK;
 }
 
+// ------------------------------------------------------------------ pose solves
+extern "C++" {
+namespace {
+
+// Scoped device buffers for the host-pointer pose API (small, per call).
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p != nullptr) {
+            (void)hipFree(p);
+        }
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 1); }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+}  // namespace
+}  // extern "C++"
+
+int slamx_pnp_dlt_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n_points, int n_hyp, double* R,
+                        double* t, double* nullvec) {
+    if (n_points < 6) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "solvePnP needs at least 6 points");  // returns false in the reference
+    }
+    if (n_points > 32 || n_hyp < 0 || p3d == nullptr || p2d == nullptr || R == nullptr || t == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pnp arguments invalid (6 <= n_points <= 32)");
+    }
+    if (n_hyp == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t H = static_cast<size_t>(n_hyp);
+    DevBuf d3, d2, dR, dt, dn;
+    HIP_TRY(d3.alloc(H * n_points * 3 * sizeof(double)));
+    HIP_TRY(d2.alloc(H * n_points * 2 * sizeof(double)));
+    HIP_TRY(dR.alloc(H * 9 * sizeof(double)));
+    HIP_TRY(dt.alloc(H * 3 * sizeof(double)));
+    HIP_TRY(dn.alloc(H * 12 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d3.p, p3d, H * n_points * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d2.p, p2d, H * n_points * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_pnp_dlt(d3.as<double>(), d2.as<double>(), n_points, n_hyp, dR.as<double>(), dt.as<double>(), dn.as<double>(), s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(R, dR.p, H * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(t, dt.p, H * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (nullvec != nullptr) {
+        HIP_TRY(hipMemcpyAsync(nullvec, dn.p, H * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
+int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
+                              const double* R, const double* t, int n_hyp, double threshold, int32_t* counts) {
+    if (n < 0 || n_hyp < 0 || K == nullptr || counts == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "inlier arguments invalid");
+    }
+    if (n_hyp == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t H = static_cast<size_t>(n_hyp);
+    DevBuf d3, d2, dK, dR, dt, dc;
+    HIP_TRY(d3.alloc(static_cast<size_t>(n) * 3 * sizeof(double)));
+    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 2 * sizeof(double)));
+    HIP_TRY(dK.alloc(9 * sizeof(double)));
+    HIP_TRY(dR.alloc(H * 9 * sizeof(double)));
+    HIP_TRY(dt.alloc(H * 3 * sizeof(double)));
+    HIP_TRY(dc.alloc(H * sizeof(int)));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(d3.p, p3d, static_cast<size_t>(n) * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d2.p, p2d, static_cast<size_t>(n) * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemcpyAsync(dK.p, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dR.p, R, H * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dt.p, t, H * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_inliers(d3.as<double>(), d2.as<double>(), n, dK.as<double>(), dR.as<double>(), dt.as<double>(), threshold,
+                   n_hyp, dc.as<int>(), s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts, dc.p, H * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
+int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, int iterations,
+                     double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers) {
+    if (n < 6 || iterations <= 0 || p3d == nullptr || p2d == nullptr || K == nullptr || R == nullptr || t == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "ransac arguments invalid (needs >= 6 correspondences)");
+    }
+    // loop_closure.cpp:177-193: the same generator, distribution and distinct-index rule
+    std::mt19937 rng(seed);
+    std::uniform_int_distribution<int> dist(0, n - 1);
+    constexpr int sampleSize = 6;
+    std::vector<double> s3(static_cast<size_t>(iterations) * sampleSize * 3);
+    std::vector<double> s2(static_cast<size_t>(iterations) * sampleSize * 2);
+    for (int i = 0; i < iterations; ++i) {
+        std::vector<int> sampleIndices;
+        while (sampleIndices.size() < sampleSize) {
+            const int idx = dist(rng);
+            if (std::find(sampleIndices.begin(), sampleIndices.end(), idx) == sampleIndices.end()) {
+                const size_t k = sampleIndices.size();
+                sampleIndices.push_back(idx);
+                std::memcpy(&s3[(static_cast<size_t>(i) * sampleSize + k) * 3], p3d + static_cast<size_t>(idx) * 3, 24);
+                std::memcpy(&s2[(static_cast<size_t>(i) * sampleSize + k) * 2], p2d + static_cast<size_t>(idx) * 2, 16);
+            }
+        }
+    }
+    std::vector<double> Rs(static_cast<size_t>(iterations) * 9), ts(static_cast<size_t>(iterations) * 3);
+    std::vector<int32_t> counts(static_cast<size_t>(iterations));
+    SLAMX_TRY(slamx_pnp_dlt_batch(ctx, s3.data(), s2.data(), sampleSize, iterations, Rs.data(), ts.data(), nullptr));
+    SLAMX_TRY(slamx_count_inliers_batch(ctx, p3d, p2d, n, K, Rs.data(), ts.data(), iterations, threshold, counts.data()));
+    // :217-221 strict '>' from maxInliers = 0, identity / zero as the initial best
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(R, I3, sizeof(I3));
+    t[0] = t[1] = t[2] = 0.0;
+    int best = 0;
+    for (int i = 0; i < iterations; ++i) {
+        if (counts[static_cast<size_t>(i)] > best) {
+            best = counts[static_cast<size_t>(i)];
+            std::memcpy(R, &Rs[static_cast<size_t>(i) * 9], 72);
+            std::memcpy(t, &ts[static_cast<size_t>(i) * 3], 24);
+        }
+    }
+    if (max_inliers != nullptr) {
+        *max_inliers = best;
+    }
+    return SLAMX_OK;
+}
+
+int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
+                       double* R, double* t, int32_t* front) {
+    if (n < 0 || E == nullptr || K == nullptr || R == nullptr || t == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "recover pose arguments invalid");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf dE, dK, d1, d2, dposes, dKP, dKP0, dfront;
+    HIP_TRY(dE.alloc(72));
+    HIP_TRY(dK.alloc(72));
+    HIP_TRY(d1.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(dposes.alloc(4 * 12 * sizeof(double)));
+    HIP_TRY(dKP.alloc(4 * 12 * sizeof(double)));
+    HIP_TRY(dKP0.alloc(12 * sizeof(double)));
+    HIP_TRY(dfront.alloc(4 * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(dE.p, E, 72, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dK.p, K, 72, hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(d1.p, pts1, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d2.p, pts2, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemsetAsync(dfront.p, 0, 4 * sizeof(int), s));
+    launch_recover_pose(dE.as<double>(), dK.as<double>(), d1.as<float>(), d2.as<float>(), n, dposes.as<double>(),
+                        dKP.as<double>(), dKP0.as<double>(), dfront.as<int>(), s);
+    HIP_TRY(hipGetLastError());
+    double poses[48];
+    int fr[4];
+    HIP_TRY(hipMemcpyAsync(poses, dposes.p, sizeof(poses), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(fr, dfront.p, sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int best = 0, maxFront = -1;  // simple_pose_recover.cpp:67-82: first maximum wins
+    for (int i = 0; i < 4; ++i) {
+        if (fr[i] > maxFront) {
+            maxFront = fr[i];
+            best = i;
+        }
+    }
+    std::memcpy(R, poses + best * 12, 72);
+    std::memcpy(t, poses + best * 12 + 9, 24);
+    if (front != nullptr) {
+        std::memcpy(front, fr, sizeof(fr));
+    }
+    return SLAMX_OK;
+}
+
+int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
+                      float* x4, double* xyz) {
+    if (n < 0 || P1 == nullptr || P2 == nullptr || xyz == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "triangulate arguments invalid");
+    }
+    if (n == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf dP1, dP2, d1, d2, dx4, dxyz;
+    HIP_TRY(dP1.alloc(96));
+    HIP_TRY(dP2.alloc(96));
+    HIP_TRY(d1.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(dx4.alloc(static_cast<size_t>(n) * 16));
+    HIP_TRY(dxyz.alloc(static_cast<size_t>(n) * 24));
+    HIP_TRY(hipMemcpyAsync(dP1.p, P1, 96, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dP2.p, P2, 96, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d1.p, pts1, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d2.p, pts2, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
+    launch_triangulate(dP1.as<double>(), dP2.as<double>(), d1.as<float>(), d2.as<float>(), n, dx4.as<float>(),
+                       dxyz.as<double>(), s);
+    HIP_TRY(hipGetLastError());
+    if (x4 != nullptr) {
+        HIP_TRY(hipMemcpyAsync(x4, dx4.p, static_cast<size_t>(n) * 16, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(xyz, dxyz.p, static_cast<size_t>(n) * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
 // ------------------------------------------------------------------ synthetic frames (host)
 int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max, uint8_t* out) {
     if (rows <= 0 || cols <= 0 || out == nullptr || rect_min <= 0 || rect_max < rect_min || k < 0 || n_rect < 0) {

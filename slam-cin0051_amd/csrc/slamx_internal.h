@@ -152,6 +152,15 @@ struct MatchView {
 void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
                               hipStream_t stream, hipEvent_t ev_mid);
 
+void launch_pnp_dlt(const double* p3d, const double* p2d, int n_points, int n_hyp, double* R, double* t, double* nullvec,
+                    hipStream_t stream);
+void launch_inliers(const double* p3d, const double* p2d, int n, const double* K, const double* R, const double* t,
+                    double threshold, int n_hyp, int* counts, hipStream_t stream);
+void launch_recover_pose(const double* E, const double* K, const float* pts1, const float* pts2, int n, double* poses,
+                         double* KP, double* KP0, int* front, hipStream_t stream);
+void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
+                        double* xyz, hipStream_t stream);
+
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream);
 void launch_debug_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,

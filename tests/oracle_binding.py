@@ -123,6 +123,45 @@ class Oracle:
         self.lib.oracle_trig_chain(_p(a), _p(b), a.shape[0], _p(deg), _p(c), _p(s))
         return deg, c, s
 
+    # ---- pose rows a11-a14 (pose_oracle.cpp) ----
+    def svd(self, A):
+        A = np.ascontiguousarray(A, np.float64)
+        m, n = A.shape
+        U, S, V = np.empty((m, n)), np.empty(n), np.empty((n, n))
+        self.lib.oracle_svd(m, n, _p(A), _p(U), _p(S), _p(V))
+        return U, S, V
+
+    def solve_pnp(self, p3d, p2d):
+        a = np.ascontiguousarray(p3d, np.float64)
+        b = np.ascontiguousarray(p2d, np.float64)
+        R, t, nv = np.empty((3, 3)), np.empty(3), np.empty(12)
+        ok = self.lib.oracle_solve_pnp(a.shape[0], _p(a), _p(b), _p(R), _p(t), _p(nv))
+        return ok, R, t, nv
+
+    def count_inliers(self, p3d, p2d, K, R, t, thr):
+        a = np.ascontiguousarray(p3d, np.float64)
+        b = np.ascontiguousarray(p2d, np.float64)
+        self.lib.oracle_count_inliers.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        return self.lib.oracle_count_inliers(a.shape[0], _p(a), _p(b), _p(np.ascontiguousarray(K, np.float64)),
+                                             _p(np.ascontiguousarray(R, np.float64)), _p(np.ascontiguousarray(t, np.float64)), float(thr))
+
+    def recover_pose(self, E, pts1, pts2, K):
+        a = np.ascontiguousarray(pts1, np.float32)
+        b = np.ascontiguousarray(pts2, np.float32)
+        R, t, front = np.empty((3, 3)), np.empty(3), np.zeros(4, np.int32)
+        self.lib.oracle_recover_pose(_p(np.ascontiguousarray(E, np.float64)), _p(a), _p(b), a.shape[0],
+                                     _p(np.ascontiguousarray(K, np.float64)), _p(R), _p(t), _p(front))
+        return R, t, front
+
+    def triangulate(self, P1, P2, pts1, pts2):
+        a = np.ascontiguousarray(pts1, np.float32)
+        b = np.ascontiguousarray(pts2, np.float32)
+        n = a.shape[0]
+        x4, xyz = np.empty((n, 4), np.float32), np.empty((n, 3))
+        self.lib.oracle_triangulate(_p(np.ascontiguousarray(P1, np.float64)), _p(np.ascontiguousarray(P2, np.float64)),
+                                    _p(a), _p(b), n, _p(x4), _p(xyz))
+        return x4, xyz
+
     def penalty(self, dist, qx, qy, tx, ty):
         d = np.ascontiguousarray(dist, np.int32)
         arrs = [np.ascontiguousarray(a, np.float32) for a in (qx, qy, tx, ty)]
