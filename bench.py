@@ -16,7 +16,8 @@ The reference has no feature-count knob, so counts are reached through the synth
 density and SuppressionWindowSize; the realised candidates M / keypoints N are in the JSON.
 
 Multi-GPU: frames shard embarrassingly (one independent stream per rank, seed + rank), no
-data-path collective; one RCCL all_gather of the per-rank result summary at the end.
+data-path collective; at the end of the timed job every rank triangulates its newest frame pair
+and the map points are exchanged with one RCCL all_gather (counts + padded points).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
 dominant kernel and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N == 1 only).
@@ -33,11 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 WORKLOADS = {
     # name: rows, cols, window, n_rect, rect_min, rect_max, batch, max_candidates, max_keypoints
-    "1080p_2k": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=64, max_cand=32768, max_kp=4096,
+    "1080p_2k": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=256, max_cand=32768, max_kp=4096,
                      desc="1920x1080, ~2k keypoints/frame (shipped YAML: t=20 N=12 window=12), detect+describe+match-to-previous"),
     "c2": dict(rows=480, cols=640, window=6, n_rect=5000, rmin=3, rmax=16, batch=256, max_cand=32768, max_kp=4096,
                desc="640x480, ~2k keypoints/frame (SuppressionWindowSize 6), detect+describe+match-to-previous"),
-    "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=32, max_cand=131072, max_kp=16384,
+    "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=64, max_cand=131072, max_kp=16384,
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
 }
 SEED = 0x5EED0051
@@ -71,6 +72,45 @@ def gather_summary(dist, values, device):
     gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(gathered, mine)
     return [[float(x) for x in g.tolist()] for g in gathered]
+
+
+def gather_map_points(dist, xyz, device):
+    """RCCL all_gather of every rank's triangulated map points (N_g x 3 doubles, variable N_g:
+    counts first, then the points padded to the largest count).  Returns the list of per-rank arrays."""
+    import numpy as np
+    import torch
+
+    world = dist.get_world_size()
+    n = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    mine = torch.zeros((cap, 3), dtype=torch.float64, device=device)
+    if xyz.shape[0] > 0:
+        mine[: xyz.shape[0]] = torch.from_numpy(np.ascontiguousarray(xyz)).to(device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
+
+
+def triangulate_last_pair(ctx, batch, matcher, B, cols, rows):
+    """Map points of the newest frame pair (PoseEstimator::triangulatePoints with a fixed synthetic
+    relative pose): the payload of the final gather."""
+    import numpy as np
+
+    kq, _ = batch.download(B - 1)
+    kt, _ = batch.download(B - 2)
+    m = batch.download_matches(matcher, B - 1)
+    f = 0.9 * cols
+    K = np.array([[f, 0, cols / 2.0], [0, f, rows / 2.0], [0, 0, 1.0]])
+    P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = K @ np.hstack([np.eye(3), np.array([[-0.2], [0.0], [0.0]])])
+    p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+    p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+    if len(m) == 0:
+        return np.zeros((0, 3))
+    return ctx.triangulate(P1, P2, p1, p2)[1]
 
 
 def cpu_baseline(mod, wl, frames, budget_s=15.0):
@@ -160,6 +200,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(K):
         step()
+    # end of the job: triangulate the newest pair and gather the map points of all ranks
+    xyz = triangulate_last_pair(ctx, batch, matcher, B, wl["cols"], wl["rows"])
+    n_map_points = xyz.shape[0]
+    if dist is not None:
+        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, "cuda"))
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -169,8 +214,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the one collective of the path: gather every rank's per-frame result summary
-        # (keypoints, matches); map points replace this payload once triangulation lands (8e)
+        # result summary of every rank (the map points themselves were gathered inside the timed region)
         rows = gather_summary(dist, [nkp.sum(), nmatch.sum(), ncand.sum()], "cuda")
         tot_kp = sum(r[0] for r in rows)
         tot_match = sum(r[1] for r in rows)
@@ -221,6 +265,7 @@ def main():
                        "candidates_per_frame": M, "keypoints_per_frame": N, "matches_per_frame": tot_match / (B * n_gpus),
                        "parallelism": "frames sharded one stream per GPU (dp%d), no data-path collective" % n_gpus},
             "matched_keypoints_per_s": N * fps,
+            "map_points_gathered": n_map_points,
             "stage_ms_per_step": stage,
             "roofline": roof,
             "frontend_hbm": {"achieved": b_fe / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None, "peak": HBM_PEAK_GBS,

@@ -60,8 +60,32 @@ using DescriptorMatrix = RowMajorMatrix<uint8_t>;       // feature_detector.hpp:
 }  // namespace slam
 #endif
 
+#include <array>
+#include <filesystem>
+#include <string>
+
+#include <slamx.h>
+
 namespace slam {
 namespace constants {
 constexpr double COLOR_RANGE = 255.0;  // common.hpp:28
 }  // namespace constants
+
+// Plain stand-ins for the OpenCV / Eigen value types the reference's pose interfaces exchange
+// (cv::Point2f, cv::Point3d, 3x3 / 3x4 double matrices); all row-major.
+struct Point2f {
+    float x{}, y{};
+};
+struct Point3d {
+    double x{}, y{}, z{};
+};
+using Mat3d = std::array<double, 9>;
+using Mat34d = std::array<double, 12>;
+using Vec3d = std::array<double, 3>;
+
+namespace detail {
+void check(int rc);
+slamx_ctx* default_context();
+}  // namespace detail
+
 }  // namespace slam

@@ -3,6 +3,7 @@
 // std::runtime_error for everything else, as the reference throws).
 #pragma once
 
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 

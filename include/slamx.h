@@ -224,6 +224,21 @@ int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const
 int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
                       float* x4, double* xyz);
 
+/* ---- slam::Camera (include/slam/common/common.hpp:67-190) ---- */
+typedef struct slamx_camera {
+    double fx, fy, cx, cy;     /* K(0,0), K(1,1), K(0,2), K(1,2)                           */
+    double k1, k2, p1, p2, k3; /* D(0..4); k3 is loaded and unused, as in the reference     */
+    int32_t width, height;     /* ImageSize                                                */
+    double K[9];               /* the full 3x3 intrinsic matrix, row-major                 */
+} slamx_camera;
+/* Camera::Camera(configPath, cameraIndex), common.hpp:76-119: keys K<i>, D<i>, ImageSize. */
+int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out);
+/* Camera::undistortImage, common.hpp:127-173: nearest-neighbour inverse mapping of the
+ * [0,1]-scaled image.  img: rows x cols uint8 (must equal ImageSize), out: rows x cols double,
+ * ROW-major (the reference returns a column-major MatrixXd; same values). */
+int slamx_undistort(slamx_ctx* ctx, const slamx_camera* cam, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                    double* out);
+
 /* ---- deterministic synthetic frames, host side, for tests and bench ---- */
 /* Frame k of the sequence with the given seed: background 96, n_rect filled rectangles with
  * sides in [rect_min, rect_max], per-pixel noise in [-4,4], translated by (2k mod 64, k mod 32). */

@@ -637,7 +637,9 @@ void oracle_undistort(const uint8_t* img, int rows, int cols, int stride, double
             double y = (v - cy) / fy;
             double r = std::sqrt(x * x + y * y);
             double r2 = r * r;
-            double r4 = std::pow(r, 4);
+            // r.pow(4): Eigen evaluates this with its own vectorised pow (third-party, unpinned); the
+            // restatement and the device kernel both use (r*r)*(r*r), which differs by at most 1 ulp
+            double r4 = r2 * r2;
             double xDist = x * (1 + k1 * r2 + k2 * r4) + 2 * p1 * x * y + p2 * (r2 + 2 * (x * x));
             double yDist = y * (1 + k1 * r2 + k2 * r4) + 2 * p2 * x * y + p1 * (r2 + 2 * (y * y));
             double uD = fx * xDist + cx;

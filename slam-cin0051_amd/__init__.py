@@ -58,6 +58,13 @@ class MatcherConfig(C.Structure):
     ]
 
 
+class Camera(C.Structure):
+    """slam::Camera (common.hpp:67-190): intrinsics, distortion, image size."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("k1", C.c_double),
+                ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("k3", C.c_double), ("width", C.c_int32),
+                ("height", C.c_int32), ("K", C.c_double * 9)]
+
+
 class BatchShape(C.Structure):
     _fields_ = [
         ("rows", C.c_int32),
@@ -79,7 +86,8 @@ EXPORTS = [
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
     "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
-    "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_recover_pose", "slamx_triangulate",
+    "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
+    "slamx_undistort",
 ]
 
 _lib = None
@@ -143,6 +151,8 @@ def load_library():
     lib.slamx_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, C.POINTER(C.c_int32)]
     lib.slamx_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.slamx_camera_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(Camera)]
+    lib.slamx_undistort.argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_ssize_t, vp]
     lib.slamx_synth_frame.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     _lib = lib
     return lib
@@ -187,6 +197,12 @@ def load_detector_config(path):
     cfg = DetectorConfig()
     _check(load_library().slamx_detector_config_load(os.fsencode(path), C.byref(cfg)))
     return cfg
+
+
+def load_camera(path, camera_index=0):
+    cam = Camera()
+    _check(load_library().slamx_camera_load(os.fsencode(path), camera_index, C.byref(cam)))
+    return cam
 
 
 def load_matcher_config(path):
@@ -298,6 +314,14 @@ class Context:
         xyz = np.empty((n, 3))
         _check(self.lib.slamx_triangulate(self.h, _ptr(A), _ptr(B), _ptr(a), _ptr(b), n, _ptr(x4), _ptr(xyz)))
         return x4, xyz
+
+    def undistort(self, cam, image):
+        """Camera::undistortImage: uint8 image -> [0,1] doubles, row-major."""
+        img = _as_image(image)
+        out = np.empty(img.shape, np.float64)
+        _check(self.lib.slamx_undistort(self.h, C.byref(cam), _ptr(img), img.shape[0], img.shape[1], img.strides[0],
+                                        _ptr(out)))
+        return out
 
     def debug_penalty(self, dist, qx, qy, tx, ty):
         d = np.ascontiguousarray(dist, dtype=np.int32)

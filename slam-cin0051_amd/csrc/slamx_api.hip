@@ -1448,6 +1448,71 @@ int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const 
     return SLAMX_OK;
 }
 
+// ------------------------------------------------------------------ camera
+int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out) {
+    YamlFile y;
+    if (yaml_path == nullptr || !y.open(yaml_path)) {
+        return fail(SLAMX_ERR_RUNTIME, std::string("Could not open calibration file: ") + (yaml_path ? yaml_path : "(null)"));
+    }
+    const std::string kKey = "K" + std::to_string(camera_index);
+    const std::string dKey = "D" + std::to_string(camera_index);
+    const YamlNode* k = y.node(kKey);
+    const YamlNode* d = y.node(dKey);
+    if (k == nullptr || d == nullptr || k->kind != YamlNode::MATRIX || d->kind != YamlNode::MATRIX ||
+        k->mat.data.size() < 9) {
+        return fail(SLAMX_ERR_RUNTIME, "Could not find keys " + kKey + " or " + dKey + " in file.");
+    }
+    std::memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 9; ++i) {
+        out->K[i] = k->mat.data[static_cast<size_t>(i)];
+    }
+    out->fx = out->K[0];
+    out->fy = out->K[4];
+    out->cx = out->K[2];
+    out->cy = out->K[5];
+    const auto& D = d->mat.data;
+    out->k1 = D.size() > 0 ? D[0] : 0.0;
+    out->k2 = D.size() > 1 ? D[1] : 0.0;
+    out->p1 = D.size() > 2 ? D[2] : 0.0;
+    out->p2 = D.size() > 3 ? D[3] : 0.0;
+    out->k3 = D.size() > 4 ? D[4] : 0.0;
+    const YamlNode* sz = y.node("ImageSize");
+    if (sz != nullptr && sz->kind == YamlNode::SEQ && sz->seq.size() >= 2) {
+        out->width = static_cast<int32_t>(sz->seq[0]);
+        out->height = static_cast<int32_t>(sz->seq[1]);
+    }
+    return SLAMX_OK;
+}
+
+int slamx_undistort(slamx_ctx* ctx, const slamx_camera* cam, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
+                    double* out) {
+    if (cam == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    if (img == nullptr || rows <= 0 || cols <= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "Input image is empty.");  // common.hpp:130-132
+    }
+    if (rows != cam->height || cols != cam->width) {
+        return fail(SLAMX_ERR_RUNTIME, "Input image size does not match camera image size.");  // :133-135
+    }
+    if (stride < cols) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "stride smaller than the row length");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf dimg, dout;
+    const size_t pitch = (static_cast<size_t>(cols) + 63) / 64 * 64;
+    HIP_TRY(dimg.alloc(pitch * rows));
+    HIP_TRY(dout.alloc(static_cast<size_t>(rows) * cols * sizeof(double)));
+    HIP_TRY(hipMemcpy2DAsync(dimg.p, pitch, img, static_cast<size_t>(stride), static_cast<size_t>(cols),
+                             static_cast<size_t>(rows), hipMemcpyHostToDevice, s));
+    launch_undistort(dimg.as<uint8_t>(), rows, cols, static_cast<int>(pitch), *cam, dout.as<double>(), s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dout.p, static_cast<size_t>(rows) * cols * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
 // ------------------------------------------------------------------ synthetic frames (host)
 int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max, uint8_t* out) {
     if (rows <= 0 || cols <= 0 || out == nullptr || rect_min <= 0 || rect_max < rect_min || k < 0 || n_rect < 0) {

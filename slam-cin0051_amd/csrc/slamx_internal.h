@@ -161,6 +161,9 @@ void launch_recover_pose(const double* E, const double* K, const float* pts1, co
 void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
                         double* xyz, hipStream_t stream);
 
+void launch_undistort(const uint8_t* img, int rows, int cols, int pitch, const slamx_camera& cam, double* out,
+                      hipStream_t stream);
+
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream);
 void launch_debug_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,

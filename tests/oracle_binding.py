@@ -162,6 +162,14 @@ class Oracle:
                                     _p(a), _p(b), n, _p(x4), _p(xyz))
         return x4, xyz
 
+    def undistort(self, img, cam):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.empty(img.shape, np.float64)
+        self.lib.oracle_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_double] * 8 + [C.c_void_p]
+        self.lib.oracle_undistort(_p(img), img.shape[0], img.shape[1], img.strides[0], cam.fx, cam.fy, cam.cx, cam.cy,
+                                  cam.k1, cam.k2, cam.p1, cam.p2, _p(out))
+        return out
+
     def penalty(self, dist, qx, qy, tx, ty):
         d = np.ascontiguousarray(dist, np.int32)
         arrs = [np.ascontiguousarray(a, np.float32) for a in (qx, qy, tx, ty)]

@@ -145,6 +145,17 @@ def test_config_files_of_the_reference_parse(slamx, ref_data):
     assert m.ratio_test_threshold == 0.5
 
 
+def test_camera_yaml_of_the_reference_parses(slamx, ref_data, tmp_path):
+    cam = slamx.load_camera(os.path.join(ref_data, "camera.yml"))
+    assert (cam.width, cam.height) == (1392, 512)
+    assert list(cam.K) == [984.2439, 0.0, 690.0, 0.0, 980.8141, 233.1966, 0.0, 0.0, 1.0]
+    assert (cam.k1, cam.k2, cam.p1, cam.p2, cam.k3) == (-0.3728755, 0.2037299, 0.002219027, 0.001383707, -0.07233722)
+    with pytest.raises(RuntimeError, match="Could not find keys K1 or D1"):
+        slamx.load_camera(os.path.join(ref_data, "camera.yml"), 1)
+    with pytest.raises(RuntimeError, match="Could not open calibration file"):
+        slamx.load_camera(str(tmp_path / "nope.yml"))
+
+
 def test_config_validation_errors(slamx, tmp_path):
     """Constructor-time std::runtime_error cases of feature_detector.hpp:55-93."""
     with pytest.raises(RuntimeError, match="Could not open feature detector file"):

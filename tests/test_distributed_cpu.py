@@ -34,6 +34,10 @@ def _worker(rank, world, port, out_dir):
     summary = [float(sum(int(f.sum()) for f in frames)), float(rank + 1), float(seed)]
     rows = bench.gather_summary(dist, summary, "cpu")
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(rows))
+    # variable-length map-point gather: rank r contributes 3 + 2r points
+    pts = np.arange((3 + 2 * rank) * 3, dtype=np.float64).reshape(-1, 3) + 100 * rank
+    parts = bench.gather_map_points(dist, pts, "cpu")
+    np.save(os.path.join(out_dir, "points%d.npy" % rank), np.concatenate(parts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,3 +56,7 @@ def test_two_rank_sharding_and_gather(tmp_path):
     assert r0[0, 2] != r0[1, 2]  # independent streams
     assert r0[0, 0] != r0[1, 0]  # ... with different pixels
     assert r0[:, 1].tolist() == [1.0, 2.0]
+    p0 = np.load(tmp_path / "points0.npy")
+    p1 = np.load(tmp_path / "points1.npy")
+    expect = np.concatenate([np.arange(9.0).reshape(-1, 3), np.arange(15.0).reshape(-1, 3) + 100])
+    assert np.array_equal(p0, expect) and np.array_equal(p1, expect)  # counts + padding handled

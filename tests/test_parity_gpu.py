@@ -411,3 +411,21 @@ def test_batch_capacity_overflow_is_loud(slamx):
     b.detect_and_compute(1)
     with pytest.raises(slamx.CapacityError):
         b.counts(1)
+
+
+# ---------------------------------------------------------------- a15 Camera::undistortImage
+def test_camera_yaml_and_undistort(slamx, gpu_ctx, oracle, ref_data):
+    """test_preprocessing.cpp:15-29: load camera.yml, undistort the first KITTI frame; the
+    u8 -> [0,1] -> u8 round trip is exact."""
+    cam = slamx.load_camera(os.path.join(ref_data, "camera.yml"))
+    assert (cam.width, cam.height) == (1392, 512)
+    assert (cam.fx, cam.fy, cam.cx, cam.cy) == (984.2439, 980.8141, 690.0, 233.1966)
+    assert (cam.k1, cam.k2, cam.p1, cam.p2, cam.k3) == (-0.3728755, 0.2037299, 0.002219027, 0.001383707, -0.07233722)
+    img = load_gray(os.path.join(ref_data, "images/0000000000.png"))
+    got = gpu_ctx.undistort(cam, img)
+    ref = oracle.undistort(img, cam)
+    assert np.array_equal(got, ref)
+    back = (got * 255.0).astype(np.uint8)  # test_preprocessing.cpp:28-29
+    assert set(np.unique(back)) <= set(np.unique(img)) | {0}
+    with pytest.raises(RuntimeError, match="does not match camera image size"):
+        gpu_ctx.undistort(cam, img[:100])
