@@ -43,9 +43,10 @@ WORKLOADS = {
 }
 SEED = 0x5EED0051
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_INT_PEAK_GOPS = 256 * 4 * 32 * 2.4  # CUs x SIMDs x 32 lanes/clk x 2.4 GHz = 78.6 Tera lane-ops/s
-# (one full-rate int32 VALU op per lane per clock; SURVEY.md 8d quotes the same peak per
-#  wave-instruction slot as 256 x 64 x 2.4 GHz / 2 clocks-per-wave64-instruction)
+# Sustained rate of the Hamming inner loop's instruction mix (v_xor_b32 + v_bcnt_u32_b32 with fused
+# accumulate) measured on MI355X with tools/microbench/valu_peak.hip: 42.1 Tera lane-ops/s
+# (v_bcnt is half rate; full-rate int32 pairs reach 65.8).  SURVEY.md 8d's nominal 3.9e13 agrees.
+VALU_HAMMING_PEAK_GOPS = 42100.0
 
 
 def load_product():
@@ -236,25 +237,51 @@ def main():
         M = tot_cand / (B * n_gpus)
         N = tot_kp / (B * n_gpus)
         px = wl["rows"] * wl["cols"]
-        # algorithmic work per launch (one launch = the whole batch of B frames), SURVEY.md 8d
-        bytes_per_frame = {"fast": px + px / 8.0, "blur": 2.0 * px, "describe": (961 + 2 * 46) * N + 52 * N,
-                           "expand": 8.0 * px / 64 + 17 * M + 8 * M, "scan": 12.0 * px / 64,
-                           "sort": 16.0 * M, "nms": 16.0 * M, "emit": 24.0 * N}
-        dom = max(stage, key=lambda s: stage[s])
+        # Algorithmic work per launch (one launch = the whole batch of B frames), SURVEY.md 8d / DESIGN.md 4.
+        # Bytes for the HBM-bound kernels, int32 ops for the Hamming kernel.
+        live_words = 2  # 46 surviving BRIEF pairs -> 2 non-zero 32-bit words per descriptor
+        hbm_bytes = {
+            "fast": px + px / 8.0,                 # frame read, corner bitmap written
+            "scan": 12.0 * px / 64,                # bitmap words read, prefix written
+            "expand": 8.0 * px / 64 + 17 * M + 8 * M,
+            "sort": 16.0 * M, "nms_build": 16.0 * M + 64.0 * M, "nms_rounds": 16.0 * M,
+            "blur": 2.0 * px,                      # frame read, blurred frame written
+            "moments": 961.0 * N + 8 * N, "trig": 16.0 * N + 12 * N,
+            "brief": 43 * 48.0 * N + 32 * N,       # 43 x 48-byte neighbourhood read, descriptor written
+            "emit": 24.0 * N,
+        }
+        dom = max(stage, key=lambda k: stage[k])
+        kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
+                     "brief": "brief_kernel", "nms_build": "nms_build_kernel", "sort": "sort_kernel",
+                     "moments": "moments_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
         if dom == "match":
-            ops = 16.0 * N * N * B  # 8 xor + 8 popcount-accumulate per 256-bit pair
+            # executed algorithmic work: xor + popcount-accumulate per live 32-bit word per pair;
+            # SURVEY.md 8d's figure (16 ops per 256-bit pair) is reported next to it
+            ops = 2.0 * live_words * N * N * B
             achieved = ops / (stage[dom] * 1e-3) / 1e9
-            roof = {"kernel": "match_kernel<8>", "bound": "valu-int32 (neither hbm nor mfma: SURVEY.md 8d)",
-                    "achieved": achieved, "peak": VALU_INT_PEAK_GOPS, "unit": "Gop/s", "frac": achieved / VALU_INT_PEAK_GOPS,
-                    "algorithmic_per_launch": ops, "traffic": None}
+            roof = {"kernel": kernel_of[dom], "bound": "valu-int32 (neither hbm nor mfma: SURVEY.md 8d)",
+                    "achieved": achieved, "peak": VALU_HAMMING_PEAK_GOPS, "unit": "Gop/s",
+                    "frac": achieved / VALU_HAMMING_PEAK_GOPS, "algorithmic_per_launch": ops,
+                    "survey_ops_per_launch_256bit": 16.0 * N * N * B, "traffic": None}
         else:
-            byts = bytes_per_frame[dom] * B
+            byts = hbm_bytes[dom] * B
             achieved = byts / (stage[dom] * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "algorithmic_per_launch": byts, "traffic": None}
+            roof = {"kernel": kernel_of.get(dom, dom), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_per_launch": byts, "traffic": None}
         roof["avg_launch_ms"] = stage[dom]
+        # every other kernel against its own roofline, for the record
+        others = {}
+        for k in stage:
+            if stage[k] <= 0:
+                continue
+            if k == "match":
+                o = 2.0 * live_words * N * N * B / (stage[k] * 1e-3) / 1e9
+                others[k] = {"ms": stage[k], "achieved": o, "unit": "Gop/s", "frac": o / VALU_HAMMING_PEAK_GOPS}
+            else:
+                g = hbm_bytes[k] * B / (stage[k] * 1e-3) / 1e9
+                others[k] = {"ms": stage[k], "achieved": g, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}
         # the HBM-bound front-end as a whole: B_fe = 4WH + 16M + 52N bytes per frame
-        fe_ms = sum(stage[s] for s in ("fast", "scan", "expand", "sort", "nms", "blur", "describe"))
+        fe_ms = sum(stage[k] for k in stage if k not in ("match", "emit"))
         b_fe = (4.0 * px + 16.0 * M + 52.0 * N) * B
         out = {
             "metric": "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X",
@@ -268,6 +295,7 @@ def main():
             "map_points_gathered": n_map_points,
             "stage_ms_per_step": stage,
             "roofline": roof,
+            "kernel_rooflines": others,
             "frontend_hbm": {"achieved": b_fe / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
             "device": ctx.device_name,

@@ -180,17 +180,20 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
  * synchronization is added).  slamx_batch_set_profiling(b, n_sets) keeps n_sets event sets
  * (0 = off); the i-th detect_and_compute call after it records into set i % n_sets, and the
  * match call that follows uses the same set.  slamx_batch_stage_ms synchronizes and reads one
- * set.  Stage MATCH is the all-pairs kernel alone; EMIT is the ratio-test/compaction kernel. */
-#define SLAMX_STAGE_FAST 0
-#define SLAMX_STAGE_SCAN 1
-#define SLAMX_STAGE_EXPAND 2
-#define SLAMX_STAGE_SORT 3
-#define SLAMX_STAGE_NMS 4
-#define SLAMX_STAGE_BLUR 5
-#define SLAMX_STAGE_DESCRIBE 6
-#define SLAMX_STAGE_MATCH 7
-#define SLAMX_STAGE_EMIT 8
-#define SLAMX_STAGE_COUNT 9
+ * set.  Every stage except NMS_ROUNDS is exactly one kernel launch. */
+#define SLAMX_STAGE_FAST 0       /* fast_detect_kernel                         */
+#define SLAMX_STAGE_SCAN 1       /* scan_kernel                                */
+#define SLAMX_STAGE_EXPAND 2     /* expand_kernel                              */
+#define SLAMX_STAGE_SORT 3       /* sort_kernel                                */
+#define SLAMX_STAGE_NMS_BUILD 4  /* nms_build_kernel                           */
+#define SLAMX_STAGE_NMS_ROUNDS 5 /* nms_round_kernel x2 + nms_finish_kernel    */
+#define SLAMX_STAGE_BLUR 6       /* blur_kernel                                */
+#define SLAMX_STAGE_MOMENTS 7    /* moments_kernel (or the fused describe_kernel for large patches) */
+#define SLAMX_STAGE_TRIG 8       /* trig_kernel                                */
+#define SLAMX_STAGE_BRIEF 9      /* brief_kernel                               */
+#define SLAMX_STAGE_MATCH 10     /* match_kernel                               */
+#define SLAMX_STAGE_EMIT 11      /* emit_kernel                                */
+#define SLAMX_STAGE_COUNT 12
 int slamx_batch_set_profiling(slamx_batch* b, int n_sets);
 int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms /* SLAMX_STAGE_COUNT entries */);
 

@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamx.so")
 
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE = range(6)
-STAGES = ("fast", "scan", "expand", "sort", "nms", "blur", "describe", "match", "emit")
+STAGES = ("fast", "scan", "expand", "sort", "nms_build", "nms_rounds", "blur", "moments", "trig", "brief", "match", "emit")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4")], align=False

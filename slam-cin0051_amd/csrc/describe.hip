@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
 }  // namespace
 
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
-                     hipStream_t stream) {
+                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig) {
     // float accumulation of integer moments is exact (order-free) iff 255 * sum over the disc
     // of |v| stays below 2^24
     const int radius = p.patch / 2;
@@ -506,11 +506,23 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
     if (radius <= 15 && exact_int != 0 && v.moments != nullptr) {
         hipLaunchKernelGGL(moments_kernel, grid, dim3(256), 0, stream, v, p, v.moments);
+        if (ev_after_moments != nullptr) {
+            (void)hipEventRecord(ev_after_moments, stream);
+        }
         hipLaunchKernelGGL(trig_kernel, dim3(grid_x(v.maxK, 256, nframes), nframes), dim3(256), 0, stream, v, v.moments,
                            v.cos_sin);
+        if (ev_after_trig != nullptr) {
+            (void)hipEventRecord(ev_after_trig, stream);
+        }
         hipLaunchKernelGGL(brief_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, v.cos_sin);
     } else {
         hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, exact_int);
+        if (ev_after_moments != nullptr) {
+            (void)hipEventRecord(ev_after_moments, stream);
+        }
+        if (ev_after_trig != nullptr) {
+            (void)hipEventRecord(ev_after_trig, stream);
+        }
     }
 }
 

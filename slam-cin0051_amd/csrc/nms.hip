@@ -316,13 +316,16 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 
 }  // namespace
 
-void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
+void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid) {
     static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
                               true);
     (void)once;
     dim3 grid(grid_x(v.maxM, 256, nframes), nframes);
     hipLaunchKernelGGL(nms_build_kernel, grid, dim3(256), 0, stream, v, p.window);
+    if (ev_mid != nullptr) {
+        (void)hipEventRecord(ev_mid, stream);
+    }
     for (int r = 0; r < NMS_PARALLEL_ROUNDS; ++r) {
         hipLaunchKernelGGL(nms_round_kernel, grid, dim3(256), 0, stream, v, p.window);
     }

@@ -105,7 +105,7 @@ struct slamx_batch {
     int2* best = nullptr;
     int* second = nullptr;
     // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
-    // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS|5|BLUR|6|DESCRIBE|7|MATCH|8|EMIT|9
+    // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS_BUILD|5|NMS_ROUNDS|6|BLUR|7|MOMENTS|8|TRIG|9|BRIEF|10|MATCH|11|EMIT|12
     static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
     int n_sets = 0;
     std::vector<hipEvent_t> ev;
@@ -217,6 +217,14 @@ void record(slamx_batch* b, int idx) {
         b->ev_valid[k] = 1;
     }
 }
+hipEvent_t event_slot(slamx_batch* b, int idx) {  // mark as recorded by a launcher
+    if (b->n_sets <= 0) {
+        return nullptr;
+    }
+    const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx;
+    b->ev_valid[k] = 1;
+    return b->ev[k];
+}
 bool recorded(const slamx_batch* b, int idx) {
     return b->n_sets > 0 && b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx] != 0;
 }
@@ -244,12 +252,13 @@ void enqueue_detect(slamx_batch* b, int nframes) {
     if (p.nms != 0) {
         launch_sort(b->v, nframes, s);
         record(b, 4);
-        launch_nms(b->v, p, nframes, s);
-        record(b, 5);
+        launch_nms(b->v, p, nframes, s, event_slot(b, 5));
+        record(b, 6);
     } else {
         launch_passthrough_keypoints(b->v, nframes, s);
         record(b, 4);
         record(b, 5);
+        record(b, 6);
     }
 }
 
@@ -257,13 +266,15 @@ void enqueue_detect(slamx_batch* b, int nframes) {
 void enqueue_compute(slamx_batch* b, int nframes) {
     hipStream_t s = b->det->ctx->stream;
     const DetectorParams p = params_of(b->det);
-    if (!recorded(b, 5)) {
-        record(b, 5);
+    if (!recorded(b, 6)) {
+        record(b, 6);
     }
     launch_blur(b->v, b->det->weights_dev, nframes, s);
-    record(b, 6);
-    launch_describe(b->v, p, b->det->pattern_dev, nframes, s);
     record(b, 7);
+    hipEvent_t e_mom = event_slot(b, 8);
+    hipEvent_t e_trig = event_slot(b, 9);
+    launch_describe(b->v, p, b->det->pattern_dev, nframes, s, e_mom, e_trig);
+    record(b, 10);
 }
 
 int ensure_single(slamx_detector* det, int rows, int cols, int min_keypoints) {
@@ -707,22 +718,17 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     mv.nsplit = match_split_for(nframes, b->v.maxK);
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
-    if (!recorded(b, 7)) {
-        record(b, 7);
+    if (!recorded(b, 10)) {
+        record(b, 10);
     }
-    hipEvent_t mid = nullptr;
-    if (b->n_sets > 0) {
-        const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + 8;
-        mid = b->ev[k];
-        b->ev_valid[k] = 1;
-    }
+    hipEvent_t mid = event_slot(b, 11);
     if (first_train_frame >= 0) {
         launch_match_consecutive(mv, 0, nframes, first_train_frame, b->det->ctx->stream, mid);
     } else {
         launch_match_consecutive(mv, 1, nframes - 1, -1, b->det->ctx->stream, mid);
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, sizeof(int), b->det->ctx->stream));
     }
-    record(b, 9);
+    record(b, 12);
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
 }

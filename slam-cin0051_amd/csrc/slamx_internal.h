@@ -125,11 +125,12 @@ void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes
 void launch_scan(const BatchView& v, int nframes, hipStream_t stream);
 void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
 void launch_sort(const BatchView& v, int nframes, hipStream_t stream);
-void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
+// ev_mid (optional) is recorded after the first kernel of a multi-kernel stage
+void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid);
 void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream);  // NonMaxSuppression: 0
 void launch_blur(const BatchView& v, const double* weights_dev, int nframes, hipStream_t stream);
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
-                     hipStream_t stream);
+                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig);
 
 struct MatchView {
     // pair q: query = frame qf[q], train = frame tf[q] of the same batch layout
