@@ -54,6 +54,63 @@ __device__ __forceinline__ void for_each_earlier_neighbour(const BatchView& v, i
     const int xhi = min(v.cols - 1, me.x + reach);
     const int w0 = xlo >> 6;
     const int w1 = xhi >> 6;
+    // Fast path (window <= 32, so the probed column range spans <= 63 pixels and <= 2 bitmap
+    // words): per row the bits of columns [xlo, xhi] are funnel-shifted into one 64-bit window;
+    // candidates of a row are consecutive in raster order, so the t-th set bit of the window is
+    // candidate base + t with base = wordoff + popcount(bits left of xlo): one prefix lookup per
+    // non-empty row instead of one per neighbour.  Coordinates are integers, so the reference's
+    // sqrtf(dx^2+dy^2) < float(w) is exactly dx^2+dy^2 < w^2 (both sides exact in float for
+    // w < 2896, sqrt correctly rounded and monotone).  Rows are probed in chunks of 8 with all
+    // bitmap loads of a chunk issued before any is used.
+    constexpr int CH = 8;
+    if (window <= 32) {
+        const bool two_words = w1 != w0;
+        const int sh = xlo - w0 * 64;          // bit of column xlo inside word w0
+        const int width = xhi - xlo + 1;       // <= 63
+        const unsigned long long wmask = low_mask(width);
+        const int w2 = window * window;
+        for (int yc = ylo; yc <= yhi; yc += CH) {
+            unsigned long long ma[CH], mb[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int yy = min(yc + k, yhi);
+                ma[k] = masks[static_cast<size_t>(yy) * v.nw + w0];
+                mb[k] = two_words ? masks[static_cast<size_t>(yy) * v.nw + w1] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int yy = yc + k;
+                if (yy > yhi) {
+                    break;
+                }
+                unsigned long long win = ma[k] >> sh;
+                if (sh != 0) {
+                    win |= mb[k] << (64 - sh);
+                }
+                win &= wmask;
+                if (win == 0) {
+                    continue;
+                }
+                const int dyi = me.y - yy;
+                const int rem = w2 - dyi * dyi;  // need dx^2 < rem
+                uint32_t nidx = off[static_cast<size_t>(yy) * v.nw + w0] +
+                                static_cast<uint32_t>(__popcll(ma[k] & low_mask(sh)));
+                while (win != 0) {
+                    const int b = __ffsll(static_cast<long long>(win)) - 1;
+                    win &= win - 1;
+                    const uint32_t cur = nidx++;
+                    const int dxi = me.x - (xlo + b);
+                    if (dxi * dxi < rem && rank_of[cur] < me.rank) {
+                        if (!visit(cur)) {
+                            return;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // windows wider than 64 pixels: plain walk over every word of every row
     for (int yy = ylo; yy <= yhi; ++yy) {
         const float dy = fy - static_cast<float>(yy);
         for (int w = w0; w <= w1; ++w) {
@@ -72,7 +129,6 @@ __device__ __forceinline__ void for_each_earlier_neighbour(const BatchView& v, i
                 if (rank_of[nidx] >= me.rank) {
                     continue;  // later in sorted order (or myself)
                 }
-                // feature_detector.cpp:177-181, same float operations
                 const float dx = fx - static_cast<float>(w * 64 + b);
                 const float dist = sqrtf_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
                 if (dist < fw) {
@@ -122,14 +178,25 @@ __device__ __forceinline__ uint8_t nms_decide(const BatchView& v, int f, int i, 
     const int cnt = nbr_cnt[i];
     bool all_decided = true;
     if (cnt != NBR_OVERFLOW) {
-        for (int k = 0; k < cnt; ++k) {
-            const uint8_t s = state[nbr[static_cast<size_t>(k) * v.maxM + i]];
-            if (s == NMS_KEPT) {
-                return NMS_SUPPRESSED;
+        // four list entries, then their four states, as independent loads per step
+        bool any_kept = false;
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            uint32_t ids[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ids[k] = k0 + k < cnt ? nbr[static_cast<size_t>(k0 + k) * v.maxM + i] : static_cast<uint32_t>(i);
             }
-            all_decided = all_decided && s != NMS_UNDECIDED;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t s = state[ids[k]];
+                any_kept = any_kept || (k0 + k < cnt && s == NMS_KEPT);
+                all_decided = all_decided && (k0 + k >= cnt || s != NMS_UNDECIDED);
+            }
+            if (any_kept) {
+                break;
+            }
         }
-        return all_decided ? NMS_KEPT : NMS_UNDECIDED;
+        return any_kept ? NMS_SUPPRESSED : (all_decided ? NMS_KEPT : NMS_UNDECIDED);
     }
     const uint32_t pxy = xy[i];
     Cand me;
