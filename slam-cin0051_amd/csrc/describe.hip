@@ -218,6 +218,18 @@ constexpr int MAX_DISC = 716;                 // pixels of the radius-15 disc (7
 // wave (1) fetches the coordinates of up to 64 of its keypoints with ONE coalesced load and hands
 // them out with readlane, and (2) issues the global loads of the NEXT keypoint's tile into
 // registers before it computes on the current one, committing them to LDS afterwards.
+// 1-D grid -> (frame, block-in-frame) such that all blocks of a frame land on ONE XCD (hardware
+// deals consecutive workgroup ids round-robin over the 8 XCDs): the L2 of an XCD then only holds the
+// active row bands of nframes/8 frames instead of all of them.  Placement is a speed matter only.
+__device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, int* f, int* bx) {
+    const int f8 = (nframes + 7) / 8;
+    const int r = static_cast<int>(blockIdx.x) & 7;
+    const int q = static_cast<int>(blockIdx.x) >> 3;
+    *f = r + 8 * (q % f8);
+    *bx = q / f8;
+    return *f < nframes && *bx < blocks_per_frame;
+}
+
 template <int ROWS, int DW, int HALF>
 struct TilePrefetch {
     static constexpr int PER_LANE = (ROWS * DW + 63) / 64;
@@ -250,11 +262,15 @@ struct TilePrefetch {
     }
 };
 
-__global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParams P, int2* __restrict__ moments) {
+__global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParams P, int2* __restrict__ moments, int nframes,
+                                                      int blocks_per_frame, int use_visit) {
     __shared__ uint32_t tile[4][MOM_ROWS * MOM_DW];
     __shared__ uint16_t disc[MAX_DISC];
     __shared__ int disc_count;
-    const int f = blockIdx.y;
+    int f, bx;
+    if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = v.n_kp[f];
@@ -280,16 +296,18 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
     const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
-    const int stride = gridDim.x * 4;
-    const int i0 = blockIdx.x * 4 + wave;
+    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+    const int stride = blocks_per_frame * 4;
+    const int i0 = bx * 4 + wave;
     TilePrefetch<MOM_ROWS, MOM_DW, MOM_HALF> pf;
     for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
-        // lane j holds the coordinates of this wave's (chunk + j)-th keypoint
+        // lane j holds the slot and coordinates of this wave's (chunk + j)-th keypoint
         const int mine = i0 + (chunk + lane) * stride;
-        int kx = 0, ky = 0;
+        int kx = 0, ky = 0, kslot = 0;
         if (mine < n) {
-            kx = static_cast<int>(kps[mine].x);
-            ky = static_cast<int>(kps[mine].y);
+            kslot = use_visit ? static_cast<int>(visit[mine]) : mine;
+            kx = static_cast<int>(kps[kslot].x);
+            ky = static_cast<int>(kps[kslot].y);
         }
         const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
         auto is_inside = [&](int x, int y) {
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
             pf.issue(v, img, x, y, lane);
         }
         for (int k = 0; k < cnt; ++k) {
-            const int i = i0 + (chunk + k) * stride;
+            const int i = __shfl(kslot, k);
             const bool inside = is_inside(x, y);  // wave-uniform
             if (inside) {
                 pf.commit(tile[wave], lane);
@@ -363,10 +381,14 @@ __global__ __launch_bounds__(256) void trig_kernel(BatchView v, const int2* __re
 }
 
 __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
-                                                    const float2* __restrict__ cs) {
+                                                    const float2* __restrict__ cs, int nframes, int blocks_per_frame,
+                                                    int use_visit) {
     __shared__ uint32_t tile[4][TILE_ROWS * TILE_DW];
     __shared__ unsigned long long dbuf[4][DESC_WORDS];
-    const int f = blockIdx.y;
+    int f, bx;
+    if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = v.n_kp[f];
@@ -374,8 +396,9 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
     const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
     const float2* csf = cs + static_cast<size_t>(f) * v.maxK;
-    const int stride = gridDim.x * 4;
-    const int i0 = blockIdx.x * 4 + wave;
+    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+    const int stride = blocks_per_frame * 4;
+    const int i0 = bx * 4 + wave;
     const int words = (v.width + 7) / 8;
     // this lane's pattern pair of the first 64-pair chunk (loop invariant)
     float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f;
@@ -388,12 +411,13 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
     for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
         const int mine = i0 + (chunk + lane) * stride;
-        int kx = 0, ky = 0;
+        int kx = 0, ky = 0, kslot = 0;
         float kc = 0.0f, ks = 0.0f;
         if (mine < n) {
-            kx = static_cast<int>(kps[mine].x);
-            ky = static_cast<int>(kps[mine].y);
-            const float2 r = csf[mine];
+            kslot = use_visit ? static_cast<int>(visit[mine]) : mine;
+            kx = static_cast<int>(kps[kslot].x);
+            ky = static_cast<int>(kps[kslot].y);
+            const float2 r = csf[kslot];
             kc = r.x;
             ks = r.y;
         }
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
             pf.issue(v, img, x, y, lane);
         }
         for (int k = 0; k < cnt; ++k) {
-            const int i = i0 + (chunk + k) * stride;
+            const int i = __shfl(kslot, k);
             uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
             const bool inside = ca == ca;  // NaN cos marks "patch leaves the image" (wave-uniform)
             if (lane < words) {
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
 
 }  // namespace
 
-void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
+void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
                      hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig) {
     // float accumulation of integer moments is exact (order-free) iff 255 * sum over the disc
     // of |v| stays below 2^24
@@ -505,7 +529,9 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     const int exact_int = (255LL * sum_abs < (1LL << 24)) ? 1 : 0;
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
     if (radius <= 15 && exact_int != 0 && v.moments != nullptr) {
-        hipLaunchKernelGGL(moments_kernel, grid, dim3(256), 0, stream, v, p, v.moments);
+        const int bpf = static_cast<int>(grid.x);
+        const dim3 grid1d(8 * ((nframes + 7) / 8) * bpf);
+        hipLaunchKernelGGL(moments_kernel, grid1d, dim3(256), 0, stream, v, p, v.moments, nframes, bpf, use_visit ? 1 : 0);
         if (ev_after_moments != nullptr) {
             (void)hipEventRecord(ev_after_moments, stream);
         }
@@ -514,7 +540,8 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
         if (ev_after_trig != nullptr) {
             (void)hipEventRecord(ev_after_trig, stream);
         }
-        hipLaunchKernelGGL(brief_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, v.cos_sin);
+        hipLaunchKernelGGL(brief_kernel, grid1d, dim3(256), 0, stream, v, p, pattern_dev, v.cos_sin, nframes, bpf,
+                           use_visit ? 1 : 0);
     } else {
         hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, stream, v, p, pattern_dev, exact_int);
         if (ev_after_moments != nullptr) {

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int windo
     uint8_t* gstate = v.state + static_cast<size_t>(f) * v.maxM;
     const uint32_t* sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
     const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
+    uint32_t* slot_of = v.rank_of + static_cast<size_t>(f) * v.maxM;  // reused after the rounds
+    const uint32_t* rank_of = slot_of;
     const uint8_t* nbr_cnt = v.nbr_cnt + static_cast<size_t>(f) * v.maxM;
     const uint32_t* nbr = v.nbr + static_cast<size_t>(f) * v.maxM * NBR_CAP;
     // all rounds run on a copy of the state in LDS when it fits (it always does below 128 Ki
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int windo
                 kp.angle = 0.0f;
                 kp.response = static_cast<float>(key >> SCORE_SHIFT);
                 kps[pos] = kp;
+                slot_of[key & INDEX_MASK] = pos;  // rank_of is dead from here on: reuse it
             }
         }
         __syncthreads();
@@ -341,8 +343,42 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int windo
         }
         __syncthreads();
     }
+    const int total_kept = static_cast<int>(carry);
+    __syncthreads();
+    // second compaction, in RASTER order: visit[q] = output slot of the q-th kept candidate in
+    // raster order.  The describe kernels walk keypoints in this order so that consecutive waves
+    // read neighbouring image rows (the rank order is spatially random).
+    if (total_kept <= v.maxK) {
+        uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+        if (threadIdx.x == 0) {
+            carry = 0;
+        }
+        __syncthreads();
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + threadIdx.x;
+            const bool keep = i < n && state[i] == NMS_KEPT;
+            const unsigned long long bm = __ballot(keep);
+            const uint32_t c = static_cast<uint32_t>(__popcll(bm));
+            if (lane == 0) {
+                wave_sums[wave] = c;
+            }
+            __syncthreads();
+            uint32_t wbase = carry;
+            for (int w = 0; w < wave; ++w) {
+                wbase += wave_sums[w];
+            }
+            if (keep) {
+                visit[wbase + static_cast<uint32_t>(__popcll(bm & low_mask(lane)))] = slot_of[i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) {
+                carry = wbase + c;
+            }
+            __syncthreads();
+        }
+    }
     if (threadIdx.x == 0) {
-        int total = static_cast<int>(carry);
+        int total = total_kept;
         if (total > v.maxK) {
             atomicOr(&v.status[f], STATUS_KP_OVERFLOW);
             total = 0;

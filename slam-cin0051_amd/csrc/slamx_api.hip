@@ -263,7 +263,7 @@ void enqueue_detect(slamx_batch* b, int nframes) {
 }
 
 // compute part: blur -> orientation + BRIEF
-void enqueue_compute(slamx_batch* b, int nframes) {
+void enqueue_compute(slamx_batch* b, int nframes, bool after_nms) {
     hipStream_t s = b->det->ctx->stream;
     const DetectorParams p = params_of(b->det);
     if (!recorded(b, 6)) {
@@ -273,7 +273,7 @@ void enqueue_compute(slamx_batch* b, int nframes) {
     record(b, 7);
     hipEvent_t e_mom = event_slot(b, 8);
     hipEvent_t e_trig = event_slot(b, 9);
-    launch_describe(b->v, p, b->det->pattern_dev, nframes, s, e_mom, e_trig);
+    launch_describe(b->v, p, b->det->pattern_dev, nframes, after_nms && p.nms != 0, s, e_mom, e_trig);
     record(b, 10);
 }
 
@@ -575,6 +575,7 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&v.kps, F * v.maxK);
     A(&v.n_kp, F);
     A(&v.desc, F * v.maxK * v.width);
+    A(&v.visit, F * v.maxK);
     A(&v.moments, F * v.maxK);
     A(&v.cos_sin, F * v.maxK);
     A(&v.status, F);
@@ -629,6 +630,7 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.kps);
     dev_free(v.n_kp);
     dev_free(v.desc);
+    dev_free(v.visit);
     dev_free(v.moments);
     dev_free(v.cos_sin);
     dev_free(v.status);
@@ -680,7 +682,7 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
     HIP_TRY(hipSetDevice(b->det->ctx->device));
     begin_set(b);
     enqueue_detect(b, nframes);
-    enqueue_compute(b, nframes);
+    enqueue_compute(b, nframes, true);
     b->last_frames = nframes;
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
@@ -889,7 +891,7 @@ int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, p
     HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));  // &n must stay alive until the copy is done
     begin_set(b);
-    enqueue_compute(b, 1);
+    enqueue_compute(b, 1, false);
     HIP_TRY(hipGetLastError());
     int cnt = 0;
     return slamx_batch_download(b, 0, kps, desc, n, &cnt);

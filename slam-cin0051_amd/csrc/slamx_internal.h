@@ -52,6 +52,7 @@ struct BatchView {
     slamx_keypoint* kps;     // [F][maxK]
     int* n_kp;               // [F]
     uint8_t* desc;           // [F][maxK][width]
+    uint32_t* visit;         // [F][maxK] keypoint slots in raster order (written by the NMS finisher)
     int2* moments;           // [F][maxK] {m01, m10} scratch of the describe stage
     float2* cos_sin;         // [F][maxK] {cos, sin} scratch of the describe stage
     int* status;             // [F]
@@ -129,7 +130,8 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream);
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid);
 void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream);  // NonMaxSuppression: 0
 void launch_blur(const BatchView& v, const double* weights_dev, int nframes, hipStream_t stream);
-void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes,
+// use_visit: walk the keypoints in the raster order left by launch_nms (v.visit) instead of slot order
+void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
                      hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig);
 
 struct MatchView {
