@@ -7,10 +7,11 @@
 //   M_PIXEL_OFFSETS       include/slam/frontend/feature_detector.hpp:138-153
 //
 // MI355X design: integer-only, one image read.
-//   K1  fast_detect : one workgroup = 64 x 16 pixel tile, staged through LDS with a 3-px halo as
-//                     aligned dword loads; pretests on every pixel, the segment test only on the
-//                     compacted survivors; the corner predicate of a 64-pixel row segment is one
-//                     64-bit word of a corner bitmap (W*H/8 bytes), the only thing written.
+//   K1  fast_detect : one workgroup = 256 x 16 pixel tile, staged through LDS with a 3-px halo as
+//                     aligned dword loads; pretest A on 4 pixels per lane with packed 16-bit math,
+//                     pretest B + segment test only on the compacted survivors; the corner
+//                     predicate of a 64-pixel row segment is one 64-bit word of a corner bitmap
+//                     (W*H/8 bytes), the only thing written.
 //   K1b scan        : per frame, exclusive prefix sum of the bitmap popcounts in raster order
 //                     (row-major, word-major) -> the raster index of every corner is
 //                     wordoff[word] + popcount(bits below it).  This bitmap+prefix pair is also
@@ -27,10 +28,10 @@ namespace {
 __device__ __constant__ int8_t CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 __device__ __constant__ int8_t CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 
-constexpr int TILE_W = 64;
+constexpr int TILE_W = 256;
 constexpr int TILE_H = 16;
 constexpr int HALO = 3;
-constexpr int LDS_ROW_DW = 18;             // 72 bytes: columns [64wx-4, 64wx+68)
+constexpr int LDS_ROW_DW = TILE_W / 4 + 2;   // 264 bytes: columns [x0-4, x0+260)
 constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 22
 
 // The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels.
@@ -58,21 +59,42 @@ __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
     return (rb | rd) != 0;
 }
 
-// Two phases per 64 x 16 tile.  Phase 1 runs only the reference's two pretests
-// (feature_detector.cpp:81-113: the four cardinal circle pixels) on every pixel and appends the
-// few survivors to an LDS list; phase 2 runs the 16-pixel segment test densely on that list, so
-// the expensive part is not paid by the ~95 % of lanes that the pretests reject (a wave only
-// skips work if ALL of its lanes fail, which almost never happens on textured frames).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// bytes (0,1) / (2,3) of w zero-extended to two u16 lanes (v_perm_b32)
+__device__ __forceinline__ us2 unpack_lo(uint32_t w) {
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
+}
+__device__ __forceinline__ us2 unpack_hi(uint32_t w) {
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+}
+// per u16 lane: non-zero iff |n - c| > t, i.e. n is "brighter" or "darker" than c
+// (feature_detector.cpp:87-91: n > c + t  or  n < c - t, in int arithmetic)
+__device__ __forceinline__ us2 differs(us2 n, us2 c, us2 t) {
+    const us2 up = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(n, c), t);
+    const us2 dn = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, n), t);
+    return up | dn;
+}
+
+// Two phases per 256 x 16 tile (a lane owns 4 horizontally adjacent pixels = one dword).
+//  phase 1: pretest A of the reference (feature_detector.cpp:81-96: circle pixels 0 and 8, the
+//           pixels 3 rows above / below, i.e. the same dword of two other tile rows) on 4 pixels at
+//           once with packed 16-bit saturating arithmetic; survivors go to an LDS list.
+//  phase 2: pretest B on the survivors, compacted again, then the 16-pixel segment test on what
+//           is left (about 1-5 % of the pixels), so every stage runs on dense waves.
+// Pixels that fail A can never be corners, so the bitmap is the reference's.
 __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint16_t survivors[TILE_W * TILE_H];
-    __shared__ uint32_t row_mask[TILE_H][2];
+    __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
+    __shared__ uint16_t survivors2[TILE_W * TILE_H];
     __shared__ int n_survivors;
-    const int wx = blockIdx.x;
+    __shared__ int n_survivors2;
+    const int tx = blockIdx.x;
     const int ty = blockIdx.y;
     const int f = blockIdx.z;
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
-    const int x0 = wx * TILE_W - 4;
+    const int x0 = tx * TILE_W - 4;
     const int y0 = ty * TILE_H - HALO;
     for (int i = threadIdx.x; i < LDS_ROWS * LDS_ROW_DW; i += 256) {
         const int r = i / LDS_ROW_DW;
@@ -85,59 +107,106 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         }
         tile[i] = val;
     }
-    if (threadIdx.x < TILE_H * 2) {
-        row_mask[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+    if (threadIdx.x < TILE_H * (TILE_W / 32)) {
+        row_mask[threadIdx.x / (TILE_W / 32)][threadIdx.x % (TILE_W / 32)] = 0;
     }
     if (threadIdx.x == 0) {
         n_survivors = 0;
+        n_survivors2 = 0;
     }
     __syncthreads();
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
-    constexpr int RS = LDS_ROW_DW * 4;  // LDS row stride in bytes
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int x = wx * TILE_W + lane;
-    const bool x_ok = x >= HALO && x < v.cols - HALO;
-    // ---- phase 1: pretests
+    const int x = tx * TILE_W + lane * 4;
+    const us2 t2 = {static_cast<unsigned short>(threshold), static_cast<unsigned short>(threshold)};
+    // ---- phase 1
 #pragma unroll
     for (int k = 0; k < TILE_H / 4; ++k) {
         const int ry = wave * (TILE_H / 4) + k;
         const int y = ty * TILE_H + ry;
+        uint32_t flags = 0;  // bit p: pixel x+p survives pretest A
+        if (y >= HALO && y < v.rows - HALO) {
+            const uint32_t* rp = tile + (ry + HALO) * LDS_ROW_DW + lane + 1;
+            const uint32_t C = rp[0];
+            const uint32_t U = rp[-HALO * LDS_ROW_DW];
+            const uint32_t D = rp[HALO * LDS_ROW_DW];
+            const us2 c01 = unpack_lo(C), c23 = unpack_hi(C);
+            const us2 f01 = differs(unpack_lo(U), c01, t2) | differs(unpack_lo(D), c01, t2);
+            const us2 f23 = differs(unpack_hi(U), c23, t2) | differs(unpack_hi(D), c23, t2);
+            flags = (f01.x != 0 ? 1u : 0u) | (f01.y != 0 ? 2u : 0u) | (f23.x != 0 ? 4u : 0u) | (f23.y != 0 ? 8u : 0u);
+            // image border: columns < 3 or >= cols - 3 are never tested
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (x + p < HALO || x + p >= v.cols - HALO) {
+                    flags &= ~(1u << p);
+                }
+            }
+        }
+        const unsigned long long any = __ballot(flags != 0);
+        if (any != 0) {
+            // wave-wide exclusive prefix of popcount(flags) through the four bit planes
+            uint32_t before = 0;
+            uint32_t total = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned long long mp = __ballot((flags >> p) & 1u);
+                before += static_cast<uint32_t>(__popcll(mp & ((1ull << lane) - 1ull)));
+                total += static_cast<uint32_t>(__popcll(mp));
+            }
+            int base = 0;
+            if (lane == 0) {
+                base = atomicAdd(&n_survivors, static_cast<int>(total));
+            }
+            base = __shfl(base, 0);
+            uint32_t pos = static_cast<uint32_t>(base) + before;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if ((flags >> p) & 1u) {
+                    survivors[pos++] = static_cast<uint16_t>((ry << 8) | (lane * 4 + p));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2a: pretest B (needs the two horizontal cardinal pixels too) on the A-survivors,
+    // compacted again, so that the segment test below runs on dense waves
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+    constexpr int RS = LDS_ROW_DW * 4;  // LDS row stride in bytes
+    const int total = n_survivors;
+    for (int s0 = 0; s0 < total; s0 += 256) {  // block-uniform trip count
+        const int s = s0 + static_cast<int>(threadIdx.x);
         bool pass = false;
-        if (x_ok && y >= HALO && y < v.rows - HALO) {
-            const uint8_t* p = t8 + (ry + HALO) * RS + (lane + 4);
+        int e = 0;
+        if (s < total) {
+            e = survivors[s];
+            const uint8_t* p = t8 + ((e >> 8) + HALO) * RS + ((e & 255) + 4);
             const int c = p[0];
             const int hi = c + threshold;
             const int lo = c - threshold;
-            const int n0 = p[-3 * RS];  // circle pixel 0  (0,-3)
-            const int n8 = p[3 * RS];   // circle pixel 8  (0,+3)
-            const int n4 = p[3];        // circle pixel 4  (+3,0)
-            const int n12 = p[-3];      // circle pixel 12 (-3,0)
-            const int b0 = n0 > hi, b8 = n8 > hi, b4 = n4 > hi, b12 = n12 > hi;
-            const int d0 = n0 < lo, d8 = n8 < lo, d4 = n4 < lo, d12 = n12 < lo;
-            const bool passA = (b0 | b8 | d0 | d8) != 0;
-            const bool passB = (b0 + b8 + b4 + b12) >= 3 || (d0 + d8 + d4 + d12) >= 3;
-            pass = passA && passB;
+            const int n0 = p[-3 * RS], n8 = p[3 * RS], n4 = p[3], n12 = p[-3];
+            const int nb = (n0 > hi) + (n8 > hi) + (n4 > hi) + (n12 > hi);
+            const int nd = (n0 < lo) + (n8 < lo) + (n4 < lo) + (n12 < lo);
+            pass = nb >= 3 || nd >= 3;
         }
         const unsigned long long m = __ballot(pass);
         if (m != 0) {
             int base = 0;
             if (lane == 0) {
-                base = atomicAdd(&n_survivors, __popcll(m));
+                base = atomicAdd(&n_survivors2, __popcll(m));
             }
             base = __shfl(base, 0);
             if (pass) {
-                survivors[base + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>((ry << 6) | lane);
+                survivors2[base + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(e);
             }
         }
     }
     __syncthreads();
-    // ---- phase 2: full segment test on the survivors
-    const int total = n_survivors;
-    for (int s = threadIdx.x; s < total; s += 256) {
-        const int e = survivors[s];
-        const int ry = e >> 6;
-        const int col = e & 63;
+    // ---- phase 2b: the 16-pixel segment test
+    const int total2 = n_survivors2;
+    for (int s = threadIdx.x; s < total2; s += 256) {
+        const int e = survivors2[s];
+        const int ry = e >> 8;
+        const int col = e & 255;
         const uint8_t* p = t8 + (ry + HALO) * RS + (col + 4);
         const int c = p[0];
         const int hi = c + threshold;
@@ -155,13 +224,16 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         }
     }
     __syncthreads();
-    if (threadIdx.x < TILE_H) {
-        const int y = ty * TILE_H + static_cast<int>(threadIdx.x);
-        if (y < v.rows) {
+    // one 64-bit bitmap word per (row, 64-column group): 16 rows x 4 words per tile
+    if (threadIdx.x < TILE_H * (TILE_W / 64)) {
+        const int ry = threadIdx.x / (TILE_W / 64);
+        const int wq = threadIdx.x % (TILE_W / 64);
+        const int y = ty * TILE_H + ry;
+        const int wx = tx * (TILE_W / 64) + wq;
+        if (y < v.rows && wx < v.nw) {
             unsigned long long* masks = v.masks + static_cast<size_t>(f) * v.rows * v.nw;
-            masks[static_cast<size_t>(y) * v.nw + wx] =
-                static_cast<unsigned long long>(row_mask[threadIdx.x][0]) |
-                (static_cast<unsigned long long>(row_mask[threadIdx.x][1]) << 32);
+            masks[static_cast<size_t>(y) * v.nw + wx] = static_cast<unsigned long long>(row_mask[ry][2 * wq]) |
+                                                        (static_cast<unsigned long long>(row_mask[ry][2 * wq + 1]) << 32);
         }
     }
 }
@@ -266,7 +338,7 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
 }  // namespace
 
 void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
-    dim3 grid(v.nw, (v.rows + TILE_H - 1) / TILE_H, nframes);
+    dim3 grid((v.cols + TILE_W - 1) / TILE_W, (v.rows + TILE_H - 1) / TILE_H, nframes);
     hipLaunchKernelGGL(fast_detect_kernel, grid, dim3(256), 0, stream, v, p.threshold, p.arc);
 }
 
