@@ -114,6 +114,19 @@ def triangulate_last_pair(ctx, batch, matcher, B, cols, rows):
     return ctx.triangulate(P1, P2, p1, p2)[1]
 
 
+def pmc_traffic_bytes(kernel, batch):
+    """FETCH_SIZE + WRITE_SIZE (KB) of one launch of `kernel`, measured offline at batch 256."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_b256.csv")
+    if batch != 256 or not os.path.exists(path):
+        return None
+    name = kernel.split("<")[0]
+    for line in open(path).read().splitlines()[1:]:
+        parts = line.rsplit(",", 2)
+        if len(parts) == 3 and parts[0].split("<")[0] == name:
+            return (float(parts[1]) + float(parts[2])) * 1024.0
+    return None
+
+
 def cpu_baseline(mod, wl, frames, budget_s=15.0):
     """The restated reference CPU path (oracle/, single thread) on a bounded sample of the SAME
     frames: detectAndCompute + match(frame k, frame k-1) with keypoints."""
@@ -269,6 +282,12 @@ def main():
             roof = {"kernel": kernel_of.get(dom, dom), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_per_launch": byts, "traffic": None}
         roof["avg_launch_ms"] = stage[dom]
+        # HBM traffic per launch from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+        # separate runs of this same command, profiles/r01_pmc_hbm_traffic_b256.csv).  Calibration
+        # on blur_kernel, whose traffic is known (one frame read, one frame written): FETCH_SIZE
+        # reads 0.97x and WRITE_SIZE 1.00x the true bytes for this code's 4-byte-per-lane accesses,
+        # so no x2 correction is applied (the halving in MI355X_MICROARCH.md is for 16 B/lane streams).
+        roof["traffic"] = pmc_traffic_bytes(roof["kernel"], B)
         # every other kernel against its own roofline, for the record
         others = {}
         for k in stage:

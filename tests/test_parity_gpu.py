@@ -429,3 +429,32 @@ def test_camera_yaml_and_undistort(slamx, gpu_ctx, oracle, ref_data):
     assert set(np.unique(back)) <= set(np.unique(img)) | {0}
     with pytest.raises(RuntimeError, match="does not match camera image size"):
         gpu_ctx.undistort(cam, img[:100])
+
+
+# ---------------------------------------------------------------- BASELINE.json full-size workloads
+@pytest.mark.parametrize("name,rows,cols,window,n_rect,rmin,rmax", [
+    ("1080p_2k", 1080, 1920, 12, 6800, 3, 24),   # bench.py default workload (the metric's config)
+    ("c2", 480, 640, 6, 5000, 3, 16),            # BASELINE.json configs[1]
+    ("c3", 1080, 1920, 8, 32000, 3, 16),         # BASELINE.json configs[2]: ~80k candidates, ~10k keypoints
+])
+def test_full_size_workloads_bit_exact(slamx, oracle, name, rows, cols, window, n_rect, rmin, rmax):
+    """The bench workloads themselves, two consecutive frames each: candidates, keypoint order,
+    angles, descriptors and matches against the oracle (which needs a few seconds at c3)."""
+    d = slamx.FeatureDetector(cfg_of(slamx, window=window))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 20, 1, 0.5))
+    mp = oracle.match_params(m.cfg)
+    frames = [synth(slamx, k, rows, cols, n_rect, rmin=rmin, rmax=rmax) for k in range(2)]
+    b = slamx.Batch(d, rows, cols, 2, max_candidates=131072, max_keypoints=16384)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(2)
+    b.match_consecutive(m, 2, use_keypoints=True, first_train_frame=1)
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    for k in range(2):
+        k_got, d_got = b.download(k)
+        assert_records_equal(k_got, ref[k][0], "%s frame %d keypoints" % (name, k))
+        assert np.array_equal(d_got, ref[k][1])
+    for q, t_ in ((1, 0), (0, 1)):
+        want = oracle.match(ref[q][1], ref[t_][1], ref[q][0], ref[t_][0], mp)
+        assert_records_equal(b.download_matches(m, q), want, "%s matches %d->%d" % (name, q, t_))
+    assert len(ref[0][0]) > 1500
