@@ -22,19 +22,28 @@ namespace slamx {
 namespace {
 
 constexpr int TILE = 256;
+constexpr int EVQ_DEPTH = 24;  // deferred-update queue entries per lane
 
 // WORDS = 32-bit words compared per descriptor (the "live" prefix: words that can be non-zero in
 // either set; the all-zero tail contributes popcount(0^0) = 0 and is skipped -- exact).
 // STRIDE words separate consecutive descriptors in memory.  QPL = queries per lane.
 //
 // A pair can only change (best, second) if its distance is < second, and the jump penalty only
-// ever increases the distance, so the Hamming distance alone filters: raw >= second => skip the
-// penalty arithmetic (correctly-rounded sqrt and divide) entirely.  Exact, order-preserving.
+// ever increases the distance, so the Hamming distance alone filters: raw >= second => the pair
+// is dropped.  About 2 % of the pairs pass (`second` tightens like a record sequence), i.e. almost
+// every 64-lane wave has SOME lane that passes at every step, so handling a pass on the spot would
+// run the penalty arithmetic at 1/64 lane utilisation.  Instead every lane appends its passes
+// (raw distance, train index, which of its queries) to a private LDS queue, and the wave drains
+// all queues together when one fills up or the train tile ends: lane utilisation of the
+// expensive part rises from ~2 % to ~40 %.  The filter then uses a slightly stale `second`
+// (an upper bound of the current one: a superset passes) and the drain re-applies the exact
+// update rule in ascending train order per query, so the result is the sequential scan's.
 template <int WORDS, int QPL>
 __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame,
                                                     int stride) {
     __shared__ uint32_t tdesc[TILE * WORDS];
     __shared__ float2 txy[TILE];
+    __shared__ uint32_t evq[4][EVQ_DEPTH * 64];  // per wave: entry k of lane l at [k * 64 + l]
     const int qf = first_query_frame + blockIdx.y;
     const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
@@ -68,20 +77,23 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
         }
     }
     constexpr int JB = 4;
-    int t0 = 0;
-    // one (query u, train t0+j) pair through the reference's update (feature_matcher.cpp:132-141)
-    auto update = [&](int dist, int j, int u) {
+    const int lane = threadIdx.x & 63;
+    uint32_t* myq = evq[threadIdx.x >> 6] + lane;
+    int qcnt = 0;  // entries in this lane's queue
+    // one (query u, train t) pair through the reference's update (feature_matcher.cpp:132-141,
+    // penalty :161-170); t is tile-relative
+    auto apply = [&](int dist, int t, int u, int t0) {
         if (dist < second[u]) {
             if (use_kp) {
-                const float2 p = txy[j];
-                // Cheap exact rejection before the sqrt/divide: d = sqrtf(dx^2+dy^2) >= max(|dx|,|dy|)
-                // holds in IEEE float, every step of the penalty is monotone in d, and the three
-                // roundings of the reference expression move it by < 4e-7 relative; so if even the
-                // lower bound dist*(1+m/500), shrunk by 1e-5, reaches `second`, the penalised
-                // distance cannot be < second and the pair changes nothing.
-                const float m = fmaxf(fabsf(__fsub_rn(qx[u], p.x)), fabsf(__fsub_rn(qy[u], p.y)));
-                if (m > 500.0f) {
-                    const float lower = static_cast<float>(dist) * (1.0f + m * 0.002f) * 0.99999f;
+                const float2 p = txy[t];
+                // Cheap exact rejection: evaluate the penalised value with the 1-ulp hardware sqrt
+                // (relative error < 1e-6 against the reference expression); if even that value
+                // shrunk by 1e-5 reaches `second`, the pair cannot change (best, second).
+                const float dx = __fsub_rn(qx[u], p.x);
+                const float dy = __fsub_rn(qy[u], p.y);
+                const float da = __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                if (da > 500.01f) {
+                    const float lower = static_cast<float>(dist) * (1.0f + da * 0.002f) * 0.99999f;
                     if (lower >= static_cast<float>(second[u])) {
                         return;
                     }
@@ -90,15 +102,39 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             }
             const bool lt = dist < best[u];
             second[u] = lt ? best[u] : min(second[u], dist);
-            best_idx[u] = lt ? (t0 + j) : best_idx[u];
+            best_idx[u] = lt ? (t0 + t) : best_idx[u];
             best[u] = lt ? dist : best[u];
         }
+    };
+    // every lane replays its own queue in push order (= ascending train index per query); an entry
+    // carries the raw distances of BOTH of the lane's queries to one train descriptor
+    // (d0 | d1 << 10 | t << 20; distances <= 512) and apply() re-tests each against the now-current `second`
+    static_assert(QPL == 2, "the packed two-query filter below assumes two queries per lane");
+    uint32_t second_pk = 0xffffffffu;  // min(second[u], 0xffff) in two 16-bit halves: the (stale) filter bound
+    auto drain = [&](int t0) {
+        for (int k = 0; __ballot(k < qcnt) != 0; ++k) {
+            if (k < qcnt) {
+                const uint32_t e = myq[k * 64];
+                const int t = static_cast<int>(e >> 20);
+                apply(static_cast<int>(e & 0x3ffu), t, 0, t0);
+                apply(static_cast<int>((e >> 10) & 0x3ffu), t, 1, t0);
+            }
+        }
+        qcnt = 0;
+        second_pk = static_cast<uint32_t>(min(second[0], 0xffff)) | (static_cast<uint32_t>(min(second[1], 0xffff)) << 16);
+    };
+    // d0 < second[0] or d1 < second[1], both halves at once: saturating packed subtract
+    auto passes = [&](int d0, int d1) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 dpk = __builtin_bit_cast(us2, static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 16));
+        const us2 spk = __builtin_bit_cast(us2, second_pk);
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(spk, dpk)) != 0u;
     };
     // this workgroup scans train chunk blockIdx.z of mv.nsplit (merged in order by emit_kernel)
     const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
     const int t_begin = static_cast<int>(blockIdx.z) * chunk;
     const int t_end = min(n2, t_begin + chunk);
-    for (t0 = t_begin; t0 < t_end; t0 += TILE) {
+    for (int t0 = t_begin; t0 < t_end; t0 += TILE) {
         const int tn = min(TILE, t_end - t0);
         __syncthreads();
         for (int e = threadIdx.x; e < tn * WORDS; e += 256) {
@@ -111,11 +147,9 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             txy[threadIdx.x] = make_float2(k.x, k.y);
         }
         __syncthreads();
-        // groups of JB train descriptors: all LDS reads first, then all popcounts, and only if
-        // some distance can still matter (dist < second, tested against the value before the
-        // group, which is an upper bound of the value inside it) the in-order update path
         int j = 0;
         for (; j + JB <= tn; j += JB) {
+            // all LDS reads of the group first, then the popcounts
             uint32_t t[JB][WORDS];
 #pragma unroll
             for (int k = 0; k < JB; ++k) {
@@ -124,42 +158,41 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
                     t[k][w] = tdesc[(j + k) * WORDS + w];
                 }
             }
-            int d[JB][QPL];
-            bool any = false;
 #pragma unroll
             for (int k = 0; k < JB; ++k) {
+                int d0 = 0, d1 = 0;
 #pragma unroll
-                for (int u = 0; u < QPL; ++u) {
-                    int dist = 0;
-#pragma unroll
-                    for (int w = 0; w < WORDS; ++w) {
-                        dist += __popc(q[u][w] ^ t[k][w]);
-                    }
-                    d[k][u] = dist;
-                    any = any || dist < second[u];
+                for (int w = 0; w < WORDS; ++w) {
+                    d0 += __popc(q[0][w] ^ t[k][w]);
+                    d1 += __popc(q[1][w] ^ t[k][w]);
+                }
+                if (passes(d0, d1)) {  // against a stale upper bound of the true `second`
+                    myq[qcnt * 64] = static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 10) |
+                                     (static_cast<uint32_t>(j + k) << 20);
+                    ++qcnt;
                 }
             }
-            if (any) {
-#pragma unroll
-                for (int k = 0; k < JB; ++k) {
-#pragma unroll
-                    for (int u = 0; u < QPL; ++u) {
-                        update(d[k][u], j + k, u);
-                    }
-                }
+            if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {  // wave-uniform
+                drain(t0);
             }
         }
         for (; j < tn; ++j) {
+            int d0 = 0, d1 = 0;
 #pragma unroll
-            for (int u = 0; u < QPL; ++u) {
-                int dist = 0;
-#pragma unroll
-                for (int w = 0; w < WORDS; ++w) {
-                    dist += __popc(q[u][w] ^ tdesc[j * WORDS + w]);
-                }
-                update(dist, j, u);
+            for (int w = 0; w < WORDS; ++w) {
+                d0 += __popc(q[0][w] ^ tdesc[j * WORDS + w]);
+                d1 += __popc(q[1][w] ^ tdesc[j * WORDS + w]);
+            }
+            if (passes(d0, d1)) {
+                myq[qcnt * 64] = static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 10) |
+                                 (static_cast<uint32_t>(j) << 20);
+                ++qcnt;
+            }
+            if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {
+                drain(t0);
             }
         }
+        drain(t0);  // the queue holds tile-relative indices and txy[] is about to be replaced
     }
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {

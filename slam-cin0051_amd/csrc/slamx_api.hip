@@ -325,8 +325,9 @@ void filter_and_sort(std::vector<slamx_match>& m, int good_matches_count) {
     }
 }
 
-// Train-set split of the matcher: enough workgroups for ~8 waves per SIMD (256 CUs x 4 SIMDs),
-// 512 queries per 4-wave workgroup.
+// Train-set split of the matcher: enough workgroups for ~8 resident waves per SIMD (256 CUs x 4
+// SIMDs) even when only ~half of the maxK query slots of a frame are used; 512 queries per
+// 4-wave workgroup.
 int match_split_for(int npairs, int maxK) {
     const long long waves = static_cast<long long>(npairs > 0 ? npairs : 1) * ((maxK + 511) / 512) * 4;
     long long s = (8192 + waves - 1) / waves;
