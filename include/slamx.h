@@ -157,7 +157,8 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
 void slamx_batch_destroy(slamx_batch* b);
 /* Device pointer of frame 0; frame f row r starts at base + f*frame_stride + r*pitch. */
 uint8_t* slamx_batch_frames(slamx_batch* b, size_t* pitch, size_t* frame_stride);
-/* Host -> HBM copy of n frames (row-major, given stride) into slots first..first+n-1 (async). */
+/* Host -> HBM copy of n frames (row-major, given stride) into slots first..first+n-1, ordered after
+ * the work already queued on the batch; the host buffer may be reused as soon as the call returns. */
 int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
                        ptrdiff_t frame_stride);
 /* detectAndCompute on frames 0..nframes-1 (async on the context stream). */
@@ -174,6 +175,9 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
 int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches);
 int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t* desc, int cap, int* n);
 /* Matches of frame k against frame k-1, with the matcher's filter step applied on request. */
+/* The frame as it sits in HBM (blurred == 0) or its 5x5-blurred copy made by the last
+ * detect_and_compute (blurred != 0): what gaussianBlur (feature_detector.cpp:315-364) returned. */
+int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride);
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
                                  int cap, int* n);
 /* Per-stage device time from hipEvents recorded on the context stream between the kernels (no

@@ -18,6 +18,7 @@ tests/conftest.py) under the module name ``slam_cin0051_amd``.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -85,7 +86,7 @@ EXPORTS = [
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
+    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
 ]
@@ -143,6 +144,7 @@ def load_library():
     lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     lib.slamx_batch_counts.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.slamx_batch_download.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -211,6 +213,12 @@ def load_matcher_config(path):
     return cfg
 
 
+def _close_children(parent):
+    """Handles must go before the handle they were created on, whatever order the GC picks."""
+    for child in list(parent._children):
+        child.close()
+
+
 class Context:
     """One per GPU: owns the HIP stream every call is enqueued on."""
 
@@ -218,9 +226,11 @@ class Context:
         self.lib = load_library()
         self.h = C.c_void_p()
         _check(self.lib.slamx_ctx_create(device, stream, C.byref(self.h)))
+        self._children = weakref.WeakSet()  # detectors / matchers: destroyed before the context
 
     def close(self):
         if self.h:
+            _close_children(self)
             self.lib.slamx_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -358,9 +368,12 @@ class FeatureDetector:
         self.h = C.c_void_p()
         _check(self.lib.slamx_detector_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
         self.width = self.lib.slamx_detector_descriptor_width(self.h)
+        self._children = weakref.WeakSet()  # batches: destroyed before the detector
+        self.ctx._children.add(self)
 
     def close(self):
         if self.h:
+            _close_children(self)
             self.lib.slamx_detector_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -458,6 +471,7 @@ class FeatureMatcher:
         self.cfg = config if isinstance(config, MatcherConfig) else load_matcher_config(config)
         self.h = C.c_void_p()
         _check(self.lib.slamx_matcher_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
+        self.ctx._children.add(self)
 
     def close(self):
         if self.h:
@@ -497,6 +511,7 @@ class Batch:
         self.h = C.c_void_p()
         _check(self.lib.slamx_batch_create(detector.h, C.byref(self.shape), C.byref(self.h)))
         self.rows, self.cols, self.max_frames = rows, cols, max_frames
+        detector._children.add(self)
 
     def close(self):
         if self.h:
@@ -543,6 +558,11 @@ class Batch:
         desc = np.empty((n.value, self.det.width), np.uint8)
         _check(self.lib.slamx_batch_download(self.h, frame, _ptr(kps), _ptr(desc), n.value, C.byref(n)))
         return kps, desc
+
+    def download_image(self, frame, blurred=False):
+        out = np.empty((self.rows, self.cols), np.uint8)
+        _check(self.lib.slamx_batch_download_image(self.h, frame, 1 if blurred else 0, _ptr(out), out.strides[0]))
+        return out
 
     def download_matches(self, matcher, frame, apply_filter=False):
         n = C.c_int()

@@ -7,9 +7,9 @@
 //   M_PIXEL_OFFSETS       include/slam/frontend/feature_detector.hpp:138-153
 //
 // MI355X design: integer-only, one image read.
-//   K1  fast_detect : one workgroup = 256 x 16 pixel tile, staged through LDS with a 3-px halo as
-//                     aligned dword loads; pretest A on 4 pixels per lane with packed 16-bit math,
-//                     pretest B + segment test only on the compacted survivors; the corner
+//   K1  fast_detect : one workgroup = 256 x 32 pixel tile, staged through LDS with a 3-px halo as
+//                     aligned dword loads; the cardinal pretest on 4 pixels per lane with packed
+//                     16-bit math, the segment test only on the compacted survivors; the corner
 //                     predicate of a 64-pixel row segment is one 64-bit word of a corner bitmap
 //                     (W*H/8 bytes), the only thing written.
 //   K1b scan        : per frame, exclusive prefix sum of the bitmap popcounts in raster order
@@ -29,10 +29,11 @@ __device__ __constant__ int8_t CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2,
 __device__ __constant__ int8_t CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 
 constexpr int TILE_W = 256;
-constexpr int TILE_H = 16;
+constexpr int TILE_H = 32;
 constexpr int HALO = 3;
 constexpr int LDS_ROW_DW = TILE_W / 4 + 2;   // 264 bytes: columns [x0-4, x0+260)
-constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 22
+constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 38
+constexpr int ROWS_PER_WAVE = TILE_H / 4;
 
 // The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels.
 __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
@@ -68,143 +69,165 @@ __device__ __forceinline__ us2 unpack_lo(uint32_t w) {
 __device__ __forceinline__ us2 unpack_hi(uint32_t w) {
     return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
 }
-// per u16 lane: non-zero iff |n - c| > t, i.e. n is "brighter" or "darker" than c
-// (feature_detector.cpp:87-91: n > c + t  or  n < c - t, in int arithmetic)
-__device__ __forceinline__ us2 differs(us2 n, us2 c, us2 t) {
-    const us2 up = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(n, c), t);
-    const us2 dn = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(c, n), t);
-    return up | dn;
+
+// Pretest B of the reference (feature_detector.cpp:98-113) for two pixels at once, in packed
+// 16-bit arithmetic: "at least 3 of the 4 cardinal circle pixels are brighter than c + t" is
+// "the second smallest of them is", "at least 3 are darker than c - t" is "the second largest
+// is"; both order statistics come out of one 4-input sorting network.  Non-zero lane = pass.
+// Pretest A (:81-96, pixels 0 and 8) is implied: 3 of 4 cardinals include pixel 0 or pixel 8.
+__device__ __forceinline__ uint32_t cardinal_test(us2 c, us2 u, us2 d, us2 l, us2 r, us2 t) {
+    const us2 hi = c + t;                                  // <= 510, no wrap
+    const us2 lo = __builtin_elementwise_sub_sat(c, t);    // max(c - t, 0): nothing is < 0
+    const us2 a = __builtin_elementwise_min(u, d), b = __builtin_elementwise_max(u, d);
+    const us2 e = __builtin_elementwise_min(l, r), f = __builtin_elementwise_max(l, r);
+    const us2 mac = __builtin_elementwise_max(a, e);
+    const us2 mbd = __builtin_elementwise_min(b, f);
+    const us2 second_smallest = __builtin_elementwise_min(mac, mbd);
+    const us2 second_largest = __builtin_elementwise_max(mac, mbd);
+    const us2 pass = __builtin_elementwise_sub_sat(second_smallest, hi) | __builtin_elementwise_sub_sat(lo, second_largest);
+    return __builtin_bit_cast(uint32_t, pass);
 }
 
-// Two phases per 256 x 16 tile (a lane owns 4 horizontally adjacent pixels = one dword).
-//  phase 1: pretest A of the reference (feature_detector.cpp:81-96: circle pixels 0 and 8, the
-//           pixels 3 rows above / below, i.e. the same dword of two other tile rows) on 4 pixels at
-//           once with packed 16-bit saturating arithmetic; survivors go to an LDS list.
-//  phase 2: pretest B on the survivors, compacted again, then the 16-pixel segment test on what
-//           is left (about 1-5 % of the pixels), so every stage runs on dense waves.
-// Pixels that fail A can never be corners, so the bitmap is the reference's.
+// Two phases per 256 x 32 tile (a lane owns 4 horizontally adjacent pixels = one dword).
+//  phase 1: the cardinal pretest on 4 pixels per lane (centre row dwords unpacked once and
+//           reused as the up / down rows of the rows 3 below / above; left / right neighbours
+//           picked with v_perm); about 1 % of the pixels survive and go to an LDS list.
+//  phase 2: the 16-pixel segment test on the survivors, on dense waves.
+// Pixels that fail the pretest can never be corners, so the bitmap is the reference's.
 __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint16_t survivors[TILE_W * TILE_H];
     __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
-    __shared__ uint16_t survivors2[TILE_W * TILE_H];
     __shared__ int n_survivors;
-    __shared__ int n_survivors2;
     const int tx = blockIdx.x;
     const int ty = blockIdx.y;
     const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     const int x0 = tx * TILE_W - 4;
     const int y0 = ty * TILE_H - HALO;
-    for (int i = threadIdx.x; i < LDS_ROWS * LDS_ROW_DW; i += 256) {
-        const int r = i / LDS_ROW_DW;
-        const int c = i - r * LDS_ROW_DW;
-        const int yy = y0 + r;
-        const int xx = x0 + c * 4;
-        uint32_t val = 0;
-        if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
-            val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+    {
+        // a wave stages whole rows (lane -> dword column), threads 0..2*LDS_ROWS-1 the two extra
+        // halo dwords of every row; all loads are issued before the first LDS store
+        constexpr int NLOAD = (LDS_ROWS + 3) / 4;
+        const int xa = x0 + lane * 4;
+        const bool ca = xa >= 0 && xa + 4 <= v.pitch;
+        uint32_t va[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int r = wave + 4 * i;
+            const int yy = y0 + r;
+            const bool ok = ca && r < LDS_ROWS && yy >= 0 && yy < v.rows;
+            const uint8_t* src = ok ? img + static_cast<size_t>(yy) * v.pitch + xa : img;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(src);
+            va[i] = ok ? w : 0u;
         }
-        tile[i] = val;
+        const int hr = static_cast<int>(threadIdx.x) >> 1;
+        const int hx = x0 + (64 + (static_cast<int>(threadIdx.x) & 1)) * 4;
+        const int hy = y0 + hr;
+        const bool hok = hr < LDS_ROWS && hy >= 0 && hy < v.rows && hx + 4 <= v.pitch;
+        const uint8_t* hsrc = hok ? img + static_cast<size_t>(hy) * v.pitch + hx : img;
+        uint32_t vh = *reinterpret_cast<const uint32_t*>(hsrc);
+        vh = hok ? vh : 0u;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int r = wave + 4 * i;
+            if (r < LDS_ROWS) {
+                tile[r * LDS_ROW_DW + lane] = va[i];
+            }
+        }
+        if (hr < LDS_ROWS) {
+            tile[hr * LDS_ROW_DW + 64 + (threadIdx.x & 1)] = vh;
+        }
     }
     if (threadIdx.x < TILE_H * (TILE_W / 32)) {
         row_mask[threadIdx.x / (TILE_W / 32)][threadIdx.x % (TILE_W / 32)] = 0;
     }
     if (threadIdx.x == 0) {
         n_survivors = 0;
-        n_survivors2 = 0;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int x = tx * TILE_W + lane * 4;
     const us2 t2 = {static_cast<unsigned short>(threshold), static_cast<unsigned short>(threshold)};
-    // ---- phase 1
+    // ---- phase 1: a wave walks its ROWS_PER_WAVE consecutive rows; every LDS row is unpacked
+    // once and serves as the centre row, as the "up" row 3 rows later and the "down" row 3 rows
+    // earlier.  Pass flags are collected as bits (acc01: pixel 0 of row k -> bit k, pixel 1 ->
+    // bit 16 + k; acc23 likewise for pixels 2, 3) and compacted once at the end.
+    uint32_t acc01 = 0, acc23 = 0;
+    {
+        const uint32_t* col = tile + (wave * ROWS_PER_WAVE) * LDS_ROW_DW + lane + 1;  // LDS row of tile row ry-3
+        us2 clo[ROWS_PER_WAVE + 2 * HALO], chi[ROWS_PER_WAVE + 2 * HALO];
+        uint32_t craw[ROWS_PER_WAVE + 2 * HALO];
 #pragma unroll
-    for (int k = 0; k < TILE_H / 4; ++k) {
-        const int ry = wave * (TILE_H / 4) + k;
-        const int y = ty * TILE_H + ry;
-        uint32_t flags = 0;  // bit p: pixel x+p survives pretest A
-        if (y >= HALO && y < v.rows - HALO) {
-            const uint32_t* rp = tile + (ry + HALO) * LDS_ROW_DW + lane + 1;
-            const uint32_t C = rp[0];
-            const uint32_t U = rp[-HALO * LDS_ROW_DW];
-            const uint32_t D = rp[HALO * LDS_ROW_DW];
-            const us2 c01 = unpack_lo(C), c23 = unpack_hi(C);
-            const us2 f01 = differs(unpack_lo(U), c01, t2) | differs(unpack_lo(D), c01, t2);
-            const us2 f23 = differs(unpack_hi(U), c23, t2) | differs(unpack_hi(D), c23, t2);
-            flags = (f01.x != 0 ? 1u : 0u) | (f01.y != 0 ? 2u : 0u) | (f23.x != 0 ? 4u : 0u) | (f23.y != 0 ? 8u : 0u);
-            // image border: columns < 3 or >= cols - 3 are never tested
+        for (int j = 0; j < 2 * HALO; ++j) {
+            craw[j] = col[j * LDS_ROW_DW];
+            clo[j] = unpack_lo(craw[j]);
+            chi[j] = unpack_hi(craw[j]);
+        }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (x + p < HALO || x + p >= v.cols - HALO) {
-                    flags &= ~(1u << p);
-                }
+        for (int k = 0; k < ROWS_PER_WAVE; ++k) {
+            const int jn = k + 2 * HALO;
+            craw[jn] = col[jn * LDS_ROW_DW];
+            clo[jn] = unpack_lo(craw[jn]);
+            chi[jn] = unpack_hi(craw[jn]);
+            const int jc = k + HALO;
+            const uint32_t C = craw[jc];
+            const uint32_t Pv = col[jc * LDS_ROW_DW - 1];
+            const uint32_t Nx = col[jc * LDS_ROW_DW + 1];
+            // left neighbours (x-3, x-2 | x-1, x) and right neighbours (x+3, x+4 | x+5, x+6) as u16 pairs
+            const us2 l_lo = __builtin_bit_cast(us2, __builtin_amdgcn_perm(C, Pv, 0x0c020c01u));
+            const us2 l_hi = __builtin_bit_cast(us2, __builtin_amdgcn_perm(C, Pv, 0x0c040c03u));
+            const us2 r_lo = __builtin_bit_cast(us2, __builtin_amdgcn_perm(Nx, C, 0x0c040c03u));
+            const us2 r_hi = __builtin_bit_cast(us2, __builtin_amdgcn_perm(Nx, C, 0x0c060c05u));
+            const uint32_t p01 = cardinal_test(clo[jc], clo[k], clo[jn], l_lo, r_lo, t2);
+            const uint32_t p23 = cardinal_test(chi[jc], chi[k], chi[jn], l_hi, r_hi, t2);
+            const us2 one = {1, 1};
+            const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, p01), one));
+            const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, p23), one));
+            acc01 |= b01 << k;
+            acc23 |= b23 << k;
+        }
+    }
+    {
+        // image border: rows / columns < 3 or >= size - 3 are never tested (feature_detector.cpp:61-63)
+        const int ybase = ty * TILE_H + wave * ROWS_PER_WAVE;
+        uint32_t rowbits = 0;
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_WAVE; ++k) {
+            if (ybase + k >= HALO && ybase + k < v.rows - HALO) {
+                rowbits |= 1u << k;
             }
         }
-        const unsigned long long any = __ballot(flags != 0);
-        if (any != 0) {
-            // wave-wide exclusive prefix of popcount(flags) through the four bit planes
-            uint32_t before = 0;
-            uint32_t total = 0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned long long mp = __ballot((flags >> p) & 1u);
-                before += static_cast<uint32_t>(__popcll(mp & ((1ull << lane) - 1ull)));
-                total += static_cast<uint32_t>(__popcll(mp));
+        const uint32_t ok0 = (x + 0 >= HALO && x + 0 < v.cols - HALO) ? rowbits : 0u;
+        const uint32_t ok1 = (x + 1 >= HALO && x + 1 < v.cols - HALO) ? rowbits : 0u;
+        const uint32_t ok2 = (x + 2 >= HALO && x + 2 < v.cols - HALO) ? rowbits : 0u;
+        const uint32_t ok3 = (x + 3 >= HALO && x + 3 < v.cols - HALO) ? rowbits : 0u;
+        acc01 &= ok0 | (ok1 << 16);
+        acc23 &= ok2 | (ok3 << 16);
+        const int cnt = __popc(acc01) + __popc(acc23);
+        if (cnt != 0) {
+            int pos = atomicAdd(&n_survivors, cnt);
+            const uint32_t ent0 = static_cast<uint32_t>((wave * ROWS_PER_WAVE) << 8) | static_cast<uint32_t>(lane * 4);
+            while (acc01 != 0) {
+                const int b = __ffs(static_cast<int>(acc01)) - 1;
+                acc01 &= acc01 - 1;
+                survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + (b >> 4));
             }
-            int base = 0;
-            if (lane == 0) {
-                base = atomicAdd(&n_survivors, static_cast<int>(total));
-            }
-            base = __shfl(base, 0);
-            uint32_t pos = static_cast<uint32_t>(base) + before;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if ((flags >> p) & 1u) {
-                    survivors[pos++] = static_cast<uint16_t>((ry << 8) | (lane * 4 + p));
-                }
+            while (acc23 != 0) {
+                const int b = __ffs(static_cast<int>(acc23)) - 1;
+                acc23 &= acc23 - 1;
+                survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + 2 + (b >> 4));
             }
         }
     }
     __syncthreads();
-    // ---- phase 2a: pretest B (needs the two horizontal cardinal pixels too) on the A-survivors,
-    // compacted again, so that the segment test below runs on dense waves
+    // ---- phase 2: the 16-pixel segment test
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
     constexpr int RS = LDS_ROW_DW * 4;  // LDS row stride in bytes
     const int total = n_survivors;
-    for (int s0 = 0; s0 < total; s0 += 256) {  // block-uniform trip count
-        const int s = s0 + static_cast<int>(threadIdx.x);
-        bool pass = false;
-        int e = 0;
-        if (s < total) {
-            e = survivors[s];
-            const uint8_t* p = t8 + ((e >> 8) + HALO) * RS + ((e & 255) + 4);
-            const int c = p[0];
-            const int hi = c + threshold;
-            const int lo = c - threshold;
-            const int n0 = p[-3 * RS], n8 = p[3 * RS], n4 = p[3], n12 = p[-3];
-            const int nb = (n0 > hi) + (n8 > hi) + (n4 > hi) + (n12 > hi);
-            const int nd = (n0 < lo) + (n8 < lo) + (n4 < lo) + (n12 < lo);
-            pass = nb >= 3 || nd >= 3;
-        }
-        const unsigned long long m = __ballot(pass);
-        if (m != 0) {
-            int base = 0;
-            if (lane == 0) {
-                base = atomicAdd(&n_survivors2, __popcll(m));
-            }
-            base = __shfl(base, 0);
-            if (pass) {
-                survivors2[base + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(e);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase 2b: the 16-pixel segment test
-    const int total2 = n_survivors2;
-    for (int s = threadIdx.x; s < total2; s += 256) {
-        const int e = survivors2[s];
+    for (int s = threadIdx.x; s < total; s += 256) {
+        const int e = survivors[s];
         const int ry = e >> 8;
         const int col = e & 255;
         const uint8_t* p = t8 + (ry + HALO) * RS + (col + 4);
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         }
     }
     __syncthreads();
-    // one 64-bit bitmap word per (row, 64-column group): 16 rows x 4 words per tile
+    // one 64-bit bitmap word per (row, 64-column group): TILE_H rows x 4 words per tile
     if (threadIdx.x < TILE_H * (TILE_W / 64)) {
         const int ry = threadIdx.x / (TILE_W / 64);
         const int wq = threadIdx.x % (TILE_W / 64);

