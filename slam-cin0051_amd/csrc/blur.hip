@@ -8,18 +8,21 @@
 // Bit-exactness without paying for 25 double MACs per pixel (that version ran at 7 % of HBM
 // bandwidth, FP64-issue bound):
 //   * fast path: the kernel is separable (w_ij = g_i g_j, g = exp(-i^2/2)/sum), so every pixel is
-//     first evaluated in float as 5 vertical + 5 horizontal FMAs.  That estimate is within 3e-4
-//     of the reference's double sum (255 * (10 float roundings + the g_i g_j vs w_ij model error),
-//     error budget in DESIGN.md), so whenever its fractional part is farther than 6e-4 from .5 the rounded byte
-//     is already determined: result = floor(v + 0.5).
+//     first evaluated in float as 5 vertical + 5 horizontal FMAs.  That estimate is within 1.3e-4
+//     of the reference's double sum (error budget in DESIGN.md), so whenever its fractional part
+//     is farther than 6e-4 from .5 the rounded byte is already determined: round-to-nearest(v).
 //   * exact path (about 0.12 % of the pixels): the reference's 25 IEEE double multiplies and adds
 //     in the reference's order (__dmul_rn / __dadd_rn, never contracted), weights computed on
-//     the HOST with the same std::exp and division as the reference.
+//     the HOST with the same std::exp and division as the reference.  These pixels are collected
+//     in an LDS list and patched by a dense second pass, so the main loop never diverges.
 // Either way the byte written is the reference's byte.
 //
-// Layout: a workgroup owns a 256 x 16 pixel tile staged through LDS as aligned dwords (2-px
-// halo); a lane produces 4 horizontally adjacent pixels = one dword store, a wave a 256-pixel row
-// segment, so loads and stores are full-width coalesced.  One HBM read + one HBM write per frame.
+// Layout: a workgroup owns a 248 x 32 pixel tile: lane l of a wave owns the dword of columns
+// X0-4+4l .. X0-1+4l, so lanes 1..62 produce output and lanes 0 / 63 are the halo columns.  A lane
+// runs the vertical pass on its own 4 columns only and receives the two neighbouring column pairs
+// it needs for the horizontal pass from lanes l-1 / l+1 through DPP wave shifts -- no column is
+// filtered twice.  Results go through an LDS output tile (patched there by the exact pass) and
+// leave as coalesced dword stores.  One HBM read + one HBM write per frame.
 #include "slamx_internal.h"
 
 #pragma clang fp contract(off)
@@ -28,26 +31,61 @@ namespace slamx {
 
 namespace {
 
-constexpr int TILE_W = 256;
-constexpr int TILE_H = 16;
+constexpr int TILE_W = 248;                  // output columns per tile (62 lanes x 4)
+constexpr int TILE_H = 32;
 constexpr int HALO = 2;
-constexpr int LDS_ROW_DW = TILE_W / 4 + 2;   // columns [x0-4, x0+260) as dwords
-constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 20
+constexpr int LDS_ROW_DW = 64;               // columns [X0-4, X0+252) as dwords, one per lane
+constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 36
+constexpr int ROWS_PER_WAVE = TILE_H / 4;
+constexpr int FIX_CAP = 2048;                // uncertain pixels listed per tile; beyond: whole tile exact
+// |frac(estimate) - 0.5| <= 6e-4 sends a pixel to the exact pass; tested as
+// frac(estimate - UNC_LO) <= UNC_SPAN, widened by 5e-5 for the rounding of that subtraction
+constexpr float UNC_LO = 0.5f - 6.5e-4f;
+constexpr float UNC_SPAN = 1.3e-3f;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float ub(uint32_t w, int k) {  // byte k of w as float (v_cvt_f32_ubyteK)
     return static_cast<float>((w >> (8 * k)) & 0xffu);
 }
 
+// the reference's sum for the pixel whose centre byte is at pc in the LDS tile
+__device__ __forceinline__ uint32_t exact_pixel(const uint8_t* pc, const double* wgt) {
+    double acc = 0.0;
+#pragma unroll
+    for (int ky = -2; ky <= 2; ++ky) {
+#pragma unroll
+        for (int kx = -2; kx <= 2; ++kx) {
+            const double px = static_cast<double>(pc[ky * (LDS_ROW_DW * 4) + kx]);
+            acc = __dadd_rn(acc, __dmul_rn(px, wgt[(ky + 2) * 5 + (kx + 2)]));
+        }
+    }
+    return static_cast<uint32_t>(static_cast<int>(round(acc)));
+}
+
+// lane i <- lane i-1 / lane i+1 of the wave (lanes 0 / 63 receive 0)
+__device__ __forceinline__ float from_left(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+
 __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __restrict__ weights) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
+    __shared__ uint32_t outt[TILE_H * LDS_ROW_DW];
+    __shared__ uint16_t fix[FIX_CAP];
+    __shared__ int nfix;
     __shared__ double wgt[25];
     __shared__ float g[5];
     const int tx = blockIdx.x;
     const int ty = blockIdx.y;
     const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     uint8_t* out = v.blurred + static_cast<size_t>(f) * v.frame_stride;
-    const int x0 = tx * TILE_W - 4;
+    const int x = tx * TILE_W - 4 + lane * 4;  // first of this lane's 4 columns
     const int y0 = ty * TILE_H - HALO;
     if (threadIdx.x < 25) {
         wgt[threadIdx.x] = weights[threadIdx.x];
@@ -56,100 +94,150 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         // separable factor: w[i][2] / sqrt(w[2][2]) == exp(-i^2/2) / sum(exp(-k^2/2))
         g[threadIdx.x] = static_cast<float>(weights[threadIdx.x * 5 + 2] / sqrt(weights[12]));
     }
-    for (int i = threadIdx.x; i < LDS_ROWS * LDS_ROW_DW; i += 256) {
-        const int r = i / LDS_ROW_DW;
-        const int c = i - r * LDS_ROW_DW;
-        const int yy = y0 + r;
-        const int xx = x0 + c * 4;
-        uint32_t val = 0;
-        if (yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
-            val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+    if (threadIdx.x == 0) {
+        nfix = 0;
+    }
+    {
+        // a wave stages whole rows, lane -> dword column; all loads are issued before the first LDS store
+        constexpr int NLOAD = LDS_ROWS / 4;
+        static_assert(LDS_ROWS % 4 == 0, "rows are dealt to 4 waves");
+        const bool ca = x >= 0 && x + 4 <= v.pitch;
+        uint32_t va[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int yy = y0 + wave + 4 * i;
+            const bool ok = ca && yy >= 0 && yy < v.rows;
+            const uint8_t* src = ok ? img + static_cast<size_t>(yy) * v.pitch + x : img;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(src);
+            va[i] = ok ? w : 0u;
         }
-        tile[i] = val;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            tile[(wave + 4 * i) * LDS_ROW_DW + lane] = va[i];
+        }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int x = tx * TILE_W + lane * 4;  // first of this lane's 4 pixels
-    if (x >= v.cols) {
-        return;
-    }
     const float g0 = g[0], g1 = g[1], g2 = g[2];  // g[3] == g[1], g[4] == g[0]
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
-    // rolling window of 5 input rows x 8 columns (x-2 .. x+5), converted to float once per row
-    float win[5][8];
-    auto load_row = [&](int lds_row, float* dst) {
-        const uint32_t* rp = tile + lds_row * LDS_ROW_DW + lane;  // dwords covering x-4 .. x+7
-        const uint32_t a = rp[0], b = rp[1], c = rp[2];
-        dst[0] = ub(a, 2);
-        dst[1] = ub(a, 3);
-        dst[2] = ub(b, 0);
-        dst[3] = ub(b, 1);
-        dst[4] = ub(b, 2);
-        dst[5] = ub(b, 3);
-        dst[6] = ub(c, 0);
-        dst[7] = ub(c, 1);
-    };
-    const int ry0 = wave * (TILE_H / 4);  // this wave's 4 output rows: ry0 .. ry0+3 (tile-relative)
+    const f2 G0 = {g0, g0}, G1 = {g1, g1}, G2 = {g2, g2};
+    // bytes of the output dword that are image border (columns < 2 or >= cols - 2): copied (:355-361)
+    uint32_t keep = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        load_row(ry0 + r, win[r]);  // LDS rows ry0 .. ry0+3 are image rows y-2 .. y+1 of output row ry0
+    for (int p = 0; p < 4; ++p) {
+        if (x + p < HALO || x + p >= v.cols - HALO) {
+            keep |= 0xffu << (8 * p);
+        }
     }
+    const bool writer = lane >= 1 && lane <= 62 && x < v.cols;
+    {
+        // rolling window of 5 input rows x this lane's 4 columns as 2 float pairs, converted once per row
+        f2 win[5][2];
+        uint32_t centre[5];
+        auto load_row = [&](int lds_row, f2* dst, uint32_t* mid) {
+            const uint32_t w = tile[lds_row * LDS_ROW_DW + lane];
+            dst[0] = f2{ub(w, 0), ub(w, 1)};
+            dst[1] = f2{ub(w, 2), ub(w, 3)};
+            *mid = w;
+        };
+        const int ry0 = wave * ROWS_PER_WAVE;  // this wave's output rows ry0 .. ry0+RPW-1 (tile-relative)
 #pragma unroll
-    for (int k = 0; k < TILE_H / 4; ++k) {
-        const int ry = ry0 + k;
-        const int y = ty * TILE_H + ry;
-        load_row(ry + 4, win[(k + 4) % 5]);
-        if (y >= v.rows) {
-            break;  // wave-uniform
+        for (int r = 0; r < 4; ++r) {
+            load_row(ry0 + r, win[r], &centre[r]);  // LDS rows ry0 .. ry0+3 are image rows y-2 .. y+1 of row ry0
         }
-        const float* rm2 = win[(k + 0) % 5];
-        const float* rm1 = win[(k + 1) % 5];
-        const float* rc = win[(k + 2) % 5];
-        const float* rp1 = win[(k + 3) % 5];
-        const float* rp2 = win[(k + 4) % 5];
-        float h[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            h[c] = fmaf(g0, rm2[c] + rp2[c], fmaf(g1, rm1[c] + rp1[c], g2 * rc[c]));
-        }
-        uint32_t packed = 0;
-        const bool row_inside = y >= HALO && y < v.rows - HALO;
+        for (int k = 0; k < ROWS_PER_WAVE; ++k) {
+            const int ry = ry0 + k;
+            const int y = ty * TILE_H + ry;
+            load_row(ry + 4, win[(k + 4) % 5], &centre[(k + 4) % 5]);
+            if (y >= v.rows) {
+                break;  // wave-uniform
+            }
+            const uint32_t src = centre[(k + 2) % 5];
+            uint32_t packed = src;
+            if (y >= HALO && y < v.rows - HALO) {  // wave-uniform
+                const f2* rm2 = win[(k + 0) % 5];
+                const f2* rm1 = win[(k + 1) % 5];
+                const f2* rc = win[(k + 2) % 5];
+                const f2* rp1 = win[(k + 3) % 5];
+                const f2* rp2 = win[(k + 4) % 5];
+                float h[8];  // vertical pass of columns x-2 .. x+5; h[2..5] are this lane's own
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int xp = x + p;
-            uint32_t res;
-            if (row_inside && xp >= HALO && xp < v.cols - HALO) {
-                const float est = fmaf(g0, h[p] + h[p + 4], fmaf(g1, h[p + 1] + h[p + 3], g2 * h[p + 2]));
-                const float fl = floorf(est);
-                const float fr = est - fl;
-                if (fabsf(fr - 0.5f) > 6.0e-4f) {
-                    res = static_cast<uint32_t>(static_cast<int>(floorf(est + 0.5f)));
-                } else {
-                    // too close to a rounding boundary for the float estimate: the reference's sum
-                    const uint8_t* pc = t8 + (ry + HALO) * (LDS_ROW_DW * 4) + (lane * 4 + p + 4);
-                    double acc = 0.0;
+                for (int c = 0; c < 2; ++c) {
+                    const f2 hv = __builtin_elementwise_fma(G0, rm2[c] + rp2[c], __builtin_elementwise_fma(G1, rm1[c] + rp1[c], G2 * rc[c]));
+                    h[2 + 2 * c] = hv.x;
+                    h[3 + 2 * c] = hv.y;
+                }
+                h[0] = from_left(h[4]);
+                h[1] = from_left(h[5]);
+                h[6] = from_right(h[2]);
+                h[7] = from_right(h[3]);
+                uint32_t acc = 0;
+                float w[4];
 #pragma unroll
-                    for (int ky = -2; ky <= 2; ++ky) {
+                for (int p = 0; p < 4; ++p) {
+                    const float est = fmaf(g0, h[p] + h[p + 4], fmaf(g1, h[p + 1] + h[p + 3], g2 * h[p + 2]));
+                    // est >= 0; round-to-nearest equals floor(est + 0.5) away from the .5 boundary
+                    acc = __builtin_amdgcn_cvt_pk_u8_f32(est, p, acc);
+                    w[p] = __builtin_amdgcn_fractf(est - UNC_LO);
+                }
+                packed = (src & keep) | (acc & ~keep);
+                const bool some = writer && fminf(fminf(w[0], w[1]), fminf(w[2], w[3])) <= UNC_SPAN;
+                if (__ballot(some) != 0) {  // about a quarter of the wave-rows
+                    if (some) {
 #pragma unroll
-                        for (int kx = -2; kx <= 2; ++kx) {
-                            const double px = static_cast<double>(pc[ky * (LDS_ROW_DW * 4) + kx]);
-                            acc = __dadd_rn(acc, __dmul_rn(px, wgt[(ky + 2) * 5 + (kx + 2)]));
+                        for (int p = 0; p < 4; ++p) {
+                            if (w[p] <= UNC_SPAN && ((keep >> (8 * p)) & 1u) == 0) {
+                                const int pos = atomicAdd(&nfix, 1);
+                                if (pos < FIX_CAP) {
+                                    fix[pos] = static_cast<uint16_t>((ry << 8) | (lane * 4 + p));
+                                }
+                            }
                         }
                     }
-                    res = static_cast<uint32_t>(static_cast<int>(round(acc)));
                 }
-            } else {
-                res = static_cast<uint32_t>(rc[p + 2]);  // border copied from the source (:355-361)
             }
-            packed |= (res & 0xffu) << (8 * p);
+            outt[ry * LDS_ROW_DW + lane] = packed;
         }
-        uint8_t* dst = out + static_cast<size_t>(y) * v.pitch + x;
-        if (x + 4 <= v.cols) {
-            *reinterpret_cast<uint32_t*>(dst) = packed;
-        } else {
-            for (int p = 0; p < v.cols - x; ++p) {
-                dst[p] = static_cast<uint8_t>(packed >> (8 * p));
+    }
+    __syncthreads();
+    // ---- exact pass on the listed pixels (or on the whole tile when the list overflowed)
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+    uint8_t* o8 = reinterpret_cast<uint8_t*>(outt);
+    const int listed = nfix;
+    if (listed <= FIX_CAP) {
+        for (int s = threadIdx.x; s < listed; s += 256) {
+            const int e = fix[s];
+            const int ry = e >> 8;
+            const int col = e & 255;  // byte column inside the LDS row
+            o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, wgt));
+        }
+    } else {
+        for (int s = threadIdx.x; s < TILE_W * TILE_H; s += 256) {
+            const int ry = s / TILE_W;
+            const int col = s - ry * TILE_W + 4;
+            const int yy = ty * TILE_H + ry;
+            const int xx = tx * TILE_W - 4 + col;
+            if (yy >= HALO && yy < v.rows - HALO && xx >= HALO && xx < v.cols - HALO) {
+                o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, wgt));
+            }
+        }
+    }
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_WAVE; ++k) {
+            const int ry = wave * ROWS_PER_WAVE + k;
+            const int y = ty * TILE_H + ry;
+            if (y >= v.rows) {
+                break;
+            }
+            const uint32_t packed = outt[ry * LDS_ROW_DW + lane];
+            uint8_t* dst = out + static_cast<size_t>(y) * v.pitch + x;
+            if (x + 4 <= v.cols) {
+                *reinterpret_cast<uint32_t*>(dst) = packed;
+            } else {
+                for (int p = 0; p < v.cols - x; ++p) {
+                    dst[p] = static_cast<uint8_t>(packed >> (8 * p));
+                }
             }
         }
     }
