@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     __shared__ int nfix;
     __shared__ double wgt[25];
     __shared__ float g[5];
+    // 2-D tile grid: with 8 tile columns (1920 / 248) a tile column stays on one XCD, whose L2
+    // then serves the halo rows shared by vertically adjacent tiles
     const int tx = blockIdx.x;
     const int ty = blockIdx.y;
     const int f = blockIdx.z;

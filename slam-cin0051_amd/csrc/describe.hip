@@ -218,18 +218,6 @@ constexpr int MAX_DISC = 716;                 // pixels of the radius-15 disc (7
 // wave (1) fetches the coordinates of up to 64 of its keypoints with ONE coalesced load and hands
 // them out with readlane, and (2) issues the global loads of the NEXT keypoint's tile into
 // registers before it computes on the current one, committing them to LDS afterwards.
-// 1-D grid -> (frame, block-in-frame) such that all blocks of a frame land on ONE XCD (hardware
-// deals consecutive workgroup ids round-robin over the 8 XCDs): the L2 of an XCD then only holds the
-// active row bands of nframes/8 frames instead of all of them.  Placement is a speed matter only.
-__device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, int* f, int* bx) {
-    const int f8 = (nframes + 7) / 8;
-    const int r = static_cast<int>(blockIdx.x) & 7;
-    const int q = static_cast<int>(blockIdx.x) >> 3;
-    *f = r + 8 * (q % f8);
-    *bx = q / f8;
-    return *f < nframes && *bx < blocks_per_frame;
-}
-
 template <int ROWS, int DW, int HALF>
 struct TilePrefetch {
     static constexpr int PER_LANE = (ROWS * DW + 63) / 64;
@@ -530,7 +518,7 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
     if (radius <= 15 && exact_int != 0 && v.moments != nullptr) {
         const int bpf = static_cast<int>(grid.x);
-        const dim3 grid1d(8 * ((nframes + 7) / 8) * bpf);
+        const dim3 grid1d(frame_grid(nframes, bpf));
         hipLaunchKernelGGL(moments_kernel, grid1d, dim3(256), 0, stream, v, p, v.moments, nframes, bpf, use_visit ? 1 : 0);
         if (ev_after_moments != nullptr) {
             (void)hipEventRecord(ev_after_moments, stream);

@@ -94,14 +94,17 @@ __device__ __forceinline__ uint32_t cardinal_test(us2 c, us2 u, us2 d, us2 l, us
 //           picked with v_perm); about 1 % of the pixels survive and go to an LDS list.
 //  phase 2: the 16-pixel segment test on the survivors, on dense waves.
 // Pixels that fail the pretest can never be corners, so the bitmap is the reference's.
-__global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc) {
+__global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc, int nframes, int tiles_x, int tiles_y) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint16_t survivors[TILE_W * TILE_H];
     __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
     __shared__ int n_survivors;
-    const int tx = blockIdx.x;
-    const int ty = blockIdx.y;
-    const int f = blockIdx.z;
+    int f, tile_id;
+    if (!frame_block(nframes, tiles_x * tiles_y, &f, &tile_id)) {
+        return;
+    }
+    const int ty = tile_id / tiles_x;
+    const int tx = tile_id - ty * tiles_x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
@@ -361,8 +364,10 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
 }  // namespace
 
 void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
-    dim3 grid((v.cols + TILE_W - 1) / TILE_W, (v.rows + TILE_H - 1) / TILE_H, nframes);
-    hipLaunchKernelGGL(fast_detect_kernel, grid, dim3(256), 0, stream, v, p.threshold, p.arc);
+    const int tiles_x = (v.cols + TILE_W - 1) / TILE_W;
+    const int tiles_y = (v.rows + TILE_H - 1) / TILE_H;
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(frame_grid(nframes, tiles_x * tiles_y)), dim3(256), 0, stream, v, p.threshold,
+                       p.arc, nframes, tiles_x, tiles_y);
 }
 
 void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {

@@ -40,15 +40,23 @@ constexpr int EVQ_DEPTH = 24;  // deferred-update queue entries per lane
 // update rule in ascending train order per query, so the result is the sequential scan's.
 template <int WORDS, int QPL>
 __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame,
-                                                    int stride) {
+                                                    int stride, int npairs, int qblocks) {
     __shared__ uint32_t tdesc[TILE * WORDS];
     __shared__ float2 txy[TILE];
     __shared__ uint32_t evq[4][EVQ_DEPTH * 64];  // per wave: entry k of lane l at [k * 64 + l]
-    const int qf = first_query_frame + blockIdx.y;
+    // 1-D grid, pair index fastest: workgroups are dealt to the 8 XCDs round-robin in launch order,
+    // so a grid with the query-block index fastest (8 blocks per pair, the last ones empty) would
+    // leave whole XCDs idle; this way every XCD gets the same mix and the blocks of one pair share
+    // an XCD (and its L2) when npairs is a multiple of 8.
+    const int pair = static_cast<int>(blockIdx.x) % npairs;
+    const int rest = static_cast<int>(blockIdx.x) / npairs;
+    const int qblock = rest % qblocks;
+    const int split = rest / qblocks;
+    const int qf = first_query_frame + pair;
     const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
-    const int block_first = static_cast<int>(blockIdx.x) * TILE * QPL;
+    const int block_first = qblock * TILE * QPL;
     if (block_first >= n1) {
         return;  // whole workgroup idle (uniform)
     }
@@ -78,6 +86,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     }
     constexpr int JB = 4;
     const int lane = threadIdx.x & 63;
+    // the last workgroup of a frame is mostly empty (2087 queries = 4 x 512 + 39): its idle waves skip the scan
+    const bool wave_has_queries = block_first + static_cast<int>(threadIdx.x & ~63u) < n1;
     uint32_t* myq = evq[threadIdx.x >> 6] + lane;
     int qcnt = 0;  // entries in this lane's queue
     // one (query u, train t) pair through the reference's update (feature_matcher.cpp:132-141,
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     };
     // this workgroup scans train chunk blockIdx.z of mv.nsplit (merged in order by emit_kernel)
     const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
-    const int t_begin = static_cast<int>(blockIdx.z) * chunk;
+    const int t_begin = split * chunk;
     const int t_end = min(n2, t_begin + chunk);
     for (int t0 = t_begin; t0 < t_end; t0 += TILE) {
         const int tn = min(TILE, t_end - t0);
@@ -147,6 +157,9 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             txy[threadIdx.x] = make_float2(k.x, k.y);
         }
         __syncthreads();
+        if (!wave_has_queries) {
+            continue;  // wave-uniform: this wave only helps staging the train tiles
+        }
         int j = 0;
         for (; j + JB <= tn; j += JB) {
             // all LDS reads of the group first, then the popcounts
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     for (int u = 0; u < QPL; ++u) {
         const int i = block_first + u * TILE + static_cast<int>(threadIdx.x);
         if (i < n1) {
-            const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + blockIdx.z) * mv.maxK + i;
+            const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + split) * mv.maxK + i;
             mv.best[slot] = make_int2(best[u], best_idx[u]);
             mv.second[slot] = second[u];
         }
@@ -330,9 +343,10 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
 template <int WORDS>
 void launch_words(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame, hipStream_t stream) {
     constexpr int QPL = 2;
-    dim3 grid((mv.maxK + TILE * QPL - 1) / (TILE * QPL), npairs, mv.nsplit);
+    const int qblocks = (mv.maxK + TILE * QPL - 1) / (TILE * QPL);
+    dim3 grid(static_cast<unsigned>(qblocks) * npairs * mv.nsplit);
     hipLaunchKernelGGL((match_kernel<WORDS, QPL>), grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame,
-                       mv.width / 4);
+                       mv.width / 4, npairs, qblocks);
 }
 
 }  // namespace

@@ -121,6 +121,32 @@ inline int grid_x(int items, int per_block, int nframes) {
     return blocks < 1 ? 1 : blocks;
 }
 
+// 1-D grid -> (frame, block-in-frame).  The hardware deals consecutive workgroup ids round-robin
+// over the 8 XCDs, so a 2-D grid whose x extent is a multiple of 8 pins block column k to XCD k
+// (uneven columns then idle whole XCDs).  With 8 or more frames all blocks of a frame land on ONE
+// XCD: its L2 then only holds the active row bands of nframes/8 frames, and the tiles of a frame
+// share their halos there.  With fewer frames the blocks are simply dealt round-robin.
+// Placement is a speed matter only.
+inline unsigned frame_grid(int nframes, int blocks_per_frame) {
+    const int slots = nframes >= 8 ? 8 * ((nframes + 7) / 8) : nframes;
+    return static_cast<unsigned>(slots) * static_cast<unsigned>(blocks_per_frame);
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, int* f, int* bx) {
+    const int id = static_cast<int>(blockIdx.x);
+    if (nframes >= 8) {
+        const int f8 = (nframes + 7) / 8;
+        const int q = id >> 3;
+        *f = (id & 7) + 8 * (q % f8);
+        *bx = q / f8;
+    } else {
+        *f = id % nframes;
+        *bx = id / nframes;
+    }
+    return *f < nframes && *bx < blocks_per_frame;
+}
+#endif
+
 // ---- launchers (each enqueues on `stream`, no synchronization) ----
 void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
 void launch_scan(const BatchView& v, int nframes, hipStream_t stream);
