@@ -417,6 +417,219 @@ __global__ __launch_bounds__(256) void passthrough_kernel(BatchView v) {
 
 constexpr int NMS_PARALLEL_ROUNDS = 2;
 
+// ---------------------------------------------------------------------------------------------
+// Fast path (2 <= window <= GREEDY_MAX_WINDOW and the cell grid fits LDS): the reference's loop
+// itself, one wave per frame, 64 candidates per step.
+//
+// The kept keypoints live in a grid of window x window pixel cells in LDS.  Kept points are at
+// least `window` apart, so a cell holds at most two of them (three points pairwise >= w apart
+// need an enclosing square of side 0.966 w > w - 1 for w <= 29), and everything closer than
+// `window` to a pixel lies in the 3 x 3 cells around it.  A cell is one dword: two entries
+// (oy << 8 | ox, offsets inside the cell), 0x7f7f = empty -- chosen so that an empty entry fails
+// the distance test by itself (|127 - offset| - 2w >= w for w <= 24) and both entries of a cell are
+// tested at once in packed 16-bit arithmetic with no validity branch.
+//
+// Per step the wave takes the next 64 candidates in std::sort order (lane = rank), drops those
+// with a kept point closer than `window` in the grid (exactly the reference's test: for integer
+// coordinates sqrtf(dx^2+dy^2) < float(w) <=> dx^2+dy^2 < w^2), then resolves the survivors among
+// themselves in rank order -- the lowest surviving lane is kept, it knocks out the later lanes
+// closer than `window`, repeat -- and inserts the kept ones into the grid.  That is the
+// sequential loop of feature_detector.cpp:165-185 with 64-wide steps; its cost is ~15 wave
+// instructions per candidate, against thousands of gathered loads for the dependency-round form.
+constexpr int GREEDY_MAX_WINDOW = 24;
+constexpr int GREEDY_LDS_BUDGET = 150 * 1024;
+constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+
+extern __shared__ uint32_t nms_grid[];
+
+__global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic, int tab_mask) {
+    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t carry;
+    __shared__ int kept_total;
+    const int f = blockIdx.x;
+    const int n = v.n_cand[f];
+    if (n == 0) {
+        return;  // scan_kernel already set n_kp = 0
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t* __restrict__ sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
+    const uint32_t* __restrict__ sorted_xy = v.keys + static_cast<size_t>(f) * v.maxM;  // left there by sort_kernel
+    uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;
+    uint32_t* slot_of = v.rank_of + static_cast<size_t>(f) * v.maxM;  // rank_of is not needed on this path
+    slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    for (int i = threadIdx.x; i < gx2 * gy2; i += 256) {
+        nms_grid[i] = CELL_EMPTY;
+    }
+    // occupancy counters of the survivors of the current step, hashed by cell index (see below)
+    uint32_t* tab = nms_grid + gx2 * gy2;
+    for (int i = threadIdx.x; i <= tab_mask; i += 256) {
+        tab[i] = 0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int w = window;
+        const int w2 = w * w;
+        const u2 W2 = {static_cast<unsigned short>(w2), static_cast<unsigned short>(w2)};
+        int count = 0;
+        bool grid_overflow = false;
+        const int nchunks = (n + 63) / 64;
+        // software pipeline: the loads of chunk k+2 are in flight while chunk k is processed
+        uint32_t key_a = lane < n ? sorted[lane] : 0u;
+        uint32_t xy_a = lane < n ? sorted_xy[lane] : 0u;
+        uint32_t key_b = 64 + lane < n ? sorted[64 + lane] : 0u;
+        uint32_t xy_b = 64 + lane < n ? sorted_xy[64 + lane] : 0u;
+        for (int k = 0; k < nchunks; ++k) {
+            const int r = k * 64 + lane;
+            const int r2 = r + 128;
+            const uint32_t key_c = r2 < n ? sorted[r2] : 0u;
+            const uint32_t xy_c = r2 < n ? sorted_xy[r2] : 0u;
+            const bool valid = r < n;
+            const uint32_t key = key_a;
+            const int x = static_cast<int>(xy_a & 0xffffu);
+            const int y = static_cast<int>(xy_a >> 16);
+            const int cx = static_cast<int>(__umulhi(static_cast<uint32_t>(x), magic));  // x / w (exact below 65536)
+            const int cy = static_cast<int>(__umulhi(static_cast<uint32_t>(y), magic));
+            const int xr = x - cx * w;
+            const int yr = y - cy * w;
+            const uint32_t* cell = nms_grid + (cy + 1) * gx2 + (cx + 1);  // the grid has a one-cell empty rim
+            // 3 x 3 cells, two entries per cell at once
+            u2 hit = {0, 0};
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+                const short yj = static_cast<short>(yr - j * w);
+                const s2 YR = {yj, yj};
+#pragma unroll
+                for (int i = -1; i <= 1; ++i) {
+                    const uint32_t word = cell[j * gx2 + i];
+                    const short xi = static_cast<short>(xr - i * w);
+                    const s2 XR = {xi, xi};
+                    const s2 OX = __builtin_bit_cast(s2, word & 0x00ff00ffu);
+                    const s2 OY = __builtin_bit_cast(s2, (word >> 8) & 0x00ff00ffu);
+                    const s2 DX = XR - OX;
+                    const s2 DY = YR - OY;
+                    const u2 D2 = __builtin_bit_cast(u2, DX * DX + DY * DY);  // <= 2 * 175^2 < 65536
+                    hit |= __builtin_elementwise_sub_sat(W2, D2);             // non-zero <=> d^2 < w^2
+                }
+            }
+            bool alive = valid && __builtin_bit_cast(uint32_t, hit) == 0u;
+            // Survivors among themselves.  Two survivors can only interact when they sit in
+            // neighbouring cells, which is rare for 64 candidates on ~10^4 cells: every survivor
+            // counts itself into a table slot hashed from its cell and sums the slots of its
+            // 3 x 3 cells; a sum of 1 means no other survivor is near (a hash collision only makes
+            // a lonely one look crowded), so it is kept without entering the rank-order loop.
+            const int cidx = (cy + 1) * gx2 + (cx + 1);
+            if (alive) {
+                atomicAdd(&tab[cidx & tab_mask], 1u);
+            }
+            uint32_t crowd = 0;
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+#pragma unroll
+                for (int i = -1; i <= 1; ++i) {
+                    crowd += tab[(cidx + j * gx2 + i) & tab_mask];
+                }
+            }
+            const bool lonely = alive && crowd == 1u;
+            if (alive) {
+                tab[cidx & tab_mask] = 0;
+            }
+            unsigned long long kept = __ballot(lonely);
+            alive = alive && !lonely;
+            // the rest in rank (= lane) order
+            unsigned long long a = __ballot(alive);
+            while (a != 0) {
+                const int l0 = __ffsll(static_cast<long long>(a)) - 1;
+                kept |= 1ull << l0;
+                const int dx = x - __builtin_amdgcn_readlane(x, l0);
+                const int dy = y - __builtin_amdgcn_readlane(y, l0);
+                alive = alive && dx * dx + dy * dy >= w2;  // clears lane l0 itself too
+                a = __ballot(alive);
+            }
+            const bool mine = (kept >> lane) & 1ull;
+            if (mine) {
+                const uint32_t entry = static_cast<uint32_t>((yr << 8) | xr);
+                uint32_t* c = nms_grid + (cy + 1) * gx2 + (cx + 1);
+                const uint32_t old = atomicCAS(c, CELL_EMPTY, (CELL_EMPTY & 0xffff0000u) | entry);
+                if (old != CELL_EMPTY) {
+                    // first slot taken (now or in an earlier step): the second one must be free
+                    const uint32_t prev = atomicXor(c, (0x7f7fu ^ entry) << 16);
+                    grid_overflow = grid_overflow || (prev >> 16) != 0x7f7fu;
+                }
+                const int pos = count + __popcll(kept & low_mask(lane));
+                if (pos < v.maxK) {
+                    slamx_keypoint kp;
+                    kp.x = static_cast<float>(x);
+                    kp.y = static_cast<float>(y);
+                    kp.size = 6.0f;  // constants::DEFAULT_KEYPOINT_SIZE
+                    kp.angle = 0.0f;
+                    kp.response = static_cast<float>(key >> SCORE_SHIFT);
+                    kps[pos] = kp;
+                    slot_of[key & INDEX_MASK] = static_cast<uint32_t>(pos);
+                }
+            }
+            if (valid) {
+                state[key & INDEX_MASK] = mine ? NMS_KEPT : NMS_SUPPRESSED;
+            }
+            count += __popcll(kept);
+            key_a = key_b;
+            key_b = key_c;
+            xy_a = xy_b;
+            xy_b = xy_c;
+        }
+        if (__ballot(grid_overflow) != 0 && lane == 0) {
+            atomicOr(&v.status[f], STATUS_KP_OVERFLOW);  // cannot happen for window <= GREEDY_MAX_WINDOW; fail loudly
+        }
+        if (lane == 0) {
+            kept_total = count;
+            carry = 0;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int total_kept = kept_total;
+    // raster-order visiting list for the describe kernels (see nms_finish_kernel)
+    if (total_kept <= v.maxK) {
+        uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+        for (int base = 0; base < n; base += 256) {
+            const int i = base + threadIdx.x;
+            const bool keep = i < n && state[i] == NMS_KEPT;
+            const unsigned long long bm = __ballot(keep);
+            const uint32_t c = static_cast<uint32_t>(__popcll(bm));
+            if (lane == 0) {
+                wave_sums[wave] = c;
+            }
+            __syncthreads();
+            uint32_t wbase = carry;
+            for (int q = 0; q < wave; ++q) {
+                wbase += wave_sums[q];
+            }
+            if (keep) {
+                visit[wbase + static_cast<uint32_t>(__popcll(bm & low_mask(lane)))] = slot_of[i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) {
+                carry = wbase + c;
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        int total = total_kept;
+        if (total > v.maxK) {
+            atomicOr(&v.status[f], STATUS_KP_OVERFLOW);
+            total = 0;
+        }
+        if ((v.status[f] & STATUS_KP_OVERFLOW) != 0) {
+            total = 0;
+        }
+        v.n_kp[f] = total;
+    }
+}
+
 }  // namespace
 
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid) {
@@ -424,6 +637,30 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
                               true);
     (void)once;
+    if (p.window >= 2 && p.window <= GREEDY_MAX_WINDOW) {
+        const int gx2 = (v.cols + p.window - 1) / p.window + 2;
+        const int gy2 = (v.rows + p.window - 1) / p.window + 2;
+        const size_t bytes = static_cast<size_t>(gx2) * gy2 * sizeof(uint32_t);
+        if (bytes + 1024 <= static_cast<size_t>(GREEDY_LDS_BUDGET)) {
+            static const bool once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, GREEDY_LDS_BUDGET),
+                                       true);
+            (void)once2;
+            const uint32_t magic = static_cast<uint32_t>(((1ull << 32) + p.window - 1) / p.window);
+            // the hashed survivor table takes what is left of the LDS budget (a power of two of dwords)
+            int tab_entries = 256;
+            while (tab_entries < 16384 && bytes + static_cast<size_t>(tab_entries) * 8 <= static_cast<size_t>(GREEDY_LDS_BUDGET)) {
+                tab_entries *= 2;
+            }
+            const size_t total = bytes + static_cast<size_t>(tab_entries) * 4;
+            hipLaunchKernelGGL(nms_greedy_kernel, dim3(nframes), dim3(256), total, stream, v, p.window, gx2, gy2, magic,
+                               tab_entries - 1);
+            if (ev_mid != nullptr) {
+                (void)hipEventRecord(ev_mid, stream);
+            }
+            return;
+        }
+    }
     dim3 grid(grid_x(v.maxM, 256, nframes), nframes);
     hipLaunchKernelGGL(nms_build_kernel, grid, dim3(256), 0, stream, v, p.window);
     if (ev_mid != nullptr) {

@@ -744,9 +744,31 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds
     uint32_t* gsegbits = reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
     int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
     const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh);
+    // by-products for the NMS: the inverse permutation, and (x,y) in sorted order -- written over
+    // the unsorted keys, which are dead from here on -- so that the greedy NMS streams its input
     uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
-    for (int r = threadIdx.x; r < n; r += blockDim.x) {
-        rank_of[out[r] & INDEX_MASK] = static_cast<uint32_t>(r);
+    const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
+    __syncthreads();
+    constexpr int U = 4;  // independent gathers in flight per thread
+    for (int r0 = threadIdx.x; r0 < n; r0 += U * SORT_THREADS) {
+        uint32_t idx[U], pxy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * SORT_THREADS;
+            idx[u] = r < n ? out[r] & INDEX_MASK : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pxy[u] = xy[idx[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * SORT_THREADS;
+            if (r < n) {
+                rank_of[idx[u]] = static_cast<uint32_t>(r);
+                gkeys[r] = pxy[u];
+            }
+        }
     }
     if (threadIdx.x == 0 && st != 0) {
         atomicOr(&v.status[f], st);
