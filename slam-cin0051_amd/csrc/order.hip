@@ -297,6 +297,132 @@ __device__ int wave_partition(uint32_t* a, int first, int last, int lane, uint8_
     return cut;
 }
 
+// ---------------- one wave: a segment of at most 64 elements, all its remaining levels ----------------
+// Lane i holds element first+i in a register; the sub-segments of a level are disjoint lane ranges
+// and advance together (median of three by shuffles, stopper ranks by ballots restricted to the
+// lane's own range, the closed-form swap rule of block_partition, partners found through the
+// wave's LDS rank scratch).  Replaces one wave_partition call per sub-segment -- thousands of
+// nearly empty waves at the deep levels -- by ~4 short steps per 64 elements.
+__device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth, int lane, uint8_t (*sel)[64],
+                                     uint32_t* segbits, int bit_base) {
+    const int m = last - first;  // 17 .. 64
+    uint32_t v = lane < m ? a[first + lane] : 0u;
+    int lo = lane < m ? 0 : lane;  // my sub-segment [lo, hi), relative to first; lanes beyond m own nothing
+    int hi = lane < m ? m : lane;
+    int dep = depth;
+    while (true) {
+        const bool active = hi - lo > SORT_LEAF;
+        if (__ballot(active) == 0) {
+            break;
+        }
+        if (__ballot(active && dep == 0) != 0) {
+            // depth limit: __partial_sort(first, last, last) = heapsort, by the first lane of the range
+            wave_mem_fence();
+            if (lane < m) {
+                a[first + lane] = v;
+            }
+            wave_mem_fence();
+            const bool mine = active && dep == 0;
+            if (mine && lane == lo) {
+                heap_sort_(a + first + lo, hi - lo);
+            }
+            wave_mem_fence();
+            if (mine) {
+                const int bit = bit_base + first + lane;  // sorted now: every element is its own leaf
+                atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+                lo = lane;
+                hi = lane;
+            }
+            if (lane < m) {
+                v = a[first + lane];
+            }
+            wave_mem_fence();
+            continue;
+        }
+        // __move_median_to_first(lo, lo+1, mid, hi-1)
+        const int ia = lo + 1;
+        const int ib = lo + (hi - lo) / 2;
+        const int ic = hi - 1;
+        const uint32_t vf = __shfl(v, lo);
+        const uint32_t va = __shfl(v, ia);
+        const uint32_t vb = __shfl(v, ib);
+        const uint32_t vc = __shfl(v, ic);
+        int im;
+        uint32_t vm;
+        if (comp(va, vb)) {
+            if (comp(vb, vc)) {
+                im = ib, vm = vb;
+            } else if (comp(va, vc)) {
+                im = ic, vm = vc;
+            } else {
+                im = ia, vm = va;
+            }
+        } else if (comp(va, vc)) {
+            im = ia, vm = va;
+        } else if (comp(vb, vc)) {
+            im = ic, vm = vc;
+        } else {
+            im = ib, vm = vb;
+        }
+        if (active) {
+            if (lane == lo) {
+                v = vm;
+            } else if (lane == im) {
+                v = vf;
+            }
+        }
+        const uint32_t p = score_of(vm);
+        // __unguarded_partition(lo+1, hi, pivot at lo), closed form (see block_partition)
+        const bool in = active && lane > lo;
+        const bool is_l = in && score_of(v) <= p;
+        const bool is_r = in && score_of(v) >= p;
+        const unsigned long long range = low_mask(hi) & ~low_mask(lo + 1);
+        const unsigned long long ls = __ballot(is_l) & range;
+        const unsigned long long rs = __ballot(is_r) & range;
+        const int l_left = __popcll(ls & low_mask(lane));        // L stoppers of my range left of me
+        const int r_right = __popcll(rs & ~low_mask(lane + 1));  // R stoppers of my range right of me
+        const bool swap_l = is_l && r_right >= l_left + 1;
+        const bool swap_r = is_r && l_left >= r_right + 1;
+        if (swap_l) {
+            sel[0][lo + l_left] = static_cast<uint8_t>(lane);
+        }
+        if (swap_r) {
+            sel[1][lo + r_right] = static_cast<uint8_t>(lane);
+        }
+        wave_mem_fence();
+        int partner = lane;
+        if (swap_l) {
+            partner = sel[1][lo + l_left];
+        } else if (swap_r) {
+            partner = sel[0][lo + r_right];
+        }
+        wave_mem_fence();
+        v = __shfl(v, partner);
+        const unsigned long long stay_l = __ballot(is_l && !swap_l) & range;
+        const unsigned long long moved_r = __ballot(swap_r) & range;
+        const int cut_l = stay_l != 0 ? __ffsll(static_cast<long long>(stay_l)) - 1 : 64;
+        const int cut_r = moved_r != 0 ? __ffsll(static_cast<long long>(moved_r)) - 1 : 64;
+        const int cut = min(cut_l, cut_r);
+        if (active) {
+            if (lane == lo) {
+                const int bit = bit_base + first + cut;
+                atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+            }
+            if (lane < cut) {
+                hi = cut;
+            } else {
+                lo = cut;
+            }
+            dep -= 1;
+        }
+    }
+    wave_mem_fence();
+    if (lane < m) {
+        a[first + lane] = v;
+    }
+    wave_mem_fence();
+}
+
 // ---------------- whole workgroup: pivot + Hoare partition of a LARGE segment ----------------
 // Same closed form as wave_partition (L_k / R_k stoppers over ORIGINAL values, swap while
 // L_k < R_k, cut = min(L_K, R_{K-1})), evaluated with two block-wide passes: every wave owns a
@@ -528,6 +654,10 @@ __device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int de
                     const int bit = bit_base + i;
                     atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
                 }
+                continue;
+            }
+            if (last - first <= 64) {
+                wave_small_introsort(a, first, last, depth, lane, sh.sel[wave], segbits, bit_base);
                 continue;
             }
             const int cut = wave_partition(a, first, last, lane, sh.sel[wave]);
