@@ -17,10 +17,10 @@
 //   (1) The Hoare partition's scans only ever test ORIGINAL values: the k-th stop of the left
 //       scan is the k-th element (from the left) with !(a > p) and the k-th stop of the right
 //       scan is the k-th element (from the right) with !(p > a); pairs are swapped while
-//       L_k < R_k and cut = min(L_{K+1}, R_K).  A wave therefore consumes the range from both
-//       ends in 64-element chunks, finds the stoppers with ballots, pairs the k-th lowest left
-//       stopper with the k-th highest right stopper with a select-kth on the ballot masks, and
-//       finishes the crossing inside one chunk.  Same swaps, same cut as the sequential loop.
+//       L_k < R_k and cut = min(L_{K+1}, R_K).  So an L stopper of rank k is swapped iff at least
+//       k+1 R stoppers lie to its right (symmetrically for R), which ballots and running counts
+//       decide for every element at once; the swapped positions are listed by rank and
+//       exchanged.  Same swaps, same cut as the sequential loop.
 //   (2) Every partition leaves left >= pivot >= right, so leaf segments (<= 16 elements) are
 //       totally ordered among themselves and the final insertion sort -- a stable sort --
 //       never moves an element across a leaf boundary: it is a stable sort INSIDE each leaf,
@@ -33,6 +33,7 @@
 // neighbour is SUPPRESSED, SUPPRESSED once one is KEPT), with neighbours enumerated from the
 // FAST corner bitmap + its prefix sums (fast.hip) instead of a cell grid.
 #include "slamx_internal.h"
+#include <cstdlib>
 
 namespace slamx {
 
@@ -112,29 +113,20 @@ struct SortShared {
     uint32_t pivot;
     int2 big[2][32];  // large segments of the current / next level (n <= 24576 keys => at most 12)
     int n_big[2];
-    uint8_t sel[16][2][64];  // per wave: lane of the k-th lowest L stopper / k-th highest R stopper
+    uint8_t sel[16][2][64];  // per wave (wave_small_introsort): lane of the k-th swapped L / R stopper of a range
 };
 
-// k-th set bit of a ballot mask, for every k at once: each flagged lane stores its own id at its
-// rank (bottom-up for `lo`, top-down for `hi`) in the wave's LDS scratch.  Replaces a 30-instruction
-// bit-bisection per query by two LDS operations.
 __device__ __forceinline__ int rank_below(unsigned long long m) {  // set bits of m below this lane
     return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
 }
-__device__ __forceinline__ void scatter_ranks(uint8_t (*sel)[64], unsigned long long lo_mask, unsigned long long hi_mask, int lane) {
-    if ((lo_mask >> lane) & 1ull) {
-        sel[0][rank_below(lo_mask)] = static_cast<uint8_t>(lane);
-    }
-    if ((hi_mask >> lane) & 1ull) {
-        sel[1][__popcll(hi_mask) - 1 - rank_below(hi_mask)] = static_cast<uint8_t>(lane);
-    }
-}
 
-// ---------------- one wave: pivot + Hoare partition of [first,last), last-first > 16 ----------------
-// returns cut (wave-uniform).  a may point to LDS or global memory.
-__device__ int wave_partition(uint32_t* a, int first, int last, int lane, uint8_t (*sel)[64]) {
-    // __move_median_to_first(first, first+1, mid, last-1)
+// ---------------- one wave: pivot + Hoare partition, closed form ----------------
+// The same rule as block_partition evaluated by a single wave over its whole segment: no step
+// depends on an LDS result of the previous one (only on running counts), so the chunk loads
+// pipeline -- the two-ended chunk walk of wave_partition is a chain of dependent LDS round trips.
+// scr: last-first 16-bit entries of LDS private to the segment.
+__device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last, int lane) {
     const int ia = first + 1;
     const int ib = first + (last - first) / 2;
     const int ic = last - 1;
@@ -166,135 +158,65 @@ __device__ int wave_partition(uint32_t* a, int first, int last, int lane, uint8_
     }
     wave_mem_fence();
     const uint32_t p = score_of(vm);
-
-    int li = first + 1;  // unread range [li, rj)
-    int rj = last;
-    unsigned long long Lm = 0;  // pending left stoppers  (score <= p), bit = lane of last left chunk
-    unsigned long long Rm = 0;  // pending right stoppers (score >= p), bit = lane of last right chunk
-    int lb = li, rb = rj;       // bases of the last chunks
-    int nl = 0, nr = 0;         // their lengths
-    uint32_t vl = 0, vr = 0;    // their ORIGINAL values, one per lane
-
-    while (true) {
-        if (Lm == 0 && li < rj) {
-            nl = min(64, rj - li);
-            lb = li;
-            vl = lane < nl ? a[lb + lane] : 0u;
-            Lm = __ballot(lane < nl && score_of(vl) <= p);
-            li += nl;
+    const int lo = first + 1;
+    const int hi = last;
+    const int n = hi - lo;
+    // pass 1: number of right stoppers
+    int nr = 0;
+#pragma unroll 4
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        nr += __popcll(__ballot(i < hi && score_of(a[min(i, hi - 1)]) >= p));
+    }
+    // pass 2: classify, list the swapped positions by rank
+    uint16_t* lpos = scr;
+    uint16_t* rpos = scr + n / 2;
+    int run_l = 0, run_r = 0, K = 0;
+    int cut_l = 0x7fffffff, cut_r = 0x7fffffff;
+#pragma unroll 2
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < hi;
+        const uint32_t sc = score_of(a[min(i, hi - 1)]);
+        const bool is_l = in && sc <= p;
+        const bool is_r = in && sc >= p;
+        const unsigned long long ml = __ballot(is_l);
+        const unsigned long long mr = __ballot(is_r);
+        const int l_left = run_l + rank_below(ml);                                  // L stoppers left of i
+        const int r_right = nr - (run_r + rank_below(mr) + (is_r ? 1 : 0));        // R stoppers right of i
+        const bool swap_l = is_l && r_right >= l_left + 1;
+        const bool swap_r = is_r && l_left >= r_right + 1;
+        if (swap_l) {
+            lpos[l_left] = static_cast<uint16_t>(i - first);
         }
-        if (Rm == 0 && li < rj) {
-            nr = min(64, rj - li);
-            rb = rj - nr;
-            vr = lane < nr ? a[rb + lane] : 0u;
-            Rm = __ballot(lane < nr && score_of(vr) >= p);
-            rj -= nr;
+        if (swap_r) {
+            rpos[r_right] = static_cast<uint16_t>(i - first);
         }
-        if (Lm == 0 || Rm == 0) {
-            if (li >= rj) {
-                break;
-            }
-            continue;
+        const unsigned long long sl = __ballot(swap_l);
+        const unsigned long long stay = ml & ~sl;
+        const unsigned long long moved = __ballot(swap_r);
+        K += __popcll(sl);
+        if (stay != 0 && cut_l == 0x7fffffff) {
+            cut_l = base + __ffsll(static_cast<long long>(stay)) - 1;
         }
-        const int c = min(__popcll(Lm), __popcll(Rm));
-        const int k = lane < c ? lane : c - 1;
-        scatter_ranks(sel, Lm, Rm, lane);
-        wave_mem_fence();
-        const int pl = sel[0][k];  // k-th lowest left stopper
-        const int pr = sel[1][k];  // k-th highest right stopper
-        wave_mem_fence();
-        const uint32_t xl = __shfl(vl, pl);
-        const uint32_t xr = __shfl(vr, pr);
-        if (lane < c) {
-            a[lb + pl] = xr;
-            a[rb + pr] = xl;
+        if (moved != 0 && cut_r == 0x7fffffff) {
+            cut_r = base + __ffsll(static_cast<long long>(moved)) - 1;
         }
-        // drop the c lowest left stoppers and the c highest right stoppers
-        const int plast = __builtin_amdgcn_readlane(pl, 63);  // lanes >= c hold entry c-1
-        const int rlast = __builtin_amdgcn_readlane(pr, 63);
-        Lm &= ~low_mask(plast + 1);
-        Rm &= low_mask(rlast);
+        run_l += __popcll(ml);
+        run_r += __popcll(mr);
     }
     wave_mem_fence();
-
-    int cut;
-    if (Lm != 0) {
-        // case A: unpaired left stoppers remain in the last left chunk [lb, lb+nl); every
-        // position >= lb+nl has been consumed by right chunks.  The right scan continues
-        // downward inside this chunk over original values.
-        const int lstar = __ffsll(static_cast<long long>(Lm)) - 1;
-        const unsigned long long Rw = __ballot(lane < nl && lane >= lstar && score_of(vl) >= p);
-        const int cl = __popcll(Lm);
-        const int cr = __popcll(Rw);
-        const int cmax = min(cl, cr);
-        int pl = 0, pr = 0;
-        bool ok = false;
-        scatter_ranks(sel, Lm, Rw, lane);
-        wave_mem_fence();
-        if (lane < cmax) {
-            pl = sel[0][lane];
-            pr = sel[1][lane];
-            ok = pl < pr;
-        }
-        const unsigned long long okm = __ballot(ok);
-        const int K = __popcll(okm);  // ok is a prefix property
-        const int k = lane < K ? lane : 0;
-        const int spl = __shfl(pl, k);
-        const int spr = __shfl(pr, k);
-        const uint32_t xl = __shfl(vl, spl);
-        const uint32_t xr = __shfl(vl, spr);
-        if (lane < K) {
-            a[lb + spl] = xr;
-            a[lb + spr] = xl;
-        }
-        cut = lb + nl;  // first position of the right-consumed territory (or `last`)
-        if (cl > K) {
-            cut = min(cut, lb + static_cast<int>(sel[0][K]));
-        }
-        if (K >= 1) {
-            cut = min(cut, lb + static_cast<int>(sel[1][K - 1]));
-        }
-    } else if (Rm != 0) {
-        // case B: unpaired right stoppers remain in the last right chunk [rb, rb+nr); the left
-        // scan continues upward inside this chunk over original values.
-        const int rstar = 63 - __clzll(static_cast<long long>(Rm));
-        const unsigned long long Lw = __ballot(lane < nr && lane <= rstar && score_of(vr) <= p);
-        const int cl = __popcll(Lw);
-        const int cr = __popcll(Rm);
-        const int cmax = min(cl, cr);
-        int pl = 0, pr = 0;
-        bool ok = false;
-        scatter_ranks(sel, Lw, Rm, lane);
-        wave_mem_fence();
-        if (lane < cmax) {
-            pl = sel[0][lane];
-            pr = sel[1][lane];
-            ok = pl < pr;
-        }
-        const unsigned long long okm = __ballot(ok);
-        const int K = __popcll(okm);
-        const int k = lane < K ? lane : 0;
-        const int spl = __shfl(pl, k);
-        const int spr = __shfl(pr, k);
-        const uint32_t xl = __shfl(vr, spl);
-        const uint32_t xr = __shfl(vr, spr);
-        if (lane < K) {
-            a[rb + spl] = xr;
-            a[rb + spr] = xl;
-        }
-        cut = rb + rstar + 1;  // everything above r* is already a stopper for the left scan
-        if (cl > K) {
-            cut = min(cut, rb + static_cast<int>(sel[0][K]));
-        }
-        if (K >= 1) {
-            cut = min(cut, rb + static_cast<int>(sel[1][K - 1]));
-        }
-    } else {
-        // case C: both queues drained exactly at the meeting point
-        cut = rj;
+    // pass 3: exchange the K pairs
+    for (int k = lane; k < K; k += 64) {
+        const int i = first + lpos[k];
+        const int j = first + rpos[k];
+        const uint32_t vi = a[i];
+        const uint32_t vj = a[j];
+        a[i] = vj;
+        a[j] = vi;
     }
     wave_mem_fence();
-    return cut;
+    return min(cut_l, cut_r);
 }
 
 // ---------------- one wave: a segment of at most 64 elements, all its remaining levels ----------------
@@ -428,8 +350,10 @@ __device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth
 // L_k < R_k, cut = min(L_K, R_{K-1})), evaluated with two block-wide passes: every wave owns a
 // contiguous slice, ballots give the stopper ranks, an L stopper of 0-based rank k is swapped iff
 // at least k+1 R stoppers lie to its right (and symmetrically), swapped positions are listed by
-// rank in `scratch` and exchanged in a third pass.  scratch: >= (last-first) words, global.
-__device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int last, SortShared& sh) {
+// rank in `scratch` (relative to `first`) and exchanged in a third pass.  scratch: last-first entries,
+// 16-bit in LDS for LDS-resident segments, 32-bit global otherwise.
+template <typename PosT>
+__device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -493,8 +417,8 @@ __device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int la
         l_before += w < wave ? sh.wave_l[w] : 0u;
         r_after += w > wave ? sh.wave_r[w] : 0u;
     }
-    uint32_t* lpos = scratch;
-    uint32_t* rpos = scratch + (n / 2 + 1);
+    PosT* lpos = scratch;  // positions relative to `first`; K <= (n - 1) / 2 pairs: both lists fit n entries
+    PosT* rpos = scratch + n / 2;
     // pass 2: classify
     uint32_t run_l = 0, run_r = 0;  // stoppers of this slice in earlier steps
     int my_swaps = 0;
@@ -514,8 +438,8 @@ __device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int la
         const uint32_t r_right = r_after + (nr - r_le);  // R at positions > i
         if (is_l) {
             // 0-based rank l_left; partner R_{l_left} exists to the right iff r_right >= l_left + 1
-            if (r_right >= l_left + 1u && l_left < static_cast<uint32_t>(n / 2 + 1)) {
-                lpos[l_left] = static_cast<uint32_t>(i);
+            if (r_right >= l_left + 1u) {
+                lpos[l_left] = static_cast<PosT>(i - first);
                 ++my_swaps;
             } else {
                 min_unswapped_l = min(min_unswapped_l, i);
@@ -523,8 +447,8 @@ __device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int la
         }
         if (is_r) {
             // 0-based rank from the right r_right; partner L_{r_right} lies to the left iff l_left >= r_right + 1
-            if (l_left >= r_right + 1u && r_right < static_cast<uint32_t>(n / 2 + 1)) {
-                rpos[r_right] = static_cast<uint32_t>(i);
+            if (l_left >= r_right + 1u) {
+                rpos[r_right] = static_cast<PosT>(i - first);
                 min_swapped_r = min(min_swapped_r, i);
             }
         }
@@ -548,8 +472,8 @@ __device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int la
     const int K = sh.n_swap;
     // pass 3: exchange the K pairs
     for (int k = tid; k < K; k += blockDim.x) {
-        const uint32_t i = lpos[k];
-        const uint32_t j = rpos[k];
+        const int i = first + static_cast<int>(lpos[k]);
+        const int j = first + static_cast<int>(rpos[k]);
         const uint32_t vi = a[i];
         const uint32_t vj = a[j];
         a[i] = vj;
@@ -561,12 +485,12 @@ __device__ int block_partition(uint32_t* a, uint32_t* scratch, int first, int la
     return cut;
 }
 
-constexpr int SORT_BLOCK_MIN = 2048;  // segments at least this long are partitioned by the whole workgroup
+__device__ int SORT_BLOCK_MIN = 2048;  // segments at least this long are partitioned by the whole workgroup
 
 // The introsort loop of std::sort on a[0, len) (LDS or global), level by level: large segments by
 // the whole workgroup one after another, the rest one wave per segment.  Leaf boundaries are
 // recorded in segbits at bit (bit_base + position).  lists: two arrays of maxSeg int2 (global).
-__device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int depth, uint32_t* segbits, int bit_base,
+__device__ void introsort_levels(uint32_t* a, uint16_t* scr16, int len, int depth, uint32_t* segbits, int bit_base,
                                  int2* lists, int maxSeg, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -634,7 +558,7 @@ __device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int de
                 }
                 continue;
             }
-            const int cut = block_partition(a, scratch, seg.x, seg.y, sh);
+            const int cut = block_partition(a, scr16 + seg.x, seg.x, seg.y, sh);
             if (tid == 0) {
                 emit_children(seg.x, cut, seg.y);
             }
@@ -660,7 +584,7 @@ __device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int de
                 wave_small_introsort(a, first, last, depth, lane, sh.sel[wave], segbits, bit_base);
                 continue;
             }
-            const int cut = wave_partition(a, first, last, lane, sh.sel[wave]);
+            const int cut = wave_partition_cf(a, scr16 + first, first, last, lane);
             if (lane == 0) {
                 emit_children(first, cut, last);
             }
@@ -687,11 +611,16 @@ __device__ void introsort_levels(uint32_t* a, uint32_t* scratch, int len, int de
 //   lists    : 3 * maxSeg int2 (global): two level lists + the list of LDS-sized segments
 // Segments longer than lds_keys are partitioned in global memory by the whole workgroup until
 // they fit; every remaining segment is then sorted in LDS.  Returns 0 or STATUS_SEG_OVERFLOW.
+constexpr int TAIL_DONE = 1 << 30;  // returned with the status: sorted (x,y) and rank_of already written
+
 __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* gsegbits,
-                               int2* lists, int maxSeg, int n, SortShared& sh) {
+                               int2* lists, int maxSeg, int n, SortShared& sh, const uint32_t* xy = nullptr,
+                               uint32_t* rank_of = nullptr) {
+    const bool all_in_lds = n <= lds_keys;
     const int tid = threadIdx.x;
     const int nwords = (n + 32) / 32;  // bits 0..n
     uint32_t* segbits = nwords <= lds_keys / 32 + 2 ? lds + lds_keys : gsegbits;
+    uint16_t* scr16 = reinterpret_cast<uint16_t*>(lds + lds_keys + lds_keys / 32 + 2);  // lds_keys entries
     for (int i = tid; i < nwords; i += blockDim.x) {
         uint32_t wbits = 0;
         if (i == 0) {
@@ -801,17 +730,28 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
             lds[i] = gkeys[first + i];
         }
         __syncthreads();
-        introsort_levels(lds, out, len, depth, segbits, first, lists, maxSeg, sh);
-        for (int i = tid; i < len; i += blockDim.x) {
-            gkeys[first + i] = lds[i];
+        introsort_levels(lds, scr16, len, depth, segbits, first, lists, maxSeg, sh);
+        if (!all_in_lds) {
+            for (int i = tid; i < len; i += blockDim.x) {
+                gkeys[first + i] = lds[i];
+            }
         }
         __threadfence_block();
         __syncthreads();
     }
+    if (all_in_lds && n_ready == 0) {  // n <= 16: a single leaf, no level ran
+        for (int i = tid; i < n; i += blockDim.x) {
+            lds[i] = gkeys[i];
+        }
+    }
     const int overflow = sh.counters[2];
     __syncthreads();
-    // __final_insertion_sort == stable sort inside each leaf: rank counting, one lane per element
-    const uint32_t* a = gkeys;
+    // __final_insertion_sort == stable sort inside each leaf: rank counting, one lane per element.
+    // When the whole array sat in LDS the keys are read from there and the by-products for the NMS
+    // (inverse permutation; (x,y) in sorted order, written over the now dead unsorted keys) are
+    // produced on the way -- the gather of (x,y) is in flight while the rank is counted.
+    const uint32_t* a = all_in_lds ? lds : gkeys;
+    const bool fuse_tail = all_in_lds && xy != nullptr;
     for (int i = tid; i < n; i += blockDim.x) {
         // leaf start s: highest flag <= i; leaf end e: lowest flag > i (flags 0 and n always set)
         int wi = i >> 5;
@@ -827,6 +767,7 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
         }
         const int e = wi * 32 + (__ffs(wbits) - 1);
         const uint32_t me = a[i];
+        const uint32_t pxy = fuse_tail ? xy[me & INDEX_MASK] : 0u;
         const uint32_t sc = score_of(me);
         int pos = s;
         for (int j = s; j < e; ++j) {
@@ -834,10 +775,14 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
             pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
         }
         out[pos] = me;
+        if (fuse_tail) {
+            gkeys[pos] = pxy;
+            rank_of[me & INDEX_MASK] = static_cast<uint32_t>(pos);
+        }
     }
     __threadfence_block();
     __syncthreads();
-    return overflow != 0 ? STATUS_SEG_OVERFLOW : 0;
+    return (overflow != 0 ? STATUS_SEG_OVERFLOW : 0) | (fuse_tail ? TAIL_DONE : 0);
 }
 
 extern __shared__ uint32_t dyn_lds[];
@@ -855,14 +800,16 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds
     uint32_t* out = v.sorted + static_cast<size_t>(f) * v.maxM;
     uint32_t* gsegbits = reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
     int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
-    const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh);
     // by-products for the NMS: the inverse permutation, and (x,y) in sorted order -- written over
-    // the unsorted keys, which are dead from here on -- so that the greedy NMS streams its input
+    // the unsorted keys, which are dead once sorted -- so that the greedy NMS streams its input
     uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
     const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
+    int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, xy, rank_of);
+    const bool tail_done = (st & TAIL_DONE) != 0;
+    st &= ~TAIL_DONE;
     __syncthreads();
     constexpr int U = 4;  // independent gathers in flight per thread
-    for (int r0 = threadIdx.x; r0 < n; r0 += U * SORT_THREADS) {
+    for (int r0 = threadIdx.x; r0 < n && !tail_done; r0 += U * SORT_THREADS) {
         uint32_t idx[U], pxy[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -907,7 +854,8 @@ int lds_keys_for(int maxM) {
 }
 
 size_t sort_lds_bytes(int lds_keys) {
-    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4;  // keys + leaf-flag words
+    // keys + leaf-flag words + 16-bit partition scratch
+    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + static_cast<size_t>(lds_keys) * 2 + 8;
 }
 void allow_big_lds(const void* fn) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(24576)));
@@ -916,6 +864,14 @@ void allow_big_lds(const void* fn) {
 }  // namespace
 
 void launch_sort(const BatchView& v, int nframes, hipStream_t stream) {
+    static const bool once_bm = [] {
+        if (getenv("SORT_BLOCK_MIN")) {
+            int bm = atoi(getenv("SORT_BLOCK_MIN"));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(SORT_BLOCK_MIN), &bm, sizeof(int));
+        }
+        return true;
+    }();
+    (void)once_bm;
     static const bool once = (allow_big_lds(reinterpret_cast<const void*>(sort_kernel)), true);
     (void)once;
     const int lds_keys = lds_keys_for(v.maxM);
