@@ -111,8 +111,9 @@ struct SortShared {
     int cut_r;   // lowest swapped R stopper
     int n_swap;  // K
     uint32_t pivot;
-    int2 big[2][32];  // large segments of the current / next level (n <= 24576 keys => at most 12)
+    int2 big[2][32];  // large segments of the current / next level (n <= 16384 keys => at most 8)
     int n_big[2];
+    int q_head, q_tail, q_pending;  // segment work queue (see SegQueue)
     uint8_t sel[16][2][64];  // per wave (wave_small_introsort): lane of the k-th swapped L / R stopper of a range
 };
 
@@ -487,113 +488,164 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
 
 __device__ int SORT_BLOCK_MIN = 2048;  // segments at least this long are partitioned by the whole workgroup
 
-// The introsort loop of std::sort on a[0, len) (LDS or global), level by level: large segments by
-// the whole workgroup one after another, the rest one wave per segment.  Leaf boundaries are
-// recorded in segbits at bit (bit_base + position).  lists: two arrays of maxSeg int2 (global).
-__device__ void introsort_levels(uint32_t* a, uint16_t* scr16, int len, int depth, uint32_t* segbits, int bit_base,
-                                 int2* lists, int maxSeg, SortShared& sh) {
+// Work queue of the wave-level segments of one introsort_levels call (LDS): a bounded ring with a
+// sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
+// seq == t + 1).  Queued segments are disjoint ranges of more than SORT_LEAF keys, so at most
+// len / 17 of them exist at any time: with SORT_QCAP >= lds_keys / 17 + 32 the ring never fills.
+constexpr int SORT_QCAP = 2048;
+constexpr int SORT_LDS_KEYS_MAX = 16384;
+static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
+
+struct SegQueue {
+    int2* data;      // {first, last | depth << 24}
+    uint32_t* seq;
+};
+
+__device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_load_relaxed(int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one lane: queue [first, last) at the given remaining depth (counted in q_pending until finished)
+__device__ void seg_push(const SegQueue& q, SortShared& sh, int first, int last, int depth) {
+    const int ticket = atomicAdd(&sh.q_tail, 1);
+    uint32_t* sq = q.seq + (ticket & (SORT_QCAP - 1));
+    int spins = 0;
+    while (lds_load_acquire(sq) != static_cast<uint32_t>(ticket)) {  // cannot happen (see above); bounded anyway
+        if (++spins > 100000) {
+            sh.counters[2] = 1;  // reported as STATUS_SEG_OVERFLOW
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    atomicAdd(&sh.q_pending, 1);
+    q.data[ticket & (SORT_QCAP - 1)] = make_int2(first, last | (depth << 24));
+    lds_store_release(sq, static_cast<uint32_t>(ticket) + 1u);
+}
+
+// lane 0 of a wave: next queued segment, or false once every segment is finished
+// Every wait below is bounded and gives up through the overflow flag (reported as
+// STATUS_SEG_OVERFLOW by the caller): a protocol error must end in a loud failure, never in a hang.
+__device__ bool seg_pop(const SegQueue& q, SortShared& sh, int2* item) {
+    for (int spins = 0;; ++spins) {
+        if (lds_load_relaxed(&sh.counters[2]) != 0) {
+            return false;
+        }
+        if (spins > 4000000) {
+            sh.counters[2] = 1;
+            return false;
+        }
+        const int h = lds_load_relaxed(&sh.q_head);
+        const int t = lds_load_relaxed(&sh.q_tail);
+        if (h < t) {
+            if (atomicCAS(&sh.q_head, h, h + 1) == h) {
+                uint32_t* sq = q.seq + (h & (SORT_QCAP - 1));
+                int waits = 0;
+                while (lds_load_acquire(sq) != static_cast<uint32_t>(h) + 1u) {  // its producer is between ticket and publish
+                    if (++waits > 1000000 || lds_load_relaxed(&sh.counters[2]) != 0) {
+                        sh.counters[2] = 1;
+                        return false;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                *item = q.data[h & (SORT_QCAP - 1)];
+                lds_store_release(sq, static_cast<uint32_t>(h) + static_cast<uint32_t>(SORT_QCAP));
+                return true;
+            }
+            continue;
+        }
+        if (lds_load_relaxed(&sh.q_pending) == 0) {
+            return false;  // nothing queued and nobody working: no segment can appear any more
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// The introsort loop of std::sort on a[0, len) in LDS.  Segments of at least SORT_BLOCK_MIN keys
+// are partitioned by the whole workgroup, level by level; everything smaller goes through a work
+// queue: a wave pops a segment, partitions it (or finishes it in registers when it has at most
+// 64 keys), keeps the larger child for itself and queues the other one.  No level barriers: the
+// duration is the longest parent-child chain, not the sum of the slowest segment of every level.
+// Leaf boundaries are recorded in segbits at bit (bit_base + position).
+__device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q, int len, int depth, uint32_t* segbits,
+                                 int bit_base, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
+    for (int i = tid; i < SORT_QCAP; i += blockDim.x) {
+        q.seq[i] = static_cast<uint32_t>(i);
+    }
     if (tid == 0) {
-        sh.counters[0] = 0;
-        sh.counters[1] = 0;
         sh.n_big[0] = 0;
         sh.n_big[1] = 0;
+        sh.q_head = 0;
+        sh.q_tail = 0;
+        sh.q_pending = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
         if (len >= SORT_BLOCK_MIN) {
             sh.big[0][0] = make_int2(0, len);
             sh.n_big[0] = 1;
         } else if (len > SORT_LEAF) {
-            lists[0] = make_int2(0, len);
-            sh.counters[0] = 1;
+            seg_push(q, sh, 0, len, depth);
         }
     }
     __threadfence_block();
     __syncthreads();
+    auto mark_leaf_boundary = [&](int pos) {  // one lane
+        const int bit = bit_base + pos;
+        atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+    };
+    // ---- phase 1: workgroup-wide partitions, level by level, while large segments exist
     int cur = 0;
     while (true) {
-        const int count = sh.counters[0];
         const int nbig = sh.n_big[cur];
-        if (count == 0 && nbig == 0) {
+        if (nbig == 0) {
             break;
         }
-        int2* src = lists + cur * maxSeg;
-        int2* dst = lists + (cur ^ 1) * maxSeg;
-        auto emit_children = [&](int first, int cut, int last) {  // one lane
-            const int bit = bit_base + cut;
-            atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
-            const int2 child[2] = {make_int2(cut, last), make_int2(first, cut)};
-            for (int c = 0; c < 2; ++c) {
-                const int size = child[c].y - child[c].x;
-                if (size >= SORT_BLOCK_MIN) {
-                    const int slot = atomicAdd(&sh.n_big[cur ^ 1], 1);
-                    if (slot < 32) {
-                        sh.big[cur ^ 1][slot] = child[c];
-                    } else {
-                        sh.counters[2] = 1;
-                    }
-                } else if (size > SORT_LEAF) {
-                    const int slot = atomicAdd(&sh.counters[1], 1);
-                    if (slot < maxSeg) {
-                        dst[slot] = child[c];
-                    } else {
-                        sh.counters[2] = 1;
-                    }
-                }
-            }
-        };
-        // large segments: whole workgroup, one after another (uniform control flow)
         for (int s = 0; s < nbig; ++s) {
             const int2 seg = sh.big[cur][s];
             if (depth == 0) {
+                // __partial_sort(first, last, last): heapsort by one lane; every element becomes
+                // its own leaf (the segment is now sorted, the final pass must not touch it)
                 if (tid == 0) {
                     heap_sort_(a + seg.x, seg.y - seg.x);
                 }
                 __threadfence_block();
                 __syncthreads();
                 for (int i = seg.x + tid; i < seg.y; i += blockDim.x) {
-                    const int bit = bit_base + i;
-                    atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
+                    mark_leaf_boundary(i);
                 }
                 continue;
             }
             const int cut = block_partition(a, scr16 + seg.x, seg.x, seg.y, sh);
             if (tid == 0) {
-                emit_children(seg.x, cut, seg.y);
-            }
-        }
-        for (int s = wave; s < count; s += nwaves) {
-            const int2 seg = src[s];
-            const int first = seg.x;
-            const int last = seg.y;
-            if (depth == 0) {
-                // __partial_sort(first, last, last): heapsort by one lane; every element becomes
-                // its own leaf (the segment is now sorted, the final pass must not touch it)
-                if (lane == 0) {
-                    heap_sort_(a + first, last - first);
+                mark_leaf_boundary(cut);
+                const int2 child[2] = {make_int2(cut, seg.y), make_int2(seg.x, cut)};
+                for (int c = 0; c < 2; ++c) {
+                    const int size = child[c].y - child[c].x;
+                    if (size >= SORT_BLOCK_MIN) {
+                        const int slot = sh.n_big[cur ^ 1]++;
+                        if (slot < 32) {
+                            sh.big[cur ^ 1][slot] = child[c];
+                        } else {
+                            sh.counters[2] = 1;
+                        }
+                    } else if (size > SORT_LEAF) {
+                        seg_push(q, sh, child[c].x, child[c].y, depth - 1);
+                    }
                 }
-                wave_mem_fence();
-                for (int i = first + lane; i < last; i += 64) {
-                    const int bit = bit_base + i;
-                    atomicOr(&segbits[bit >> 5], 1u << (bit & 31));
-                }
-                continue;
-            }
-            if (last - first <= 64) {
-                wave_small_introsort(a, first, last, depth, lane, sh.sel[wave], segbits, bit_base);
-                continue;
-            }
-            const int cut = wave_partition_cf(a, scr16 + first, first, last, lane);
-            if (lane == 0) {
-                emit_children(first, cut, last);
             }
         }
         __threadfence_block();
         __syncthreads();
         if (tid == 0) {
-            sh.counters[0] = min(sh.counters[1], maxSeg);
-            sh.counters[1] = 0;
             sh.n_big[cur] = 0;
             sh.n_big[cur ^ 1] = min(sh.n_big[cur ^ 1], 32);
         }
@@ -601,6 +653,75 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, int len, int dept
         cur ^= 1;
         __syncthreads();
     }
+    // ---- phase 2: the queue
+    bool have = false;
+    int first = 0, last = 0, dep = 0;
+    while (true) {
+        if (!have) {
+            int got = 0;
+            int2 item = make_int2(0, 0);
+            if (lane == 0) {
+                got = seg_pop(q, sh, &item) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(got) == 0) {
+                break;
+            }
+            first = __builtin_amdgcn_readfirstlane(item.x);
+            const int packed = __builtin_amdgcn_readfirstlane(item.y);
+            last = packed & 0xffffff;
+            dep = packed >> 24;
+        }
+        have = false;
+        if (dep == 0) {
+            if (lane == 0) {
+                heap_sort_(a + first, last - first);
+            }
+            wave_mem_fence();
+            for (int i = first + lane; i < last; i += 64) {
+                mark_leaf_boundary(i);
+            }
+        } else if (last - first <= 64) {
+            wave_small_introsort(a, first, last, dep, lane, sh.sel[wave], segbits, bit_base);
+        } else {
+            const int cut = wave_partition_cf(a, scr16 + first, first, last, lane);
+            const int size_l = cut - first;
+            const int size_r = last - cut;
+            if (lane == 0) {
+                mark_leaf_boundary(cut);
+            }
+            const bool keep_l = size_l > SORT_LEAF;
+            const bool keep_r = size_r > SORT_LEAF;
+            if (keep_l && keep_r) {
+                // continue with the larger child, queue the other one
+                const bool go_left = size_l >= size_r;
+                if (lane == 0) {
+                    if (go_left) {
+                        seg_push(q, sh, cut, last, dep - 1);
+                    } else {
+                        seg_push(q, sh, first, cut, dep - 1);
+                    }
+                }
+                if (go_left) {
+                    last = cut;
+                } else {
+                    first = cut;
+                }
+                have = true;
+            } else if (keep_l) {
+                last = cut;
+                have = true;
+            } else if (keep_r) {
+                first = cut;
+                have = true;
+            }
+            dep -= 1;
+        }
+        if (!have && lane == 0) {
+            atomicSub(&sh.q_pending, 1);  // this chain of segments is finished
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
 }
 
 // Sort n keys descending by score exactly as std::sort does.  One workgroup.
@@ -621,6 +742,10 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
     const int nwords = (n + 32) / 32;  // bits 0..n
     uint32_t* segbits = nwords <= lds_keys / 32 + 2 ? lds + lds_keys : gsegbits;
     uint16_t* scr16 = reinterpret_cast<uint16_t*>(lds + lds_keys + lds_keys / 32 + 2);  // lds_keys entries
+    SegQueue queue;
+    queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2 + (lds_keys + 3) / 2 + 1);
+    queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
+    queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
     for (int i = tid; i < nwords; i += blockDim.x) {
         uint32_t wbits = 0;
         if (i == 0) {
@@ -730,7 +855,7 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
             lds[i] = gkeys[first + i];
         }
         __syncthreads();
-        introsort_levels(lds, scr16, len, depth, segbits, first, lists, maxSeg, sh);
+        introsort_levels(lds, scr16, queue, len, depth, segbits, first, sh);
         if (!all_in_lds) {
             for (int i = tid; i < len; i += blockDim.x) {
                 gkeys[first + i] = lds[i];
@@ -847,18 +972,19 @@ __global__ __launch_bounds__(SORT_THREADS) void debug_sort_kernel(uint32_t* keys
 
 
 int lds_keys_for(int maxM) {
-    // keys kept in LDS while they fit ~96 KiB; longer arrays are first split in global memory by
+    // keys kept in LDS while they fit 64 KiB; longer arrays are first split in global memory by
     // the workgroup-wide partition until every piece fits
-    const int cap = 24576;
+    const int cap = SORT_LDS_KEYS_MAX;
     return maxM < cap ? (maxM < 64 ? 64 : maxM) : cap;
 }
 
 size_t sort_lds_bytes(int lds_keys) {
-    // keys + leaf-flag words + 16-bit partition scratch
-    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + static_cast<size_t>(lds_keys) * 2 + 8;
+    // keys + leaf-flag words + 16-bit partition scratch + segment queue (data, sequence numbers)
+    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + static_cast<size_t>(lds_keys) * 2 + 32 +
+           static_cast<size_t>(SORT_QCAP) * 12;
 }
 void allow_big_lds(const void* fn) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(24576)));
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(SORT_LDS_KEYS_MAX)));
 }
 
 }  // namespace
