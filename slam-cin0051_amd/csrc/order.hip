@@ -162,49 +162,68 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
     const int lo = first + 1;
     const int hi = last;
     const int n = hi - lo;
-    // pass 1: number of right stoppers
+    // pass 1: number of right stoppers.  Chunks are read four at a time so that the LDS latency is
+    // paid once per 256 keys.
+    constexpr int U = 4;
     int nr = 0;
-#pragma unroll 4
-    for (int base = lo; base < hi; base += 64) {
-        const int i = base + lane;
-        nr += __popcll(__ballot(i < hi && score_of(a[min(i, hi - 1)]) >= p));
+    for (int base = lo; base < hi; base += 64 * U) {
+        uint32_t sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sc[u] = score_of(a[min(base + u * 64 + lane, hi - 1)]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            nr += __popcll(__ballot(base + u * 64 + lane < hi && sc[u] >= p));
+        }
     }
     // pass 2: classify, list the swapped positions by rank
     uint16_t* lpos = scr;
     uint16_t* rpos = scr + n / 2;
     int run_l = 0, run_r = 0, K = 0;
     int cut_l = 0x7fffffff, cut_r = 0x7fffffff;
-#pragma unroll 2
-    for (int base = lo; base < hi; base += 64) {
-        const int i = base + lane;
-        const bool in = i < hi;
-        const uint32_t sc = score_of(a[min(i, hi - 1)]);
-        const bool is_l = in && sc <= p;
-        const bool is_r = in && sc >= p;
-        const unsigned long long ml = __ballot(is_l);
-        const unsigned long long mr = __ballot(is_r);
-        const int l_left = run_l + rank_below(ml);                                  // L stoppers left of i
-        const int r_right = nr - (run_r + rank_below(mr) + (is_r ? 1 : 0));        // R stoppers right of i
-        const bool swap_l = is_l && r_right >= l_left + 1;
-        const bool swap_r = is_r && l_left >= r_right + 1;
-        if (swap_l) {
-            lpos[l_left] = static_cast<uint16_t>(i - first);
+    for (int base0 = lo; base0 < hi; base0 += 64 * U) {
+        uint32_t scs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            scs[u] = score_of(a[min(base0 + u * 64 + lane, hi - 1)]);
         }
-        if (swap_r) {
-            rpos[r_right] = static_cast<uint16_t>(i - first);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int base = base0 + u * 64;
+            if (base >= hi) {
+                break;  // wave-uniform
+            }
+            const int i = base + lane;
+            const bool in = i < hi;
+            const uint32_t sc = scs[u];
+            const bool is_l = in && sc <= p;
+            const bool is_r = in && sc >= p;
+            const unsigned long long ml = __ballot(is_l);
+            const unsigned long long mr = __ballot(is_r);
+            const int l_left = run_l + rank_below(ml);                            // L stoppers left of i
+            const int r_right = nr - (run_r + rank_below(mr) + (is_r ? 1 : 0));  // R stoppers right of i
+            const bool swap_l = is_l && r_right >= l_left + 1;
+            const bool swap_r = is_r && l_left >= r_right + 1;
+            if (swap_l) {
+                lpos[l_left] = static_cast<uint16_t>(i - first);
+            }
+            if (swap_r) {
+                rpos[r_right] = static_cast<uint16_t>(i - first);
+            }
+            const unsigned long long sl = __ballot(swap_l);
+            const unsigned long long stay = ml & ~sl;
+            const unsigned long long moved = __ballot(swap_r);
+            K += __popcll(sl);
+            if (stay != 0 && cut_l == 0x7fffffff) {
+                cut_l = base + __ffsll(static_cast<long long>(stay)) - 1;
+            }
+            if (moved != 0 && cut_r == 0x7fffffff) {
+                cut_r = base + __ffsll(static_cast<long long>(moved)) - 1;
+            }
+            run_l += __popcll(ml);
+            run_r += __popcll(mr);
         }
-        const unsigned long long sl = __ballot(swap_l);
-        const unsigned long long stay = ml & ~sl;
-        const unsigned long long moved = __ballot(swap_r);
-        K += __popcll(sl);
-        if (stay != 0 && cut_l == 0x7fffffff) {
-            cut_l = base + __ffsll(static_cast<long long>(stay)) - 1;
-        }
-        if (moved != 0 && cut_r == 0x7fffffff) {
-            cut_r = base + __ffsll(static_cast<long long>(moved)) - 1;
-        }
-        run_l += __popcll(ml);
-        run_r += __popcll(mr);
     }
     wave_mem_fence();
     // pass 3: exchange the K pairs
