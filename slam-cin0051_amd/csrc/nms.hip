@@ -632,16 +632,25 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
 
 }  // namespace
 
+bool nms_uses_greedy_path(const BatchView& v, const DetectorParams& p) {
+    if (p.window < 2 || p.window > GREEDY_MAX_WINDOW) {
+        return false;
+    }
+    const int gx2 = (v.cols + p.window - 1) / p.window + 2;
+    const int gy2 = (v.rows + p.window - 1) / p.window + 2;
+    return static_cast<size_t>(gx2) * gy2 * sizeof(uint32_t) + 1024 <= static_cast<size_t>(GREEDY_LDS_BUDGET);
+}
+
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid) {
     static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
                               true);
     (void)once;
-    if (p.window >= 2 && p.window <= GREEDY_MAX_WINDOW) {
+    if (nms_uses_greedy_path(v, p)) {
         const int gx2 = (v.cols + p.window - 1) / p.window + 2;
         const int gy2 = (v.rows + p.window - 1) / p.window + 2;
         const size_t bytes = static_cast<size_t>(gx2) * gy2 * sizeof(uint32_t);
-        if (bytes + 1024 <= static_cast<size_t>(GREEDY_LDS_BUDGET)) {
+        {
             static const bool once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel),
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, GREEDY_LDS_BUDGET),
                                        true);

@@ -751,11 +751,9 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q
 //   lists    : 3 * maxSeg int2 (global): two level lists + the list of LDS-sized segments
 // Segments longer than lds_keys are partitioned in global memory by the whole workgroup until
 // they fit; every remaining segment is then sorted in LDS.  Returns 0 or STATUS_SEG_OVERFLOW.
-constexpr int TAIL_DONE = 1 << 30;  // returned with the status: sorted (x,y) and rank_of already written
-
 __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* gsegbits,
-                               int2* lists, int maxSeg, int n, SortShared& sh, const uint32_t* xy = nullptr,
-                               uint32_t* rank_of = nullptr) {
+                               int2* lists, int maxSeg, int n, SortShared& sh, uint32_t* rank_of = nullptr,
+                               const uint32_t* xy = nullptr) {
     const bool all_in_lds = n <= lds_keys;
     const int tid = threadIdx.x;
     const int nwords = (n + 32) / 32;  // bits 0..n
@@ -891,49 +889,69 @@ __device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, in
     const int overflow = sh.counters[2];
     __syncthreads();
     // __final_insertion_sort == stable sort inside each leaf: rank counting, one lane per element.
-    // When the whole array sat in LDS the keys are read from there and the by-products for the NMS
-    // (inverse permutation; (x,y) in sorted order, written over the now dead unsorted keys) are
-    // produced on the way -- the gather of (x,y) is in flight while the rank is counted.
+    // When the whole array sat in LDS the keys are read from there, and (x,y) in sorted order is
+    // written over the dead unsorted keys for the greedy NMS, which then streams its input (the
+    // gather is cheaper here, spread over 16 waves, than in that single-wave kernel).  rank_of
+    // (optional): the inverse permutation, a divergent scatter.
     const uint32_t* a = all_in_lds ? lds : gkeys;
-    const bool fuse_tail = all_in_lds && xy != nullptr;
-    for (int i = tid; i < n; i += blockDim.x) {
-        // leaf start s: highest flag <= i; leaf end e: lowest flag > i (flags 0 and n always set)
-        int wi = i >> 5;
-        uint32_t wbits = segbits[wi] & (0xffffffffu >> (31 - (i & 31)));
-        while (wbits == 0) {
-            wbits = segbits[--wi];
+    const bool sorted_xy = all_in_lds && xy != nullptr;  // the unsorted keys in gkeys are dead: (x,y) in sorted order go there
+    constexpr int LU = 4;  // elements per thread and step: their gathers are in flight together
+    for (int i0 = tid; i0 < n; i0 += LU * blockDim.x) {
+        uint32_t me[LU], pxy[LU];
+        int lo_[LU], hi_[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int i = min(i0 + u * static_cast<int>(blockDim.x), n - 1);
+            me[u] = a[i];
+            // A leaf has at most SORT_LEAF = 16 elements, so its start flag lies in (i-16, i] and its
+            // end flag in (i, i+16]: both inside the 64 flag bits that start at word (i-16)/32
+            // (flags 0 and n are always set).
+            const int w0 = max(i - 16, 0) >> 5;
+            const unsigned long long x = static_cast<unsigned long long>(segbits[w0]) |
+                                         (static_cast<unsigned long long>(segbits[min(w0 + 1, nwords - 1)]) << 32);
+            const int rel = i - w0 * 32;  // <= 47
+            const unsigned long long upto = x & low_mask(rel + 1);
+            const unsigned long long above = x & ~low_mask(rel + 1);
+            lo_[u] = w0 * 32 + (63 - __clzll(static_cast<long long>(upto)));
+            hi_[u] = w0 * 32 + (__ffsll(static_cast<long long>(above)) - 1);
         }
-        const int s = wi * 32 + (31 - __clz(wbits));
-        wi = (i + 1) >> 5;
-        wbits = segbits[wi] & (0xffffffffu << ((i + 1) & 31));
-        while (wbits == 0) {
-            wbits = segbits[++wi];
+        if (sorted_xy) {
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                pxy[u] = xy[me[u] & INDEX_MASK];
+            }
         }
-        const int e = wi * 32 + (__ffs(wbits) - 1);
-        const uint32_t me = a[i];
-        const uint32_t pxy = fuse_tail ? xy[me & INDEX_MASK] : 0u;
-        const uint32_t sc = score_of(me);
-        int pos = s;
-        for (int j = s; j < e; ++j) {
-            const uint32_t o = score_of(a[j]);
-            pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
-        }
-        out[pos] = me;
-        if (fuse_tail) {
-            gkeys[pos] = pxy;
-            rank_of[me & INDEX_MASK] = static_cast<uint32_t>(pos);
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int i = i0 + u * static_cast<int>(blockDim.x);
+            if (i >= n) {
+                break;
+            }
+            const uint32_t sc = score_of(me[u]);
+            int pos = lo_[u];
+            for (int j = lo_[u]; j < hi_[u]; ++j) {
+                const uint32_t o = score_of(a[j]);
+                pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
+            }
+            out[pos] = me[u];
+            if (rank_of != nullptr) {
+                rank_of[me[u] & INDEX_MASK] = static_cast<uint32_t>(pos);
+            }
+            if (sorted_xy) {
+                gkeys[pos] = pxy[u];
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
-    return (overflow != 0 ? STATUS_SEG_OVERFLOW : 0) | (fuse_tail ? TAIL_DONE : 0);
+    return overflow != 0 ? STATUS_SEG_OVERFLOW : 0;
 }
 
 extern __shared__ uint32_t dyn_lds[];
 
 constexpr int SORT_THREADS = 1024;
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds_keys) {
+__global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds_keys, int need_rank_of) {
     __shared__ SortShared sh;
     const int f = blockIdx.x;
     const int n = v.n_cand[f];
@@ -944,33 +962,16 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds
     uint32_t* out = v.sorted + static_cast<size_t>(f) * v.maxM;
     uint32_t* gsegbits = reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
     int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
-    // by-products for the NMS: the inverse permutation, and (x,y) in sorted order -- written over
-    // the unsorted keys, which are dead once sorted -- so that the greedy NMS streams its input
-    uint32_t* rank_of = v.rank_of + static_cast<size_t>(f) * v.maxM;
-    const uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
-    int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, xy, rank_of);
-    const bool tail_done = (st & TAIL_DONE) != 0;
-    st &= ~TAIL_DONE;
-    __syncthreads();
-    constexpr int U = 4;  // independent gathers in flight per thread
-    for (int r0 = threadIdx.x; r0 < n && !tail_done; r0 += U * SORT_THREADS) {
-        uint32_t idx[U], pxy[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + u * SORT_THREADS;
-            idx[u] = r < n ? out[r] & INDEX_MASK : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            pxy[u] = xy[idx[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + u * SORT_THREADS;
-            if (r < n) {
-                rank_of[idx[u]] = static_cast<uint32_t>(r);
-                gkeys[r] = pxy[u];
-            }
+    // by-products (written by the leaf pass): the inverse permutation for the generic NMS path, or
+    // (x,y) in sorted order for the greedy one
+    uint32_t* rank_of = need_rank_of != 0 ? v.rank_of + static_cast<size_t>(f) * v.maxM : nullptr;
+    const uint32_t* xy = need_rank_of != 0 ? nullptr : v.cand_xy + static_cast<size_t>(f) * v.maxM;
+    const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, rank_of, xy);
+    if (xy != nullptr && n > lds_keys) {
+        // the array did not fit LDS: the keys were sorted in place in gkeys, gather in a separate pass
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            gkeys[r] = xy[out[r] & INDEX_MASK];
         }
     }
     if (threadIdx.x == 0 && st != 0) {
@@ -1008,7 +1009,7 @@ void allow_big_lds(const void* fn) {
 
 }  // namespace
 
-void launch_sort(const BatchView& v, int nframes, hipStream_t stream) {
+void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_rank_of) {
     static const bool once_bm = [] {
         if (getenv("SORT_BLOCK_MIN")) {
             int bm = atoi(getenv("SORT_BLOCK_MIN"));
@@ -1020,7 +1021,8 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream) {
     static const bool once = (allow_big_lds(reinterpret_cast<const void*>(sort_kernel)), true);
     (void)once;
     const int lds_keys = lds_keys_for(v.maxM);
-    hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys);
+    hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys,
+                       need_rank_of ? 1 : 0);
 }
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,

@@ -250,7 +250,7 @@ void enqueue_detect(slamx_batch* b, int nframes) {
     launch_expand(b->v, p, nframes, s);
     record(b, 3);
     if (p.nms != 0) {
-        launch_sort(b->v, nframes, s);
+        launch_sort(b->v, nframes, s, !nms_uses_greedy_path(b->v, p));
         record(b, 4);
         launch_nms(b->v, p, nframes, s, event_slot(b, 5));
         record(b, 6);

@@ -151,7 +151,10 @@ __device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, i
 void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
 void launch_scan(const BatchView& v, int nframes, hipStream_t stream);
 void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream);
-void launch_sort(const BatchView& v, int nframes, hipStream_t stream);
+// need_rank_of: also write the inverse permutation (only the generic NMS path reads it)
+void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_rank_of);
+// true when launch_nms will take the greedy one-wave-per-frame path (which needs no rank_of)
+bool nms_uses_greedy_path(const BatchView& v, const DetectorParams& p);
 // ev_mid (optional) is recorded after the first kernel of a multi-kernel stage
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid);
 void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream);  // NonMaxSuppression: 0
