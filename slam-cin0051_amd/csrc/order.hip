@@ -417,14 +417,35 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     const int per_wave = ((n + nwaves - 1) / nwaves + 63) & ~63;  // slice length, multiple of 64
     const int w_lo = min(hi, lo + wave * per_wave);
     const int w_hi = min(hi, w_lo + per_wave);
+    // A slice of at most 1024 keys (always the case for LDS-resident arrays) is read ONCE, sixteen
+    // independent loads, and both passes run on registers; longer slices are streamed twice.
+    constexpr int RC = 16;
+    const bool in_regs = per_wave <= 64 * RC;
+    uint32_t held[RC];
+    if (in_regs) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int i = w_lo + c * 64 + lane;
+            held[c] = i < w_hi ? score_of(a[i]) : 0u;
+        }
+    }
     // pass 1: stoppers per wave slice
     uint32_t nl = 0, nr = 0;
-    for (int base = w_lo; base < w_hi; base += 64) {
-        const int i = base + lane;
-        const bool in = i < w_hi;
-        const uint32_t sc = in ? score_of(a[i]) : 0u;
-        nl += static_cast<uint32_t>(__popcll(__ballot(in && sc <= p)));
-        nr += static_cast<uint32_t>(__popcll(__ballot(in && sc >= p)));
+    if (in_regs) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const bool in = w_lo + c * 64 + lane < w_hi;
+            nl += static_cast<uint32_t>(__popcll(__ballot(in && held[c] <= p)));
+            nr += static_cast<uint32_t>(__popcll(__ballot(in && held[c] >= p)));
+        }
+    } else {
+        for (int base = w_lo; base < w_hi; base += 64) {
+            const int i = base + lane;
+            const bool in = i < w_hi;
+            const uint32_t sc = in ? score_of(a[i]) : 0u;
+            nl += static_cast<uint32_t>(__popcll(__ballot(in && sc <= p)));
+            nr += static_cast<uint32_t>(__popcll(__ballot(in && sc >= p)));
+        }
     }
     if (lane == 0) {
         sh.wave_l[wave] = nl;
@@ -439,48 +460,56 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     }
     PosT* lpos = scratch;  // positions relative to `first`; K <= (n - 1) / 2 pairs: both lists fit n entries
     PosT* rpos = scratch + n / 2;
-    // pass 2: classify
+    // pass 2: classify (all running values are wave-uniform: ballots, no cross-lane reductions)
     uint32_t run_l = 0, run_r = 0;  // stoppers of this slice in earlier steps
     int my_swaps = 0;
     int min_unswapped_l = 0x7fffffff;
     int min_swapped_r = 0x7fffffff;
-    for (int base = w_lo; base < w_hi; base += 64) {
+    auto classify = [&](int base, uint32_t sc) {
         const int i = base + lane;
         const bool in = i < w_hi;
-        const uint32_t sc = in ? score_of(a[i]) : 0u;
         const bool is_l = in && sc <= p;
         const bool is_r = in && sc >= p;
         const unsigned long long ml = __ballot(is_l);
         const unsigned long long mr = __ballot(is_r);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const uint32_t l_left = l_before + run_l + static_cast<uint32_t>(__popcll(ml & below));  // L at positions < i
-        const uint32_t r_le = run_r + static_cast<uint32_t>(__popcll(mr & (below | (1ull << lane))));
+        const uint32_t l_left = l_before + run_l + static_cast<uint32_t>(rank_below(ml));  // L at positions < i
+        const uint32_t r_le = run_r + static_cast<uint32_t>(rank_below(mr)) + (is_r ? 1u : 0u);
         const uint32_t r_right = r_after + (nr - r_le);  // R at positions > i
-        if (is_l) {
-            // 0-based rank l_left; partner R_{l_left} exists to the right iff r_right >= l_left + 1
-            if (r_right >= l_left + 1u) {
-                lpos[l_left] = static_cast<PosT>(i - first);
-                ++my_swaps;
-            } else {
-                min_unswapped_l = min(min_unswapped_l, i);
-            }
+        // L stopper of 0-based rank l_left: its partner R_{l_left} exists to the right iff r_right >= l_left + 1;
+        // R stopper of rank-from-the-right r_right: its partner lies to the left iff l_left >= r_right + 1
+        const bool swap_l = is_l && r_right >= l_left + 1u;
+        const bool swap_r = is_r && l_left >= r_right + 1u;
+        if (swap_l) {
+            lpos[l_left] = static_cast<PosT>(i - first);
         }
-        if (is_r) {
-            // 0-based rank from the right r_right; partner L_{r_right} lies to the left iff l_left >= r_right + 1
-            if (l_left >= r_right + 1u) {
-                rpos[r_right] = static_cast<PosT>(i - first);
-                min_swapped_r = min(min_swapped_r, i);
-            }
+        if (swap_r) {
+            rpos[r_right] = static_cast<PosT>(i - first);
+        }
+        const unsigned long long sl = __ballot(swap_l);
+        const unsigned long long stay = ml & ~sl;
+        const unsigned long long moved = __ballot(swap_r);
+        my_swaps += __popcll(sl);
+        if (stay != 0 && min_unswapped_l == 0x7fffffff) {
+            min_unswapped_l = base + __ffsll(static_cast<long long>(stay)) - 1;
+        }
+        if (moved != 0 && min_swapped_r == 0x7fffffff) {
+            min_swapped_r = base + __ffsll(static_cast<long long>(moved)) - 1;
         }
         run_l += static_cast<uint32_t>(__popcll(ml));
         run_r += static_cast<uint32_t>(__popcll(mr));
-    }
-    // wave reductions, then one LDS atomic per wave
+    };
+    if (in_regs) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        my_swaps += __shfl_xor(my_swaps, d);
-        min_unswapped_l = min(min_unswapped_l, __shfl_xor(min_unswapped_l, d));
-        min_swapped_r = min(min_swapped_r, __shfl_xor(min_swapped_r, d));
+        for (int c = 0; c < RC; ++c) {
+            if (w_lo + c * 64 < w_hi) {  // wave-uniform
+                classify(w_lo + c * 64, held[c]);
+            }
+        }
+    } else {
+        for (int base = w_lo; base < w_hi; base += 64) {
+            const int i = base + lane;
+            classify(base, i < w_hi ? score_of(a[i]) : 0u);
+        }
     }
     if (lane == 0) {
         atomicAdd(&sh.n_swap, my_swaps);
