@@ -212,7 +212,6 @@ constexpr int TILE_DW = 12;                   // 48 bytes: columns [x0a, x0a+48)
 constexpr int MOM_HALF = 15;
 constexpr int MOM_ROWS = 2 * MOM_HALF + 1;    // 31
 constexpr int MOM_DW = 9;                     // 36 bytes: columns [x0a, x0a+36), x0a = (x-15) & ~3
-constexpr int MAX_DISC = 716;                 // pixels of the radius-15 disc (709) rounded up
 
 // Both wave-per-keypoint kernels below are latency chains (keypoint -> tile -> result), so each
 // wave (1) fetches the coordinates of up to 64 of its keypoints with ONE coalesced load and hands
@@ -250,11 +249,25 @@ struct TilePrefetch {
     }
 };
 
+// sum over the 64 lanes (DPP row reductions + row broadcasts; the total lands in lane 63)
+__device__ __forceinline__ int wave_sum_dpp(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror: every lane holds its row's sum
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// Wave per keypoint, no LDS: lane l loads the tile dwords e = l + 64 k (k < 5) of the 31 x 36-byte
+// tile straight into registers -- for the NEXT keypoint while the current one is reduced -- and
+// multiplies them with per-lane constant weights: v_dot4_u32_u8 with the per-byte weights u + 15
+// gives sum (u + 15) I, with the disc flags it gives sum I, and m10 = sum (u+15) I - 15 sum I,
+// m01 = sum over dwords of v * (sum I of the dword).  All integer, exact.  The weights depend on
+// the alignment (x - 15) & 3 of the tile: four register sets, picked by a wave-uniform switch.
 __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParams P, int2* __restrict__ moments, int nframes,
                                                       int blocks_per_frame, int use_visit) {
-    __shared__ uint32_t tile[4][MOM_ROWS * MOM_DW];
-    __shared__ uint16_t disc[MAX_DISC];
-    __shared__ int disc_count;
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
         return;
@@ -263,31 +276,39 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
     const int wave = threadIdx.x >> 6;
     const int n = v.n_kp[f];
     const int radius = P.patch / 2;
-    if (threadIdx.x == 0) {
-        disc_count = 0;
-    }
-    __syncthreads();
-    {
-        // disc offsets (u,v) with u^2+v^2 <= r^2, any order (the integer moments are order-free)
-        const int side = 2 * radius + 1;
-        for (int t = threadIdx.x; t < side * side; t += 256) {
-            const int vv = t / side - radius;
-            const int uu = t - (vv + radius) * side - radius;
-            if (uu * uu + vv * vv <= radius * radius) {
-                const int slot = atomicAdd(&disc_count, 1);
-                disc[slot] = static_cast<uint16_t>(((vv + 128) << 8) | (uu + 128));
-            }
-        }
-    }
-    __syncthreads();
-    const int ndisc = disc_count;
-    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);
-    const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
-    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
     const int stride = blocks_per_frame * 4;
     const int i0 = bx * 4 + wave;
-    TilePrefetch<MOM_ROWS, MOM_DW, MOM_HALF> pf;
+    if (i0 >= n) {
+        return;
+    }
+    constexpr int SLOTS = 5;
+    int off[SLOTS], vrow[SLOTS];
+    uint2 wgt[4][SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int e = lane + 64 * k;
+        const int ee = e < MOM_ROWS * MOM_DW ? e : 0;  // surplus slots re-read dword 0 with zero weights
+        const int r = ee / MOM_DW;
+        off[k] = r * v.pitch + (ee - r * MOM_DW) * 4;
+        vrow[k] = r - MOM_HALF;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            wgt[a][k] = P.moment_weights[(a * SLOTS + k) * 64 + lane];
+        }
+    }
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+    auto is_inside = [&](int x, int y) {
+        return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
+    };
+    auto issue = [&](int x, int y, uint32_t* px) {  // the tile of an inside keypoint never leaves the padded frame
+        const uint8_t* base = img + static_cast<size_t>(y - MOM_HALF) * v.pitch + ((x - MOM_HALF) & ~3);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            px[k] = *reinterpret_cast<const uint32_t*>(base + off[k]);
+        }
+    };
     for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
         // lane j holds the slot and coordinates of this wave's (chunk + j)-th keypoint
         const int mine = i0 + (chunk + lane) * stride;
@@ -298,53 +319,87 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
             ky = static_cast<int>(kps[kslot].y);
         }
         const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
-        auto is_inside = [&](int x, int y) {
-            return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
-        };
-        int x = __shfl(kx, 0);
-        int y = __shfl(ky, 0);
+        int x = __builtin_amdgcn_readlane(kx, 0);
+        int y = __builtin_amdgcn_readlane(ky, 0);
+        uint32_t nxt[SLOTS] = {0, 0, 0, 0, 0};
         if (is_inside(x, y)) {
-            pf.issue(v, img, x, y, lane);
+            issue(x, y, nxt);
         }
         for (int k = 0; k < cnt; ++k) {
-            const int i = __shfl(kslot, k);
+            const int slot = __shfl(kslot, k);
             const bool inside = is_inside(x, y);  // wave-uniform
-            if (inside) {
-                pf.commit(tile[wave], lane);
+            uint32_t cur[SLOTS];
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                cur[q] = nxt[q];
             }
-            const int cx = x - ((x - MOM_HALF) & ~3);
-            // prefetch the next keypoint's tile while this one is reduced
             const int xn = __shfl(kx, (k + 1) & 63);
             const int yn = __shfl(ky, (k + 1) & 63);
             if (k + 1 < cnt && is_inside(xn, yn)) {
-                pf.issue(v, img, xn, yn, lane);
+                issue(xn, yn, nxt);
             }
             int m01 = 0;
-            int m10 = 0;
+            int m10 = 0x7fffffff;  // marks "patch leaves the image"
             if (inside) {
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int t = lane; t < ndisc; t += 64) {
-                    const int d = disc[t];
-                    const int vv = (d >> 8) - 128;
-                    const int uu = (d & 0xff) - 128;
-                    const int I = t8[(vv + MOM_HALF) * (MOM_DW * 4) + cx + uu];
-                    m01 += vv * I;
-                    m10 += uu * I;
+                uint32_t su = 0, s = 0;
+                int sv = 0;
+                auto reduce = [&](const uint2* w) {
+#pragma unroll
+                    for (int q = 0; q < SLOTS; ++q) {
+                        su = __builtin_amdgcn_udot4(cur[q], w[q].x, su, false);
+                        const uint32_t row = __builtin_amdgcn_udot4(cur[q], w[q].y, 0u, false);
+                        s += row;
+                        sv += vrow[q] * static_cast<int>(row);
+                    }
+                };
+                switch ((x - MOM_HALF) & 3) {  // wave-uniform
+                    case 0: reduce(wgt[0]); break;
+                    case 1: reduce(wgt[1]); break;
+                    case 2: reduce(wgt[2]); break;
+                    default: reduce(wgt[3]); break;
                 }
-                m01 = wave_sum(m01);
-                m10 = wave_sum(m10);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                m10 = wave_sum_dpp(static_cast<int>(su) - MOM_HALF * static_cast<int>(s));
+                m01 = wave_sum_dpp(sv);
             }
             if (lane == 0) {
-                moments[static_cast<size_t>(f) * v.maxK + i] = make_int2(m01, inside ? m10 : 0x7fffffff);
+                moments[static_cast<size_t>(f) * v.maxK + slot] = make_int2(m01, m10);
             }
             x = xn;
             y = yn;
         }
     }
 }
+
+// host side of the table described in slamx_internal.h
+}  // namespace
+
+void moment_weight_table(int radius, uint32_t* out_xy) {
+    for (int a = 0; a < 4; ++a) {
+        for (int k = 0; k < 5; ++k) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int e = lane + 64 * k;
+                uint32_t wu = 0, wm = 0;
+                if (e < MOM_ROWS * MOM_DW) {
+                    const int r = e / MOM_DW;
+                    const int c = e - r * MOM_DW;
+                    const int vv = r - MOM_HALF;
+                    for (int b = 0; b < 4; ++b) {
+                        const int uu = 4 * c + b - (MOM_HALF + a);
+                        if (uu >= -MOM_HALF && uu <= MOM_HALF && uu * uu + vv * vv <= radius * radius) {
+                            wu |= static_cast<uint32_t>(uu + MOM_HALF) << (8 * b);
+                            wm |= 1u << (8 * b);
+                        }
+                    }
+                }
+                const size_t idx = (static_cast<size_t>(a) * 5 + k) * 64 + lane;
+                out_xy[2 * idx] = wu;
+                out_xy[2 * idx + 1] = wm;
+            }
+        }
+    }
+}
+
+namespace {
 
 // lane per keypoint: (m01, m10) -> angle -> cos, sin.  m10 == INT_MAX marks "patch leaves the
 // image": angle 0 and an all-zero descriptor (feature_detector.cpp:211-214, :242-245).

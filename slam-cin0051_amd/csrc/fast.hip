@@ -322,8 +322,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
 
 // One lane per bitmap word (coalesced 8-byte loads; ~half of the words hold a corner, usually
 // one): the lane walks its set bits and writes (x,y) and the sort key of each corner.
-__global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
-    const int f = blockIdx.y;
+__global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, int blocks_per_frame) {
+    int f, bx;
+    if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
+        return;
+    }
     const int m_total = v.n_cand[f];
     if (m_total == 0) {
         return;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v) {
     const uint8_t* __restrict__ img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+    for (int w = bx * 256 + static_cast<int>(threadIdx.x); w < n; w += blocks_per_frame * 256) {
         unsigned long long m = masks[w];
         if (m == 0) {
             continue;
@@ -377,7 +380,8 @@ void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {
 void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
     (void)p;
     const int n = v.rows * v.nw;
-    hipLaunchKernelGGL(expand_kernel, dim3(grid_x(n, 256, nframes), nframes), dim3(256), 0, stream, v);
+    const int bpf = grid_x(n, 256, nframes);
+    hipLaunchKernelGGL(expand_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, nframes, bpf);
 }
 
 }  // namespace slamx

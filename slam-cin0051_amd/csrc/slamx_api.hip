@@ -76,6 +76,7 @@ struct slamx_detector {
     slamx_detector_config cfg{};
     std::vector<int32_t> pattern;  // x1,y1,x2,y2 per surviving pair
     int8_t* pattern_dev = nullptr;
+    uint2* moment_weights_dev = nullptr;  // moment_weight_table() for PatchSize / 2 <= 15
     double* weights_dev = nullptr;
     slamx_batch* single = nullptr;  // lazily created 1-frame batch behind the host-buffer API
 };
@@ -194,6 +195,7 @@ DetectorParams params_of(const slamx_detector* d) {
     p.patch = d->cfg.patch_size;
     p.npairs = d->cfg.num_brief_pairs;
     p.pattern_len = static_cast<int>(d->pattern.size() / 4);
+    p.moment_weights = d->moment_weights_dev;
     return p;
 }
 
@@ -491,6 +493,16 @@ int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slam
     }
     HIP_TRY(hipMemcpy(d->pattern_dev, p8.data(), p8.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->weights_dev, w25, sizeof(w25), hipMemcpyHostToDevice));
+    if (cfg->patch_size / 2 <= 15) {
+        std::vector<uint32_t> mw(2 * MOMENT_TABLE_ENTRIES);
+        moment_weight_table(cfg->patch_size / 2, mw.data());
+        rc = dev_alloc(&d->moment_weights_dev, MOMENT_TABLE_ENTRIES);
+        if (rc != SLAMX_OK) {
+            slamx_detector_destroy(d);
+            return rc;
+        }
+        HIP_TRY(hipMemcpy(d->moment_weights_dev, mw.data(), mw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     *out = d;
     return SLAMX_OK;
 }
@@ -503,6 +515,7 @@ void slamx_detector_destroy(slamx_detector* det) {
         slamx_batch_destroy(det->single);
     }
     dev_free(det->pattern_dev);
+    dev_free(det->moment_weights_dev);
     dev_free(det->weights_dev);
     delete det;
 }

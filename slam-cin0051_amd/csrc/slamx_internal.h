@@ -61,7 +61,16 @@ struct BatchView {
 
 struct DetectorParams {
     int threshold, arc, nms, window, patch, npairs /*NumBRIEFPairs*/, pattern_len;
+    const uint2* moment_weights;  // device table of moment_weight_table() or nullptr (radius > 15)
 };
+
+// Orientation moments over dword-aligned tiles (describe.hip, moments_kernel): a keypoint's disc sits
+// in a 31-row x 36-byte tile whose first column is (x - 15) & ~3; lane l of a wave owns the tile
+// dwords e = l + 64 k (k < 5, e = row * 9 + dword column).  Entry ((a * 5 + k) * 64 + l) of the
+// table holds, for alignment a = (x - 15) & 3, the four per-byte weights u + 15 (.x) and the four
+// disc-membership flags (.y) of that dword, zero outside the disc of the given radius.
+constexpr int MOMENT_TABLE_ENTRIES = 4 * 5 * 64;
+void moment_weight_table(int radius, uint32_t* out_xy /* 2 * MOMENT_TABLE_ENTRIES words */);
 
 // Correctly rounded float sqrt.  NOTE: HIP's __fsqrt_rn() is __ocml_native_sqrt_f32 (1 ulp,
 // v_sqrt_f32 alone) unless OCML_BASIC_ROUNDED_OPERATIONS is defined; plain sqrtf is expanded to the
@@ -124,8 +133,9 @@ inline int grid_x(int items, int per_block, int nframes) {
 // 1-D grid -> (frame, block-in-frame).  The hardware deals consecutive workgroup ids round-robin
 // over the 8 XCDs, so a 2-D grid whose x extent is a multiple of 8 pins block column k to XCD k
 // (uneven columns then idle whole XCDs).  With 8 or more frames all blocks of a frame land on ONE
-// XCD: its L2 then only holds the active row bands of nframes/8 frames, and the tiles of a frame
-// share their halos there.  With fewer frames the blocks are simply dealt round-robin.
+// XCD, frame after frame: its 4 MB L2 then only has to hold the active row bands of the few frames
+// in flight, and neighbouring tiles / keypoint patches of a frame find each other's lines there.
+// With fewer frames the blocks are simply dealt round-robin.
 // Placement is a speed matter only.
 inline unsigned frame_grid(int nframes, int blocks_per_frame) {
     const int slots = nframes >= 8 ? 8 * ((nframes + 7) / 8) : nframes;
@@ -135,10 +145,9 @@ inline unsigned frame_grid(int nframes, int blocks_per_frame) {
 __device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, int* f, int* bx) {
     const int id = static_cast<int>(blockIdx.x);
     if (nframes >= 8) {
-        const int f8 = (nframes + 7) / 8;
         const int q = id >> 3;
-        *f = (id & 7) + 8 * (q % f8);
-        *bx = q / f8;
+        *f = (id & 7) + 8 * (q / blocks_per_frame);  // an XCD takes its frames one after another
+        *bx = q - (q / blocks_per_frame) * blocks_per_frame;
     } else {
         *f = id % nframes;
         *bx = id / nframes;
