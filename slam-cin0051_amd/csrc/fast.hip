@@ -320,9 +320,66 @@ __global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
     }
 }
 
-// One lane per bitmap word (coalesced 8-byte loads; ~half of the words hold a corner, usually
-// one): the lane walks its set bits and writes (x,y) and the sort key of each corner.
+// computeFASTScore for one corner: the 16 circle pixels come from 7 rows; per row one 12-byte load at
+// the dword-aligned address below x-3 and two v_alignbyte give the bytes x-3..x and x+1..x+4, the
+// circle bytes are gathered four to a dword with v_perm (unused byte positions hold the centre, whose
+// difference is 0) and summed with v_sad_u8.
+struct RowBytes {
+    uint32_t a;  // pixels x-3, x-2, x-1, x
+    uint32_t b;  // pixels x+1, x+2, x+3, x+4
+};
+__device__ __forceinline__ RowBytes load_row7(const uint8_t* row, int x) {
+    const int a0 = (x - 3) & ~3;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(row + a0);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t sh = static_cast<uint32_t>(x - 3 - a0);
+    RowBytes r;
+    r.a = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    r.b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    return r;
+}
+// v_perm_b32(hi, lo, sel): selector byte 0-3 picks lo.b0-3, 4-7 picks hi.b0-3
+__device__ __forceinline__ int corner_score(const uint8_t* img, int pitch, int x, int y) {
+    const uint8_t* centre_row = img + static_cast<size_t>(y) * pitch;
+    const RowBytes m3 = load_row7(centre_row - 3 * pitch, x);
+    const RowBytes m2 = load_row7(centre_row - 2 * pitch, x);
+    const RowBytes m1 = load_row7(centre_row - pitch, x);
+    const RowBytes z0 = load_row7(centre_row, x);
+    const RowBytes p1 = load_row7(centre_row + pitch, x);
+    const RowBytes p2 = load_row7(centre_row + 2 * pitch, x);
+    const RowBytes p3 = load_row7(centre_row + 3 * pitch, x);
+    const uint32_t c4 = __builtin_amdgcn_perm(0u, z0.a, 0x03030303u);  // centre in all four bytes
+    // rows -3 / +3: dx -1, 0, +1 = a.b2, a.b3, b.b0; the fourth byte is the centre
+    uint32_t s = 0;
+    uint32_t t;
+    t = __builtin_amdgcn_perm(m3.b, m3.a, 0x00040302u);  // x-1, x, x+1, (replaced below)
+    t = (t & 0x00ffffffu) | (c4 & 0xff000000u);
+    s = __builtin_amdgcn_sad_u8(t, c4, s);
+    t = __builtin_amdgcn_perm(p3.b, p3.a, 0x00040302u);
+    t = (t & 0x00ffffffu) | (c4 & 0xff000000u);
+    s = __builtin_amdgcn_sad_u8(t, c4, s);
+    // rows -2 / +2: dx -2, +2 = a.b1, b.b1 ; rows -1 / +1: dx -3, +3 = a.b0, b.b2
+    t = __builtin_amdgcn_perm(m2.b, m2.a, 0x00000501u);  // bytes: x-2, x+2, (2 fillers)
+    uint32_t u = __builtin_amdgcn_perm(m1.b, m1.a, 0x06000000u);  // bytes 2,3: x-3 (a.b0), x+3 (b.b2)
+    t = (t & 0x0000ffffu) | (u & 0xffff0000u);
+    s = __builtin_amdgcn_sad_u8(t, c4, s);
+    t = __builtin_amdgcn_perm(p2.b, p2.a, 0x00000501u);
+    u = __builtin_amdgcn_perm(p1.b, p1.a, 0x06000000u);
+    t = (t & 0x0000ffffu) | (u & 0xffff0000u);
+    s = __builtin_amdgcn_sad_u8(t, c4, s);
+    // row 0: dx -3, +3 = a.b0, b.b2
+    t = __builtin_amdgcn_perm(z0.b, z0.a, 0x00060000u);  // bytes: x-3, (filler), x+3, (filler)
+    t = (t & 0x00ff00ffu) | (c4 & 0xff00ff00u);
+    s = __builtin_amdgcn_sad_u8(t, c4, s);
+    return static_cast<int>(s);
+}
+
+// Corners -> (x,y) and the sort key score<<20 | rasterIndex, in raster order.  A wave walks 64
+// bitmap words at a time (coalesced 8-byte loads; about a quarter of the words hold corners, in
+// clusters), every lane peels off the set bits of its word and the wave compacts them into an LDS
+// list, so that the score of 64 corners at a time is computed on full waves.
 __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, int blocks_per_frame) {
+    __shared__ uint2 list[4][128];  // per wave: {y << 16 | x, raster index}
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
         return;
@@ -331,37 +388,62 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
     if (m_total == 0) {
         return;
     }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int n = v.rows * v.nw;
     const unsigned long long* __restrict__ masks = v.masks + static_cast<size_t>(f) * n;
     const uint32_t* __restrict__ off = v.wordoff + static_cast<size_t>(f) * n;
     const uint8_t* __restrict__ img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
-    for (int w = bx * 256 + static_cast<int>(threadIdx.x); w < n; w += blocks_per_frame * 256) {
-        unsigned long long m = masks[w];
-        if (m == 0) {
-            continue;
+    uint2* q = list[wave];
+    int cnt = 0;  // entries waiting in q (wave-uniform)
+    auto emit = [&](int count) {  // the first `count` (<= 64) entries of q
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < count) {
+            const uint2 e = q[lane];
+            const int x = static_cast<int>(e.x & 0xffffu);
+            const int y = static_cast<int>(e.x >> 16);
+            const int score = corner_score(img, v.pitch, x, y);
+            xy[e.y] = e.x;
+            keys[e.y] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | e.y;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int wbase = bx * 256 + wave * 64; wbase < n; wbase += blocks_per_frame * 256) {  // wave-uniform
+        const int w = wbase + lane;
+        unsigned long long m = w < n ? masks[w] : 0ull;
         const int row = w / v.nw;
         const int x0 = (w - row * v.nw) * 64;
-        uint32_t idx = off[w];
-        const uint8_t* prow = img + static_cast<size_t>(row) * v.pitch + x0;
-        while (m != 0) {
-            const int b = __ffsll(static_cast<long long>(m)) - 1;
-            m &= m - 1;
-            const uint8_t* p = prow + b;
-            const int c = p[0];
-            int score = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int nb = p[CIRC_DY[q] * v.pitch + CIRC_DX[q]];
-                score += abs(nb - c);
+        uint32_t idx = m != 0 ? off[w] : 0u;
+        while (true) {
+            const bool has = m != 0;
+            const unsigned long long bal = __ballot(has);
+            if (bal == 0) {
+                break;
             }
-            xy[idx] = (static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x0 + b);
-            keys[idx] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | idx;
-            ++idx;
+            if (has) {
+                const int b = __ffsll(static_cast<long long>(m)) - 1;
+                m &= m - 1;
+                const int slot = cnt + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                                           static_cast<uint32_t>(bal >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u)));
+                q[slot] = make_uint2((static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x0 + b), idx);
+                ++idx;
+            }
+            cnt += __popcll(bal);
+            if (cnt >= 64) {
+                emit(64);
+                cnt -= 64;
+                if (lane < cnt) {  // move the tail to the front
+                    const uint2 e = q[64 + lane];
+                    q[lane] = e;
+                }
+            }
         }
     }
+    emit(cnt);
 }
 
 }  // namespace
