@@ -22,28 +22,31 @@ namespace slamx {
 namespace {
 
 constexpr int TILE = 256;
-constexpr int EVQ_DEPTH = 24;  // deferred-update queue entries per lane
+constexpr int EVQ_DEPTH = 32;  // deferred-update queue entries per lane
 
 // WORDS = 32-bit words compared per descriptor (the "live" prefix: words that can be non-zero in
 // either set; the all-zero tail contributes popcount(0^0) = 0 and is skipped -- exact).
-// STRIDE words separate consecutive descriptors in memory.  QPL = queries per lane.
+// STRIDE words separate consecutive descriptors in memory.  QPL = queries per lane (2 or 4): a
+// train descriptor read from LDS is compared with QPL queries, which spreads the loop, filter and
+// queue overhead (more than half of the instructions at QPL = 2) over more pairs.
 //
 // A pair can only change (best, second) if its distance is < second, and the jump penalty only
 // ever increases the distance, so the Hamming distance alone filters: raw >= second => the pair
 // is dropped.  About 2 % of the pairs pass (`second` tightens like a record sequence), i.e. almost
 // every 64-lane wave has SOME lane that passes at every step, so handling a pass on the spot would
-// run the penalty arithmetic at 1/64 lane utilisation.  Instead every lane appends its passes
-// (raw distance, train index, which of its queries) to a private LDS queue, and the wave drains
-// all queues together when one fills up or the train tile ends: lane utilisation of the
-// expensive part rises from ~2 % to ~40 %.  The filter then uses a slightly stale `second`
-// (an upper bound of the current one: a superset passes) and the drain re-applies the exact
+// run the penalty arithmetic at 1/64 lane utilisation.  Instead every lane appends the train index
+// of a step in which one of its queries passed to a private LDS queue, and the wave drains all
+// queues together when one fills up or the train tile ends: lane utilisation of the expensive part
+// rises from ~2 % to ~40 %.  The filter then uses a slightly stale `second` (an upper bound of the
+// current one: a superset passes) and the drain recomputes the distances and re-applies the exact
 // update rule in ascending train order per query, so the result is the sequential scan's.
 template <int WORDS, int QPL>
 __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame,
                                                     int stride, int npairs, int qblocks) {
+    static_assert(QPL == 2 || QPL == 4, "queries are filtered in packed pairs");
     __shared__ uint32_t tdesc[TILE * WORDS];
     __shared__ float2 txy[TILE];
-    __shared__ uint32_t evq[4][EVQ_DEPTH * 64];  // per wave: entry k of lane l at [k * 64 + l]
+    __shared__ uint16_t evq[4][EVQ_DEPTH * 64];  // per wave: entry k of lane l at [k * 64 + l]
     // 1-D grid, pair index fastest: workgroups are dealt to the 8 XCDs round-robin in launch order,
     // so a grid with the query-block index fastest (8 blocks per pair, the last ones empty) would
     // leave whole XCDs idle; this way every XCD gets the same mix and the blocks of one pair share
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     const int lane = threadIdx.x & 63;
     // the last workgroup of a frame is mostly empty (2087 queries = 4 x 512 + 39): its idle waves skip the scan
     const bool wave_has_queries = block_first + static_cast<int>(threadIdx.x & ~63u) < n1;
-    uint32_t* myq = evq[threadIdx.x >> 6] + lane;
+    uint16_t* myq = evq[threadIdx.x >> 6] + lane;
     int qcnt = 0;  // entries in this lane's queue
     // one (query u, train t) pair through the reference's update (feature_matcher.cpp:132-141,
     // penalty :161-170); t is tile-relative
@@ -116,31 +119,70 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             best[u] = lt ? dist : best[u];
         }
     };
-    // every lane replays its own queue in push order (= ascending train index per query); an entry
-    // carries the raw distances of BOTH of the lane's queries to one train descriptor
-    // (d0 | d1 << 10 | t << 20; distances <= 512) and apply() re-tests each against the now-current `second`
-    static_assert(QPL == 2, "the packed two-query filter below assumes two queries per lane");
-    uint32_t second_pk = 0xffffffffu;  // min(second[u], 0xffff) in two 16-bit halves: the (stale) filter bound
+    // min(second[u], 0xffff) of two queries per dword: the (stale) filter bounds
+    uint32_t second_pk[QPL / 2];
+#pragma unroll
+    for (int h = 0; h < QPL / 2; ++h) {
+        second_pk[h] = 0xffffffffu;
+    }
+    // every lane replays its own queue in push order (= ascending train index); an entry is the
+    // tile-relative train index, the distances to the lane's queries are recomputed from the LDS
+    // tile and apply() re-tests each against the now-current `second`
     auto drain = [&](int t0) {
         for (int k = 0; __ballot(k < qcnt) != 0; ++k) {
             if (k < qcnt) {
-                const uint32_t e = myq[k * 64];
-                const int t = static_cast<int>(e >> 20);
-                apply(static_cast<int>(e & 0x3ffu), t, 0, t0);
-                apply(static_cast<int>((e >> 10) & 0x3ffu), t, 1, t0);
+                const int t = myq[k * 64];
+                uint32_t tw[WORDS];
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) {
+                    tw[w] = tdesc[t * WORDS + w];
+                }
+#pragma unroll
+                for (int u = 0; u < QPL; ++u) {
+                    int dd = 0;
+#pragma unroll
+                    for (int w = 0; w < WORDS; ++w) {
+                        dd += __popc(q[u][w] ^ tw[w]);
+                    }
+                    apply(dd, t, u, t0);
+                }
             }
         }
         qcnt = 0;
-        second_pk = static_cast<uint32_t>(min(second[0], 0xffff)) | (static_cast<uint32_t>(min(second[1], 0xffff)) << 16);
+#pragma unroll
+        for (int h = 0; h < QPL / 2; ++h) {
+            second_pk[h] = static_cast<uint32_t>(min(second[2 * h], 0xffff)) |
+                           (static_cast<uint32_t>(min(second[2 * h + 1], 0xffff)) << 16);
+        }
     };
-    // d0 < second[0] or d1 < second[1], both halves at once: saturating packed subtract
-    auto passes = [&](int d0, int d1) {
+    // some d[u] < second[u], two queries per packed saturating subtract
+    auto passes = [&](const int* dq) {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const us2 dpk = __builtin_bit_cast(us2, static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 16));
-        const us2 spk = __builtin_bit_cast(us2, second_pk);
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(spk, dpk)) != 0u;
+        uint32_t any = 0;
+#pragma unroll
+        for (int h = 0; h < QPL / 2; ++h) {
+            const us2 dpk = __builtin_bit_cast(us2, static_cast<uint32_t>(dq[2 * h]) | (static_cast<uint32_t>(dq[2 * h + 1]) << 16));
+            const us2 spk = __builtin_bit_cast(us2, second_pk[h]);
+            any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(spk, dpk));
+        }
+        return any != 0u;
     };
-    // this workgroup scans train chunk blockIdx.z of mv.nsplit (merged in order by emit_kernel)
+    auto step = [&](const uint32_t* tw, int j) {  // one train descriptor against the lane's queries
+        int dq[QPL];
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            dq[u] = 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) {
+                dq[u] += __popc(q[u][w] ^ tw[w]);
+            }
+        }
+        if (passes(dq)) {  // against a stale upper bound of the true `second`
+            myq[qcnt * 64] = static_cast<uint16_t>(j);
+            ++qcnt;
+        }
+    };
+    // this workgroup scans train chunk `split` of mv.nsplit (merged in order by emit_kernel)
     const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
     const int t_begin = split * chunk;
     const int t_end = min(n2, t_begin + chunk);
@@ -173,34 +215,19 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             }
 #pragma unroll
             for (int k = 0; k < JB; ++k) {
-                int d0 = 0, d1 = 0;
-#pragma unroll
-                for (int w = 0; w < WORDS; ++w) {
-                    d0 += __popc(q[0][w] ^ t[k][w]);
-                    d1 += __popc(q[1][w] ^ t[k][w]);
-                }
-                if (passes(d0, d1)) {  // against a stale upper bound of the true `second`
-                    myq[qcnt * 64] = static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 10) |
-                                     (static_cast<uint32_t>(j + k) << 20);
-                    ++qcnt;
-                }
+                step(t[k], j + k);
             }
             if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {  // wave-uniform
                 drain(t0);
             }
         }
         for (; j < tn; ++j) {
-            int d0 = 0, d1 = 0;
+            uint32_t t[WORDS];
 #pragma unroll
             for (int w = 0; w < WORDS; ++w) {
-                d0 += __popc(q[0][w] ^ tdesc[j * WORDS + w]);
-                d1 += __popc(q[1][w] ^ tdesc[j * WORDS + w]);
+                t[w] = tdesc[j * WORDS + w];
             }
-            if (passes(d0, d1)) {
-                myq[qcnt * 64] = static_cast<uint32_t>(d0) | (static_cast<uint32_t>(d1) << 10) |
-                                 (static_cast<uint32_t>(j) << 20);
-                ++qcnt;
-            }
+            step(t, j);
             if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {
                 drain(t0);
             }
@@ -342,7 +369,7 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
 
 template <int WORDS>
 void launch_words(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame, hipStream_t stream) {
-    constexpr int QPL = 2;
+    constexpr int QPL = 2;  // 4 per lane measured slower (0.55 vs 0.40 ms): longer drains, fewer waves
     const int qblocks = (mv.maxK + TILE * QPL - 1) / (TILE * QPL);
     dim3 grid(static_cast<unsigned>(qblocks) * npairs * mv.nsplit);
     hipLaunchKernelGGL((match_kernel<WORDS, QPL>), grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame,
