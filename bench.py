@@ -123,7 +123,9 @@ def pmc_traffic_bytes(kernel, batch):
     for line in open(path).read().splitlines()[1:]:
         parts = line.rsplit(",", 2)
         if len(parts) == 3 and parts[0].split("<")[0] == name:
-            return (float(parts[1]) + float(parts[2])) * 1024.0
+            # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section):
+            # doubled here as that guide prescribes; WRITE_SIZE is exact
+            return (2.0 * float(parts[1]) + float(parts[2])) * 1024.0
     return None
 
 
@@ -257,7 +259,9 @@ def main():
             "fast": px + px / 8.0,                 # frame read, corner bitmap written
             "scan": 12.0 * px / 64,                # bitmap words read, prefix written
             "expand": 8.0 * px / 64 + 17 * M + 8 * M,
-            "sort": 16.0 * M, "nms_build": 16.0 * M + 64.0 * M, "nms_rounds": 16.0 * M,
+            "sort": 16.0 * M,                      # keys read, sorted keys + sorted (x,y) written, (x,y) gathered
+            "nms_build": 9.0 * M + 28.0 * N,       # greedy NMS: sorted key + (x,y) read, state byte, keypoint + slot written
+            "nms_rounds": 4.0 * M,                 # (only the generic NMS path has rounds: ~0 on the greedy path)
             "blur": 2.0 * px,                      # frame read, blurred frame written
             "moments": 961.0 * N + 8 * N, "trig": 16.0 * N + 12 * N,
             "brief": 43 * 48.0 * N + 32 * N,       # 43 x 48-byte neighbourhood read, descriptor written
@@ -265,7 +269,7 @@ def main():
         }
         dom = max(stage, key=lambda k: stage[k])
         kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
-                     "brief": "brief_kernel", "nms_build": "nms_build_kernel", "sort": "sort_kernel",
+                     "brief": "brief_kernel", "nms_build": "nms_greedy_kernel", "sort": "sort_kernel",
                      "moments": "moments_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
         if dom == "match":
             # executed algorithmic work: xor + popcount-accumulate per live 32-bit word per pair;
@@ -283,10 +287,10 @@ def main():
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_per_launch": byts, "traffic": None}
         roof["avg_launch_ms"] = stage[dom]
         # HBM traffic per launch from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-        # separate runs of this same command, profiles/r01_pmc_hbm_traffic_b256.csv).  Calibration
-        # on blur_kernel, whose traffic is known (one frame read, one frame written): FETCH_SIZE
-        # reads 0.97x and WRITE_SIZE 1.00x the true bytes for this code's 4-byte-per-lane accesses,
-        # so no x2 correction is applied (the halving in MI355X_MICROARCH.md is for 16 B/lane streams).
+        # separate runs of this same command by tools/collect_profiles.sh ->
+        # profiles/r01_pmc_hbm_traffic_b256.csv), FETCH_SIZE doubled as the guide prescribes for
+        # gfx950.  Check on fast_detect_kernel, whose compulsory traffic is known (every frame byte
+        # once): 2 x 259 MB = 519 MB against 531 MB of frames.
         roof["traffic"] = pmc_traffic_bytes(roof["kernel"], B)
         # every other kernel against its own roofline, for the record
         others = {}
