@@ -65,6 +65,10 @@ __device__ __forceinline__ int select64d(unsigned long long m, int k) {
     return pos;
 }
 
+__device__ __forceinline__ unsigned long long low_mask_d(int nbits) {  // bits [0, nbits)
+    return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -236,6 +240,24 @@ struct TilePrefetch {
                 val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
             }
             reg[k] = val;
+        }
+    }
+    // same for a tile that lies entirely inside the padded frame (the caller checks): off[k] is the
+    // byte offset of this lane's k-th dword from the tile's first byte, computed once per wave
+    __device__ __forceinline__ void init_offsets(int pitch, int lane, int* off) const {
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            const int ee = e < ROWS * DW ? e : 0;
+            const int r = ee / DW;
+            off[k] = r * pitch + (ee - r * DW) * 4;
+        }
+    }
+    __device__ __forceinline__ void issue_inside(const uint8_t* img, int pitch, int x, int y, const int* off) {
+        const uint8_t* base = img + static_cast<size_t>(y - HALF) * pitch + ((x - HALF) & ~3);
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            reg[k] = *reinterpret_cast<const uint32_t*>(base + off[k]);
         }
     }
     __device__ __forceinline__ void commit(uint32_t* tile, int lane) const {
@@ -452,6 +474,18 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
         q2y = static_cast<float>(pattern[4 * lane + 3]);
     }
     TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
+    int tile_off[TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF>::PER_LANE];
+    pf.init_offsets(v.pitch, lane, tile_off);
+    auto fetch = [&](int x, int y) {  // wave-uniform choice: no per-element bounds checks when the tile is inside
+        const int xa = (x - TILE_HALF) & ~3;
+        if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
+            pf.issue_inside(img, v.pitch, x, y, tile_off);
+        } else {
+            pf.issue(v, img, x, y, lane);
+        }
+    };
+    const bool one_chunk = P.pattern_len <= 64 && (v.width & 7) == 0;
+    const unsigned long long all_pairs = low_mask_d(P.pattern_len < 64 ? P.pattern_len : 64);
     for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform
         const int mine = i0 + (chunk + lane) * stride;
         int kx = 0, ky = 0, kslot = 0;
@@ -470,15 +504,16 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
         float ca = __shfl(kc, 0);
         float sa = __shfl(ks, 0);
         if (ca == ca) {
-            pf.issue(v, img, x, y, lane);
+            fetch(x, y);
         }
         for (int k = 0; k < cnt; ++k) {
             const int i = __shfl(kslot, k);
             uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
             const bool inside = ca == ca;  // NaN cos marks "patch leaves the image" (wave-uniform)
-            if (lane < words) {
+            if (!one_chunk && lane < words) {
                 dbuf[wave][lane] = 0ull;
             }
+            unsigned long long first_word = 0;  // the descriptor itself when the pattern fits one chunk
             if (inside) {
                 pf.commit(tile[wave], lane);
             }
@@ -487,7 +522,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
             const float can = __shfl(kc, (k + 1) & 63);
             const float san = __shfl(ks, (k + 1) & 63);
             if (k + 1 < cnt && can == can) {
-                pf.issue(v, img, xn, yn, lane);
+                fetch(xn, yn);
             }
             if (inside) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -522,12 +557,17 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
                     const unsigned long long vm = __ballot(valid);
                     const unsigned long long bm = __ballot(valid && bit);
                     const int c2 = __popcll(vm);
-                    bool outbit = false;
-                    if (lane < c2) {
-                        outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                    unsigned long long packed = bm;  // every pair of the chunk valid: nothing to close up
+                    if (vm != (base == 0 ? all_pairs : low_mask_d(min(64, P.pattern_len - base)))) {
+                        bool outbit = false;
+                        if (lane < c2) {
+                            outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                        }
+                        packed = __ballot(outbit);
                     }
-                    const unsigned long long packed = __ballot(outbit);
-                    if (lane == 0 && c2 > 0) {
+                    if (one_chunk) {
+                        first_word = packed;
+                    } else if (lane == 0 && c2 > 0) {
                         const int w = bitIndex >> 6;
                         const int sh = bitIndex & 63;
                         dbuf[wave][w] |= packed << sh;
@@ -538,14 +578,20 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
                     bitIndex += c2;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint8_t* d8 = reinterpret_cast<const uint8_t*>(dbuf[wave]);
-            for (int b = lane; b < v.width; b += 64) {
-                desc[b] = d8[b];
+            if (one_chunk) {
+                if (lane < words) {  // descriptor rows are 8-byte aligned (width % 8 == 0)
+                    reinterpret_cast<unsigned long long*>(desc)[lane] = lane == 0 ? first_word : 0ull;
+                }
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint8_t* d8 = reinterpret_cast<const uint8_t*>(dbuf[wave]);
+                for (int b = lane; b < v.width; b += 64) {
+                    desc[b] = d8[b];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             x = xn;
             y = yn;
             ca = can;
