@@ -14,6 +14,8 @@ Workloads (BASELINE.json): the metric is quoted on "1080p @ 2k feats/frame", whi
 default; `c2` = configs[1] (640x480, ~2000 keypoints), `c3` = configs[2] (1080p, ~10k keypoints).
 The reference has no feature-count knob, so counts are reached through the synthetic corner
 density and SuppressionWindowSize; the realised candidates M / keypoints N are in the JSON.
+Frames per step (512 / 1024 / 256): the sort and the NMS run one workgroup per frame, so a batch
+must be a multiple of the 256 CUs -- and of 2 x 256 where two of them fit a CU -- to keep the chip full.
 
 Multi-GPU: frames shard embarrassingly (one independent stream per rank, seed + rank), no
 data-path collective; at the end of the timed job every rank triangulates its newest frame pair
@@ -34,11 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 WORKLOADS = {
     # name: rows, cols, window, n_rect, rect_min, rect_max, batch, max_candidates, max_keypoints
-    "1080p_2k": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=256, max_cand=32768, max_kp=4096,
+    "1080p_2k": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=512, max_cand=32768, max_kp=4096,
                      desc="1920x1080, ~2k keypoints/frame (shipped YAML: t=20 N=12 window=12), detect+describe+match-to-previous"),
-    "c2": dict(rows=480, cols=640, window=6, n_rect=5000, rmin=3, rmax=16, batch=256, max_cand=32768, max_kp=4096,
+    "c2": dict(rows=480, cols=640, window=6, n_rect=5000, rmin=3, rmax=16, batch=1024, max_cand=32768, max_kp=4096,
                desc="640x480, ~2k keypoints/frame (SuppressionWindowSize 6), detect+describe+match-to-previous"),
-    "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=64, max_cand=131072, max_kp=16384,
+    "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=256, max_cand=131072, max_kp=16384,
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
 }
 SEED = 0x5EED0051
@@ -115,17 +117,20 @@ def triangulate_last_pair(ctx, batch, matcher, B, cols, rows):
 
 
 def pmc_traffic_bytes(kernel, batch):
-    """FETCH_SIZE + WRITE_SIZE (KB) of one launch of `kernel`, measured offline at batch 256."""
+    """2 x FETCH_SIZE + WRITE_SIZE of one launch of `kernel`: measured offline at 256 frames per launch
+    (tools/collect_profiles.sh) and scaled to `batch` frames -- the per-frame traffic of these kernels
+    does not depend on the batch."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_b256.csv")
-    if batch != 256 or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
+    scale = batch / 256.0
     name = kernel.split("<")[0]
     for line in open(path).read().splitlines()[1:]:
         parts = line.rsplit(",", 2)
         if len(parts) == 3 and parts[0].split("<")[0] == name:
             # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section):
             # doubled here as that guide prescribes; WRITE_SIZE is exact
-            return (2.0 * float(parts[1]) + float(parts[2])) * 1024.0
+            return (2.0 * float(parts[1]) + float(parts[2])) * 1024.0 * scale
     return None
 
 

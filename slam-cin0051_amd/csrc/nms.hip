@@ -657,8 +657,11 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
             (void)once2;
             const uint32_t magic = static_cast<uint32_t>(((1ull << 32) + p.window - 1) / p.window);
             // the hashed survivor table takes what is left of the LDS budget (a power of two of dwords)
+            // (a power of two of dwords), but at most half of a CU's 160 KB when that is within reach, so that
+            // two frames share a CU in batches of more than 256 frames
+            const size_t budget = bytes + 4096 * 4 <= 80 * 1024 ? 80 * 1024 : static_cast<size_t>(GREEDY_LDS_BUDGET);
             int tab_entries = 256;
-            while (tab_entries < 16384 && bytes + static_cast<size_t>(tab_entries) * 8 <= static_cast<size_t>(GREEDY_LDS_BUDGET)) {
+            while (tab_entries < 16384 && bytes + static_cast<size_t>(tab_entries) * 8 <= budget) {
                 tab_entries *= 2;
             }
             const size_t total = bytes + static_cast<size_t>(tab_entries) * 4;

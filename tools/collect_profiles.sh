@@ -9,12 +9,13 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 3 > "$out/bench_1080p_2k_b256.json"
+python bench.py --steps 10 --warmup 2 > "$out/bench_1080p_2k.json"
+python bench.py --batch 256 --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench_1080p_2k_b256.json"
 python bench.py --workload c2 --steps 20 --warmup 3 > "$out/bench_c2.json"
 python bench.py --workload c3 --steps 10 --warmup 2 > "$out/bench_c3.json"
-rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o write --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$out/bench_under_rocprof.json"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o write --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
 python tools/pmc_summary.py "$out/pmc_fetch/fetch_counter_collection.csv" > "$out/pmc_fetch.csv"
 python tools/pmc_summary.py "$out/pmc_write/write_counter_collection.csv" > "$out/pmc_write.csv"
 ls -la "$out"
