@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     const int lane = threadIdx.x & 63;
     // the last workgroup of a frame is mostly empty (2087 queries = 4 x 512 + 39): its idle waves skip the scan
     const bool wave_has_queries = block_first + static_cast<int>(threadIdx.x & ~63u) < n1;
-    uint16_t* myq = evq[threadIdx.x >> 6] + lane;
-    int qcnt = 0;  // entries in this lane's queue
+    // LDS address space spelled out: the queue cursor then is a 32-bit offset, not a 64-bit flat pointer
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    lds_u16* const myq = (lds_u16*)(evq[threadIdx.x >> 6] + lane);
+    lds_u16* qend = myq;  // one past this lane's last queue entry (entries are 64 elements apart)
     // one (query u, train t) pair through the reference's update (feature_matcher.cpp:132-141,
     // penalty :161-170); t is tile-relative
     auto apply = [&](int dist, int t, int u, int t0) {
@@ -119,19 +121,19 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             best[u] = lt ? dist : best[u];
         }
     };
-    // min(second[u], 0xffff) of two queries per dword: the (stale) filter bounds
-    uint32_t second_pk[QPL / 2];
+    // the (stale) filter bounds: `second` as of the last drain
+    int bound[QPL];
 #pragma unroll
-    for (int h = 0; h < QPL / 2; ++h) {
-        second_pk[h] = 0xffffffffu;
+    for (int u = 0; u < QPL; ++u) {
+        bound[u] = 0x7fffffff;
     }
     // every lane replays its own queue in push order (= ascending train index); an entry is the
     // tile-relative train index, the distances to the lane's queries are recomputed from the LDS
     // tile and apply() re-tests each against the now-current `second`
     auto drain = [&](int t0) {
-        for (int k = 0; __ballot(k < qcnt) != 0; ++k) {
-            if (k < qcnt) {
-                const int t = myq[k * 64];
+        for (const lds_u16* e = myq; __ballot(e < qend) != 0; e += 64) {
+            if (e < qend) {
+                const int t = *e;
                 uint32_t tw[WORDS];
 #pragma unroll
                 for (int w = 0; w < WORDS; ++w) {
@@ -148,24 +150,21 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
                 }
             }
         }
-        qcnt = 0;
+        qend = myq;
 #pragma unroll
-        for (int h = 0; h < QPL / 2; ++h) {
-            second_pk[h] = static_cast<uint32_t>(min(second[2 * h], 0xffff)) |
-                           (static_cast<uint32_t>(min(second[2 * h + 1], 0xffff)) << 16);
+        for (int u = 0; u < QPL; ++u) {
+            bound[u] = second[u];
         }
     };
-    // some d[u] < second[u], two queries per packed saturating subtract
+    // some d[u] < bound[u]: one VOPC compare per query, combined on the scalar side (a packed 16-bit
+    // subtract of two queries at once costs two VOP3 instructions, i.e. more issue cycles)
     auto passes = [&](const int* dq) {
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        uint32_t any = 0;
+        bool any = false;
 #pragma unroll
-        for (int h = 0; h < QPL / 2; ++h) {
-            const us2 dpk = __builtin_bit_cast(us2, static_cast<uint32_t>(dq[2 * h]) | (static_cast<uint32_t>(dq[2 * h + 1]) << 16));
-            const us2 spk = __builtin_bit_cast(us2, second_pk[h]);
-            any |= __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(spk, dpk));
+        for (int u = 0; u < QPL; ++u) {
+            any = any | (dq[u] < bound[u]);
         }
-        return any != 0u;
+        return any;
     };
     auto step = [&](const uint32_t* tw, int j) {  // one train descriptor against the lane's queries
         int dq[QPL];
@@ -178,8 +177,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             }
         }
         if (passes(dq)) {  // against a stale upper bound of the true `second`
-            myq[qcnt * 64] = static_cast<uint16_t>(j);
-            ++qcnt;
+            *qend = static_cast<uint16_t>(j);
+            qend += 64;
         }
     };
     // this workgroup scans train chunk `split` of mv.nsplit (merged in order by emit_kernel)
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             for (int k = 0; k < JB; ++k) {
                 step(t[k], j + k);
             }
-            if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {  // wave-uniform
+            if (__ballot(qend > myq + (EVQ_DEPTH - JB) * 64) != 0) {  // wave-uniform
                 drain(t0);
             }
         }
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
                 t[w] = tdesc[j * WORDS + w];
             }
             step(t, j);
-            if (__ballot(qcnt > EVQ_DEPTH - JB) != 0) {
+            if (__ballot(qend > myq + (EVQ_DEPTH - JB) * 64) != 0) {
                 drain(t0);
             }
         }
