@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
             qy[u] = k.y;
         }
     }
-    constexpr int JB = 4;
+    constexpr int JB = 8;
     const int lane = threadIdx.x & 63;
     // the last workgroup of a frame is mostly empty (2087 queries = 4 x 512 + 39): its idle waves skip the scan
     const bool wave_has_queries = block_first + static_cast<int>(threadIdx.x & ~63u) < n1;
