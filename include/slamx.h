@@ -220,6 +220,18 @@ int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p
  * GPU launches, first maximum wins.  max_inliers == 0 leaves R = I, t = 0 as the reference does. */
 int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, int iterations,
                      double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers);
+/* Essential matrix by RANSAC, the step PoseEstimator::estimate delegates to cv::findEssentialMat
+ * (src/frontend/pose_estimator.cpp:37-47; third-party in the reference, so this is the build's own
+ * estimator: normalised 8-point hypotheses, Sampson-distance scoring, all hypotheses solved and scored
+ * in two launches).  pts1/pts2: n x 2 float PIXEL coordinates of the matched keypoints, K 3x3
+ * row-major; threshold_px is divided by the mean focal length as OpenCV does; sampling as in the
+ * reference's own RANSAC (std::mt19937 + uniform_int_distribution, distinct indices) from `seed`.
+ * Out: E 3x3 row-major with singular values (1,1,0), the inlier count of the winning hypothesis (first
+ * maximum) and optionally one flag per correspondence.  n < 8 -> SLAMX_ERR_INVALID_ARGUMENT
+ * (pose_estimator.cpp:21-25).  Feed E to slamx_recover_pose with the normalised points. */
+int slamx_essential_ransac(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K, int iterations,
+                           double threshold_px, uint32_t seed, double* E, int32_t* n_inliers, uint8_t* inlier_mask);
+
 /* simpleRecoverPose (simple_pose_recover.cpp:35-98): E 3x3, pts1/pts2 n x 2 float (normalised
  * points as PoseEstimator::estimate passes them), K 3x3 -> R 3x3, t 3; front (optional) gets the
  * four cheirality counts. */

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <vector>
 
 namespace {
@@ -348,6 +349,202 @@ void oracle_triangulate(const double* P1, const double* P2, const float* pts1, c
             xyz[3 * i + k] = static_cast<double>(xf[k] * alpha);
         }
     }
+}
+
+// f3: the essential-matrix RANSAC of this build (cv::findEssentialMat, pose_estimator.cpp:37-47, is
+// third-party: PARITY UNPINNED BY THE REFERENCE).  CPU restatement of the algorithm the HIP path
+// runs -- same sampling, same conditioning, null vector by the one-sided Jacobi SVD, same Sampson
+// test -- used to check the GPU implementation, not to pin it against OpenCV.
+// pts: n x 2 float pixel coordinates.  E_all (optional): iterations x 9, counts_all (optional).
+int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const double* K, int iterations,
+                            double threshold_px, unsigned seed, double* E, int* n_inliers, unsigned char* mask,
+                            double* E_all, int* counts_all) {
+    if (n < 8 || iterations <= 0) {
+        return -1;
+    }
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    std::vector<double> x1(static_cast<size_t>(n) * 2), x2(static_cast<size_t>(n) * 2);
+    for (int i = 0; i < n; ++i) {
+        x1[2 * i] = (static_cast<double>(pts1[2 * i]) - cx) / fx;
+        x1[2 * i + 1] = (static_cast<double>(pts1[2 * i + 1]) - cy) / fy;
+        x2[2 * i] = (static_cast<double>(pts2[2 * i]) - cx) / fx;
+        x2[2 * i + 1] = (static_cast<double>(pts2[2 * i + 1]) - cy) / fy;
+    }
+    std::mt19937 rng(seed);
+    std::uniform_int_distribution<int> dist(0, n - 1);
+    const double thr = threshold_px / (0.5 * (fx + fy));
+    const double thr2 = thr * thr;
+    int best = -1, best_count = -1;
+    std::vector<double> Ebest(9, 0.0);
+    auto count = [&](const double* e, unsigned char* flags) {
+        int c = 0;
+        for (int i = 0; i < n; ++i) {
+            const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+            const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
+            const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
+            const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
+            const double et0 = e[0] * u2 + e[3] * v2 + e[6];
+            const double et1 = e[1] * u2 + e[4] * v2 + e[7];
+            const double r = u2 * ex0 + v2 * ex1 + ex2;
+            const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+            const bool in = den > 0.0 && r * r < thr2 * den;
+            c += in ? 1 : 0;
+            if (flags != nullptr) {
+                flags[i] = in ? 1 : 0;
+            }
+        }
+        return c;
+    };
+    for (int it = 0; it < iterations; ++it) {
+        int idx[8];
+        int have = 0;
+        while (have < 8) {
+            const int c = dist(rng);
+            if (std::find(idx, idx + have, c) == idx + have) {
+                idx[have++] = c;
+            }
+        }
+        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+        for (int i = 0; i < 8; ++i) {
+            c1x += x1[2 * idx[i]];
+            c1y += x1[2 * idx[i] + 1];
+            c2x += x2[2 * idx[i]];
+            c2y += x2[2 * idx[i] + 1];
+        }
+        c1x /= 8.0;
+        c1y /= 8.0;
+        c2x /= 8.0;
+        c2y /= 8.0;
+        double d1 = 0, d2 = 0;
+        for (int i = 0; i < 8; ++i) {
+            const double ux = x1[2 * idx[i]] - c1x, uy = x1[2 * idx[i] + 1] - c1y;
+            const double vx = x2[2 * idx[i]] - c2x, vy = x2[2 * idx[i] + 1] - c2y;
+            d1 += std::sqrt(ux * ux + uy * uy);
+            d2 += std::sqrt(vx * vx + vy * vy);
+        }
+        const double s1 = d1 > 0.0 ? std::sqrt(2.0) * 8.0 / d1 : 1.0;
+        const double s2 = d2 > 0.0 ? std::sqrt(2.0) * 8.0 / d2 : 1.0;
+        double A[9 * 9] = {0};  // 8 constraint rows + a zero row: the one-sided Jacobi wants m >= n
+        for (int r = 0; r < 8; ++r) {
+            const double p1[3] = {(x1[2 * idx[r]] - c1x) * s1, (x1[2 * idx[r] + 1] - c1y) * s1, 1.0};
+            const double p2[3] = {(x2[2 * idx[r]] - c2x) * s2, (x2[2 * idx[r] + 1] - c2y) * s2, 1.0};
+            for (int c = 0; c < 9; ++c) {
+                A[r * 9 + c] = p2[c / 3] * p1[c % 3];
+            }
+        }
+        double U[81], S[9], V[81];
+        svd_jacobi(9, 9, A, U, S, V);
+        double En[9];
+        for (int k = 0; k < 9; ++k) {
+            En[k] = V[k * 9 + 8];
+        }
+        const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+        const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
+        double tmp[9], E0[9], U3[9], S3[3], V3[9], Vt3[9], UD[9], Ef[9];
+        mul3(En, T1, tmp);
+        mul3(T2t, tmp, E0);
+        svd3(E0, U3, S3, V3);
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                Vt3[i * 3 + j] = V3[j * 3 + i];
+            }
+        }
+        const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+        mul3(U3, D, UD);
+        mul3(UD, Vt3, Ef);
+        const int c = count(Ef, nullptr);
+        if (E_all != nullptr) {
+            std::copy(Ef, Ef + 9, E_all + static_cast<size_t>(it) * 9);
+        }
+        if (counts_all != nullptr) {
+            counts_all[it] = c;
+        }
+        if (c > best_count) {
+            best_count = c;
+            best = it;
+            std::copy(Ef, Ef + 9, Ebest.begin());
+        }
+    }
+    // refit on the inliers of the winner (normal equations of the conditioned 8-point system), kept
+    // only if it explains at least as many correspondences
+    std::vector<unsigned char> flags(static_cast<size_t>(n)), flags2(static_cast<size_t>(n));
+    count(Ebest.data(), flags.data());
+    double Efit[9];
+    std::copy(Ebest.begin(), Ebest.end(), Efit);
+    if (best_count >= 8) {
+        double c1x = 0, c1y = 0, c2x = 0, c2y = 0, cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            if (flags[i]) {
+                c1x += x1[2 * i];
+                c1y += x1[2 * i + 1];
+                c2x += x2[2 * i];
+                c2y += x2[2 * i + 1];
+                cnt += 1.0;
+            }
+        }
+        c1x /= cnt;
+        c1y /= cnt;
+        c2x /= cnt;
+        c2y /= cnt;
+        double d1 = 0, d2 = 0;
+        for (int i = 0; i < n; ++i) {
+            if (flags[i]) {
+                const double ux = x1[2 * i] - c1x, uy = x1[2 * i + 1] - c1y;
+                const double vx = x2[2 * i] - c2x, vy = x2[2 * i + 1] - c2y;
+                d1 += std::sqrt(ux * ux + uy * uy);
+                d2 += std::sqrt(vx * vx + vy * vy);
+            }
+        }
+        const double s1 = d1 > 0.0 ? std::sqrt(2.0) * cnt / d1 : 1.0;
+        const double s2 = d2 > 0.0 ? std::sqrt(2.0) * cnt / d2 : 1.0;
+        double G[81] = {0};
+        for (int i = 0; i < n; ++i) {
+            if (!flags[i]) {
+                continue;
+            }
+            const double p1[3] = {(x1[2 * i] - c1x) * s1, (x1[2 * i + 1] - c1y) * s1, 1.0};
+            const double p2[3] = {(x2[2 * i] - c2x) * s2, (x2[2 * i + 1] - c2y) * s2, 1.0};
+            double a[9];
+            for (int c = 0; c < 9; ++c) {
+                a[c] = p2[c / 3] * p1[c % 3];
+            }
+            for (int r = 0; r < 9; ++r) {
+                for (int c = 0; c < 9; ++c) {
+                    G[r * 9 + c] += a[r] * a[c];
+                }
+            }
+        }
+        double U[81], S[9], V[81];
+        svd_jacobi(9, 9, G, U, S, V);
+        double En[9];
+        for (int k = 0; k < 9; ++k) {
+            En[k] = V[k * 9 + 8];
+        }
+        const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+        const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
+        double tmp[9], E0[9], U3[9], S3[3], V3[9], Vt3[9], UD[9];
+        mul3(En, T1, tmp);
+        mul3(T2t, tmp, E0);
+        svd3(E0, U3, S3, V3);
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                Vt3[i * 3 + j] = V3[j * 3 + i];
+            }
+        }
+        const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+        mul3(U3, D, UD);
+        mul3(UD, Vt3, Efit);
+    }
+    const int fit_count = count(Efit, flags2.data());
+    const bool use_fit = fit_count >= best_count;
+    std::copy(use_fit ? Efit : Ebest.data(), (use_fit ? Efit : Ebest.data()) + 9, E);
+    if (n_inliers != nullptr) {
+        *n_inliers = use_fit ? fit_count : best_count;
+    }
+    if (mask != nullptr) {
+        std::copy(use_fit ? flags2.begin() : flags.begin(), use_fit ? flags2.end() : flags.end(), mask);
+    }
+    return best;
 }
 
 }  // extern "C"

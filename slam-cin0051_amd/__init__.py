@@ -87,7 +87,7 @@ EXPORTS = [
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
-    "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
+    "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
 ]
 
@@ -151,6 +151,7 @@ def load_library():
     lib.slamx_pnp_dlt_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.slamx_count_inliers_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, vp]
     lib.slamx_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, C.POINTER(C.c_int32)]
+    lib.slamx_essential_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp]
     lib.slamx_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.slamx_camera_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(Camera)]
@@ -301,6 +302,18 @@ class Context:
         _check(self.lib.slamx_pnp_ransac(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), iterations, float(threshold),
                                          seed, _ptr(R), _ptr(t), C.byref(best)))
         return R, t, best.value
+
+    def essential_ransac(self, pts1, pts2, K, iterations=512, threshold_px=1.0, seed=0):
+        """E (3x3), inlier count, inlier mask from n x 2 float pixel correspondences."""
+        a = np.ascontiguousarray(pts1, dtype=np.float32)
+        b = np.ascontiguousarray(pts2, dtype=np.float32)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        E = np.empty((3, 3))
+        cnt = C.c_int32()
+        mask = np.zeros(a.shape[0], np.uint8)
+        _check(self.lib.slamx_essential_ransac(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), iterations,
+                                               float(threshold_px), seed, _ptr(E), C.byref(cnt), _ptr(mask)))
+        return E, cnt.value, mask
 
     def recover_pose(self, E, pts1, pts2, K):
         Ec = np.ascontiguousarray(E, dtype=np.float64)

@@ -286,6 +286,48 @@ __device__ void jacobi_sym(double* G, double* Vp, int n, int lane) {
     }
 }
 
+// Right singular vector of the smallest singular value of w.A (rows x ncols, ncols <= 12, zero padded
+// to 16 columns): three passes of {G = A^T A on MFMA; cyclic Jacobi on G; A <- A Vp, Vt <- Vt Vp}.
+// Returns the column of w.Vt that holds it (wave-uniform).
+__device__ int wave_null_column(PnpWork& w, int rows, int ncols, int lane) {
+    for (int e = lane; e < LD * LD; e += 64) {
+        w.Vt[e] = (e / LD == e % LD) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    for (int pass = 0; pass < 3; ++pass) {
+        mfma_gram(w.A, rows, w.G, lane);
+        for (int e = lane; e < LD * LD; e += 64) {
+            w.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
+        }
+        wave_sync();
+        jacobi_sym(w.G, w.Vp, ncols, lane);
+        mfma_mul(w.A, rows, w.Vp, w.T, lane);
+        wave_sync();
+        for (int e = lane; e < rows * LD; e += 64) {
+            w.A[e] = w.T[e];
+        }
+        mfma_mul(w.Vt, LD, w.Vp, w.T, lane);
+        wave_sync();
+        for (int e = lane; e < LD * LD; e += 64) {
+            w.Vt[e] = w.T[e];
+        }
+        wave_sync();
+    }
+    // smallest singular value: column norms of the final A (= diag of its Gram matrix)
+    mfma_gram(w.A, rows, w.G, lane);
+    wave_sync();
+    int jmin = 0;
+    double smin = w.G[0];
+    for (int j = 1; j < ncols; ++j) {
+        const double dj = w.G[j * LD + j];
+        if (dj < smin) {
+            smin = dj;
+            jmin = j;
+        }
+    }
+    return jmin;
+}
+
 __global__ __launch_bounds__(256) void pnp_dlt_kernel(const double* __restrict__ p3d, const double* __restrict__ p2d,
                                                       int n_points, int n_hyp, double* __restrict__ R_out,
                                                       double* __restrict__ t_out, double* __restrict__ null_out) {
@@ -314,41 +356,7 @@ __global__ __launch_bounds__(256) void pnp_dlt_kernel(const double* __restrict__
             }
             w.A[e] = val;
         }
-        for (int e = lane; e < LD * LD; e += 64) {
-            w.Vt[e] = (e / LD == e % LD) ? 1.0 : 0.0;
-        }
-        wave_sync();
-        for (int pass = 0; pass < 3; ++pass) {
-            mfma_gram(w.A, rows, w.G, lane);
-            for (int e = lane; e < LD * LD; e += 64) {
-                w.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
-            }
-            wave_sync();
-            jacobi_sym(w.G, w.Vp, 12, lane);
-            mfma_mul(w.A, rows, w.Vp, w.T, lane);
-            wave_sync();
-            for (int e = lane; e < rows * LD; e += 64) {
-                w.A[e] = w.T[e];
-            }
-            mfma_mul(w.Vt, LD, w.Vp, w.T, lane);
-            wave_sync();
-            for (int e = lane; e < LD * LD; e += 64) {
-                w.Vt[e] = w.T[e];
-            }
-            wave_sync();
-        }
-        // smallest singular value: column norms of the final A (= diag of its Gram matrix)
-        mfma_gram(w.A, rows, w.G, lane);
-        wave_sync();
-        int jmin = 0;
-        double smin = w.G[0];
-        for (int j = 1; j < 12; ++j) {
-            const double d = w.G[j * LD + j];
-            if (d < smin) {
-                smin = d;
-                jmin = j;
-            }
-        }
+        const int jmin = wave_null_column(w, rows, 12, lane);
         if (lane == 0) {
             double p[12];
             for (int k = 0; k < 12; ++k) {
@@ -541,6 +549,234 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double* __restri
     }
 }
 
+// ---------------- f3: essential matrix from 8 correspondences, one wave per hypothesis ----------------
+// The reference calls cv::findEssentialMat(points1, points2, K, cv::RANSAC) (pose_estimator.cpp:37-47,
+// third-party).  This build's own estimator: normalised 8-point algorithm on K^-1-normalised points
+// (Hartley conditioning of the 8 samples, null vector of the 8 x 9 constraint matrix with the same
+// MFMA Gram / Jacobi iteration as the PnP, projection onto the essential manifold by a 3 x 3 SVD),
+// hypotheses scored by the Sampson distance.  x1, x2: [n_hyp][8][2] normalised sample coordinates.
+__global__ __launch_bounds__(256) void essential_8pt_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                            int n_hyp, double* __restrict__ E_out) {
+    extern __shared__ double pose_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork) / sizeof(double)));
+    for (int h = blockIdx.x * 4 + wave; h < n_hyp; h += gridDim.x * 4) {  // wave-uniform
+        const double* a = x1 + static_cast<size_t>(h) * 16;
+        const double* b = x2 + static_cast<size_t>(h) * 16;
+        // Hartley conditioning: centroid to the origin, mean distance sqrt(2) (every lane computes it)
+        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+        for (int i = 0; i < 8; ++i) {
+            c1x += a[2 * i];
+            c1y += a[2 * i + 1];
+            c2x += b[2 * i];
+            c2y += b[2 * i + 1];
+        }
+        c1x /= 8.0;
+        c1y /= 8.0;
+        c2x /= 8.0;
+        c2y /= 8.0;
+        double d1 = 0, d2 = 0;
+        for (int i = 0; i < 8; ++i) {
+            const double ux = a[2 * i] - c1x, uy = a[2 * i + 1] - c1y;
+            const double vx = b[2 * i] - c2x, vy = b[2 * i + 1] - c2y;
+            d1 += sqrt(ux * ux + uy * uy);
+            d2 += sqrt(vx * vx + vy * vy);
+        }
+        const double s1 = d1 > 0.0 ? sqrt(2.0) * 8.0 / d1 : 1.0;
+        const double s2 = d2 > 0.0 ? sqrt(2.0) * 8.0 / d2 : 1.0;
+        // constraint rows x2^T E x1 = 0, E row-major: [u2 u1, u2 v1, u2, v2 u1, v2 v1, v2, u1, v1, 1]
+        for (int e = lane; e < 8 * LD; e += 64) {
+            const int r = e / LD;
+            const int c = e - r * LD;
+            const double u1 = (a[2 * r] - c1x) * s1, v1 = (a[2 * r + 1] - c1y) * s1;
+            const double u2 = (b[2 * r] - c2x) * s2, v2 = (b[2 * r + 1] - c2y) * s2;
+            const double p1[3] = {u1, v1, 1.0};
+            const double p2[3] = {u2, v2, 1.0};
+            w.A[e] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
+        }
+        wave_sync();
+        const int jmin = wave_null_column(w, 8, 9, lane);
+        if (lane == 0) {
+            double En[9];
+            for (int k = 0; k < 9; ++k) {
+                En[k] = w.Vt[k * LD + jmin];
+            }
+            // undo the conditioning: E = T2^T En T1, T = [s 0 -s cx; 0 s -s cy; 0 0 1]
+            const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+            const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
+            double tmp[9], E0[9];
+            mul3(En, T1, tmp);
+            mul3(T2t, tmp, E0);
+            // nearest essential matrix: singular values (1, 1, 0)
+            double U[9], S[3], V[9], Vt3[9], UD[9], Ef[9];
+            svd3(E0, U, S, V);
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) {
+                    Vt3[i * 3 + j] = V[j * 3 + i];
+                }
+            }
+            const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+            mul3(U, D, UD);
+            mul3(UD, Vt3, Ef);
+            for (int k = 0; k < 9; ++k) {
+                E_out[static_cast<size_t>(h) * 9 + k] = Ef[k];
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Least-squares refit of the winning hypothesis on its inliers (flags): the same conditioned
+// 8-point equations over all inliers, 9 x 9 normal matrix accumulated on MFMA in chunks of 64 rows,
+// smallest eigenvector by cyclic Jacobi, projection onto the essential manifold.  One wave.
+__global__ __launch_bounds__(64) void essential_refit_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                             const uint8_t* __restrict__ flags, int n,
+                                                             double* __restrict__ E_out) {
+    extern __shared__ double pose_lds[];
+    __shared__ double red[64][6];
+    const int lane = threadIdx.x;
+    PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds);
+    // conditioning over the inliers: centroids, then mean distances
+    double acc[6] = {0, 0, 0, 0, 0, 0};  // sum u1, v1, u2, v2, count
+    for (int i = lane; i < n; i += 64) {
+        if (flags[i] != 0) {
+            acc[0] += x1[2 * i];
+            acc[1] += x1[2 * i + 1];
+            acc[2] += x2[2 * i];
+            acc[3] += x2[2 * i + 1];
+            acc[4] += 1.0;
+        }
+    }
+    for (int k = 0; k < 6; ++k) {
+        red[lane][k] = acc[k];
+    }
+    wave_sync();
+    double tot[6] = {0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < 64; ++l) {  // every lane sums in the same order: identical values everywhere
+        for (int k = 0; k < 5; ++k) {
+            tot[k] += red[l][k];
+        }
+    }
+    const double cnt = tot[4];
+    if (cnt < 8.0) {
+        return;  // wave-uniform; E_out keeps the minimal-sample model
+    }
+    const double c1x = tot[0] / cnt, c1y = tot[1] / cnt, c2x = tot[2] / cnt, c2y = tot[3] / cnt;
+    double dd[2] = {0, 0};
+    for (int i = lane; i < n; i += 64) {
+        if (flags[i] != 0) {
+            const double ux = x1[2 * i] - c1x, uy = x1[2 * i + 1] - c1y;
+            const double vx = x2[2 * i] - c2x, vy = x2[2 * i + 1] - c2y;
+            dd[0] += sqrt(ux * ux + uy * uy);
+            dd[1] += sqrt(vx * vx + vy * vy);
+        }
+    }
+    wave_sync();
+    red[lane][0] = dd[0];
+    red[lane][1] = dd[1];
+    wave_sync();
+    double d1 = 0, d2 = 0;
+    for (int l = 0; l < 64; ++l) {
+        d1 += red[l][0];
+        d2 += red[l][1];
+    }
+    const double s1 = d1 > 0.0 ? sqrt(2.0) * cnt / d1 : 1.0;
+    const double s2 = d2 > 0.0 ? sqrt(2.0) * cnt / d2 : 1.0;
+    // normal matrix, 64 correspondences per MFMA pass (outliers contribute zero rows)
+    for (int e = lane; e < LD * LD; e += 64) {
+        w.Vt[e] = 0.0;  // running sum of the Gram matrices
+    }
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n && flags[i] != 0;
+        const double p1[3] = {in ? (x1[2 * i] - c1x) * s1 : 0.0, in ? (x1[2 * i + 1] - c1y) * s1 : 0.0, in ? 1.0 : 0.0};
+        const double p2[3] = {in ? (x2[2 * i] - c2x) * s2 : 0.0, in ? (x2[2 * i + 1] - c2y) * s2 : 0.0, in ? 1.0 : 0.0};
+        for (int c = 0; c < LD; ++c) {
+            w.A[lane * LD + c] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
+        }
+        wave_sync();
+        mfma_gram(w.A, 64, w.G, lane);
+        wave_sync();
+        for (int e = lane; e < LD * LD; e += 64) {
+            w.Vt[e] += w.G[e];
+        }
+        wave_sync();
+    }
+    for (int e = lane; e < LD * LD; e += 64) {
+        w.G[e] = w.Vt[e];
+        w.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    jacobi_sym(w.G, w.Vp, 9, lane);
+    wave_sync();
+    if (lane == 0) {
+        int jmin = 0;
+        for (int j = 1; j < 9; ++j) {
+            if (w.G[j * LD + j] < w.G[jmin * LD + jmin]) {
+                jmin = j;
+            }
+        }
+        double En[9];
+        for (int k = 0; k < 9; ++k) {
+            En[k] = w.Vp[k * LD + jmin];
+        }
+        const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+        const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
+        double tmp[9], E0[9], U[9], S[3], V[9], Vt3[9], UD[9], Ef[9];
+        mul3(En, T1, tmp);
+        mul3(T2t, tmp, E0);
+        svd3(E0, U, S, V);
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                Vt3[i * 3 + j] = V[j * 3 + i];
+            }
+        }
+        const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+        mul3(U, D, UD);
+        mul3(UD, Vt3, Ef);
+        for (int k = 0; k < 9; ++k) {
+            E_out[k] = Ef[k];
+        }
+    }
+}
+
+// Sampson distance of every correspondence under every hypothesis, one workgroup per hypothesis:
+// counts[h] = number of points with r^2 / (|E x1|_xy^2 + |E^T x2|_xy^2) < thr2 (normalised units);
+// flags (optional, n_hyp == 1 use): 1 per inlier.
+__global__ __launch_bounds__(256) void sampson_kernel(const double* __restrict__ x1, const double* __restrict__ x2, int n,
+                                                      const double* __restrict__ E, double thr2, int32_t* __restrict__ counts,
+                                                      uint8_t* __restrict__ flags) {
+    __shared__ int total;
+    const int h = blockIdx.x;
+    const double* e = E + static_cast<size_t>(h) * 9;
+    if (threadIdx.x == 0) {
+        total = 0;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
+        const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
+        const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
+        const double et0 = e[0] * u2 + e[3] * v2 + e[6];
+        const double et1 = e[1] * u2 + e[4] * v2 + e[7];
+        const double r = u2 * ex0 + v2 * ex1 + ex2;
+        const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+        const bool in = den > 0.0 && r * r < thr2 * den;
+        mine += in ? 1 : 0;
+        if (flags != nullptr) {
+            flags[static_cast<size_t>(h) * n + i] = in ? 1 : 0;
+        }
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[h] = total;
+    }
+}
+
 }  // namespace
 
 void launch_pnp_dlt(const double* p3d, const double* p2d, int n_points, int n_hyp, double* R, double* t, double* nullvec,
@@ -579,6 +815,33 @@ void launch_triangulate(const double* P1, const double* P2, const float* pts1, c
         bx = 2048;
     }
     hipLaunchKernelGGL(triangulate_kernel, dim3(bx < 1 ? 1 : bx), dim3(256), 0, stream, P1, P2, pts1, pts2, n, x4, xyz);
+}
+
+void launch_essential_8pt(const double* x1, const double* x2, int n_hyp, double* E, hipStream_t stream) {
+    const size_t lds = 4 * sizeof(PnpWork);
+    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(essential_8pt_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
+                              true);
+    (void)once;
+    int blocks = (n_hyp + 3) / 4;
+    if (blocks > 2048) {
+        blocks = 2048;
+    }
+    hipLaunchKernelGGL(essential_8pt_kernel, dim3(blocks), dim3(256), lds, stream, x1, x2, n_hyp, E);
+}
+
+void launch_essential_refit(const double* x1, const double* x2, const uint8_t* flags, int n, double* E, hipStream_t stream) {
+    const size_t lds = sizeof(PnpWork);
+    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(essential_refit_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
+                              true);
+    (void)once;
+    hipLaunchKernelGGL(essential_refit_kernel, dim3(1), dim3(64), lds, stream, x1, x2, flags, n, E);
+}
+
+void launch_sampson(const double* x1, const double* x2, int n, const double* E, int n_hyp, double thr2, int32_t* counts,
+                    uint8_t* flags, hipStream_t stream) {
+    hipLaunchKernelGGL(sampson_kernel, dim3(n_hyp), dim3(256), 0, stream, x1, x2, n, E, thr2, counts, flags);
 }
 
 }  // namespace slamx

@@ -1406,6 +1406,103 @@ int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n
     return SLAMX_OK;
 }
 
+int slamx_essential_ransac(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K, int iterations,
+                           double threshold_px, uint32_t seed, double* E, int32_t* n_inliers, uint8_t* inlier_mask) {
+    if (iterations <= 0 || pts1 == nullptr || pts2 == nullptr || K == nullptr || E == nullptr || threshold_px <= 0.0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "essential ransac arguments invalid");
+    }
+    if (n < 8) {
+        // PoseEstimator::estimate refuses fewer than 8 matches (pose_estimator.cpp:21-25)
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "Cannot estimate pose, not enough matches. Required at least 8.");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    // K^-1-normalised coordinates, as pose_estimator.cpp:60-65 forms them for simpleRecoverPose
+    std::vector<double> x1(static_cast<size_t>(n) * 2), x2(static_cast<size_t>(n) * 2);
+    for (int i = 0; i < n; ++i) {
+        x1[2 * static_cast<size_t>(i)] = (static_cast<double>(pts1[2 * i]) - cx) / fx;
+        x1[2 * static_cast<size_t>(i) + 1] = (static_cast<double>(pts1[2 * i + 1]) - cy) / fy;
+        x2[2 * static_cast<size_t>(i)] = (static_cast<double>(pts2[2 * i]) - cx) / fx;
+        x2[2 * static_cast<size_t>(i) + 1] = (static_cast<double>(pts2[2 * i + 1]) - cy) / fy;
+    }
+    // the sampling rule of the reference's own RANSAC (loop_closure.cpp:177-193): mt19937,
+    // uniform_int_distribution, indices redrawn until distinct -- here with an explicit seed
+    std::mt19937 rng(seed);
+    std::uniform_int_distribution<int> dist(0, n - 1);
+    constexpr int sampleSize = 8;
+    std::vector<double> s1(static_cast<size_t>(iterations) * sampleSize * 2), s2(static_cast<size_t>(iterations) * sampleSize * 2);
+    for (int i = 0; i < iterations; ++i) {
+        int idx[sampleSize];
+        int have = 0;
+        while (have < sampleSize) {
+            const int c = dist(rng);
+            if (std::find(idx, idx + have, c) == idx + have) {
+                idx[have] = c;
+                const size_t o = (static_cast<size_t>(i) * sampleSize + have) * 2;
+                s1[o] = x1[2 * static_cast<size_t>(c)];
+                s1[o + 1] = x1[2 * static_cast<size_t>(c) + 1];
+                s2[o] = x2[2 * static_cast<size_t>(c)];
+                s2[o + 1] = x2[2 * static_cast<size_t>(c) + 1];
+                ++have;
+            }
+        }
+    }
+    const size_t H = static_cast<size_t>(iterations);
+    DevBuf ds1, ds2, dx1, dx2, dE, dcnt, dflags;
+    HIP_TRY(ds1.alloc(s1.size() * sizeof(double)));
+    HIP_TRY(ds2.alloc(s2.size() * sizeof(double)));
+    HIP_TRY(dx1.alloc(x1.size() * sizeof(double)));
+    HIP_TRY(dx2.alloc(x2.size() * sizeof(double)));
+    HIP_TRY(dE.alloc(H * 9 * sizeof(double)));
+    HIP_TRY(dcnt.alloc(H * sizeof(int32_t)));
+    HIP_TRY(dflags.alloc(static_cast<size_t>(n)));
+    HIP_TRY(hipMemcpyAsync(ds1.p, s1.data(), s1.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ds2.p, s2.data(), s2.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dx1.p, x1.data(), x1.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dx2.p, x2.data(), x2.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    // cv::findEssentialMat scales its pixel threshold by the focal length; same convention
+    const double thr = threshold_px / (0.5 * (fx + fy));
+    launch_essential_8pt(ds1.as<double>(), ds2.as<double>(), iterations, dE.as<double>(), s);
+    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, dE.as<double>(), iterations, thr * thr, dcnt.as<int32_t>(), nullptr, s);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> counts(H);
+    HIP_TRY(hipMemcpyAsync(counts.data(), dcnt.p, H * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int best = 0;  // first maximum wins
+    for (int i = 1; i < iterations; ++i) {
+        if (counts[static_cast<size_t>(i)] > counts[static_cast<size_t>(best)]) {
+            best = i;
+        }
+    }
+    // refit on the inliers of the winner; kept only if it explains at least as many correspondences
+    double* e_best = dE.as<double>() + static_cast<size_t>(best) * 9;
+    DevBuf dfit;
+    HIP_TRY(dfit.alloc(72 + sizeof(int32_t) + static_cast<size_t>(n)));
+    double* e_fit = dfit.as<double>();
+    int32_t* fit_cnt = reinterpret_cast<int32_t*>(dfit.as<char>() + 72);
+    uint8_t* fit_flags = reinterpret_cast<uint8_t*>(dfit.as<char>() + 72 + sizeof(int32_t));
+    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, e_best, 1, thr * thr, dcnt.as<int32_t>(), dflags.as<uint8_t>(), s);
+    HIP_TRY(hipMemcpyAsync(e_fit, e_best, 72, hipMemcpyDeviceToDevice, s));
+    launch_essential_refit(dx1.as<double>(), dx2.as<double>(), dflags.as<uint8_t>(), n, e_fit, s);
+    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, e_fit, 1, thr * thr, fit_cnt, fit_flags, s);
+    HIP_TRY(hipGetLastError());
+    int32_t refit_count = 0;
+    HIP_TRY(hipMemcpyAsync(&refit_count, fit_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const bool use_fit = refit_count >= counts[static_cast<size_t>(best)];
+    HIP_TRY(hipMemcpyAsync(E, use_fit ? e_fit : e_best, 72, hipMemcpyDeviceToHost, s));
+    if (inlier_mask != nullptr) {
+        HIP_TRY(hipMemcpyAsync(inlier_mask, use_fit ? fit_flags : dflags.as<uint8_t>(), static_cast<size_t>(n),
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_inliers != nullptr) {
+        *n_inliers = use_fit ? refit_count : counts[static_cast<size_t>(best)];
+    }
+    return SLAMX_OK;
+}
+
 int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
                        double* R, double* t, int32_t* front) {
     if (n < 0 || E == nullptr || K == nullptr || R == nullptr || t == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {

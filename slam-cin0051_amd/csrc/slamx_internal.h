@@ -199,6 +199,10 @@ void launch_inliers(const double* p3d, const double* p2d, int n, const double* K
                     double threshold, int n_hyp, int* counts, hipStream_t stream);
 void launch_recover_pose(const double* E, const double* K, const float* pts1, const float* pts2, int n, double* poses,
                          double* KP, double* KP0, int* front, hipStream_t stream);
+void launch_essential_8pt(const double* x1, const double* x2, int n_hyp, double* E, hipStream_t stream);
+void launch_essential_refit(const double* x1, const double* x2, const uint8_t* flags, int n, double* E, hipStream_t stream);
+void launch_sampson(const double* x1, const double* x2, int n, const double* E, int n_hyp, double thr2, int32_t* counts,
+                    uint8_t* flags, hipStream_t stream);
 void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
                         double* xyz, hipStream_t stream);
 

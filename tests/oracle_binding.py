@@ -145,6 +145,21 @@ class Oracle:
         return self.lib.oracle_count_inliers(a.shape[0], _p(a), _p(b), _p(np.ascontiguousarray(K, np.float64)),
                                              _p(np.ascontiguousarray(R, np.float64)), _p(np.ascontiguousarray(t, np.float64)), float(thr))
 
+    def essential_ransac(self, pts1, pts2, K, iterations=512, threshold_px=1.0, seed=0):
+        a = np.ascontiguousarray(pts1, np.float32)
+        b = np.ascontiguousarray(pts2, np.float32)
+        n = a.shape[0]
+        E = np.empty((3, 3))
+        cnt = C.c_int()
+        mask = np.zeros(n, np.uint8)
+        E_all = np.empty((iterations, 9))
+        counts = np.empty(iterations, np.int32)
+        self.lib.oracle_essential_ransac.restype = C.c_int
+        best = self.lib.oracle_essential_ransac(_p(a), _p(b), n, _p(np.ascontiguousarray(K, np.float64)), iterations,
+                                                C.c_double(threshold_px), C.c_uint(seed), _p(E), C.byref(cnt),
+                                                _p(mask), _p(E_all), _p(counts))
+        return E, cnt.value, mask, best, E_all, counts
+
     def recover_pose(self, E, pts1, pts2, K):
         a = np.ascontiguousarray(pts1, np.float32)
         b = np.ascontiguousarray(pts2, np.float32)

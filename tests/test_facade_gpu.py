@@ -73,3 +73,14 @@ def test_cli_runs_the_pipeline(ref_data):
     lines = [l for l in text.splitlines() if l.startswith("frame ")]
     assert len(lines) == 4 and "59 keypoints" in lines[0]
     assert _run([os.path.join(BIN, "cli"), "-h"]).startswith("cli -c")
+
+
+def test_cli_estimates_the_pose_between_kitti_frames(ref_data):
+    """camera.yml present -> PoseEstimator::estimate + triangulatePoints on the matches (the two KITTI
+    frames are 0.1 s apart on a forward-driving car: small rotation, translation mostly along z)."""
+    text = _run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images")])
+    pose = [l for l in text.splitlines() if l.strip().startswith("pose:")]
+    assert len(pose) == 1, text
+    t = [float(x) for x in pose[0].split("(")[1].split(")")[0].split()]
+    trace = float(pose[0].split("trace(R) =")[1].split(",")[0])
+    assert trace > 2.99 and abs(t[2]) > 0.9

@@ -162,3 +162,63 @@ def test_triangulate_matches_oracle(gpu_ctx, oracle):
 def test_pose_argument_errors(gpu_ctx):
     with pytest.raises(ValueError):
         gpu_ctx.pnp_dlt_batch(np.zeros((1, 5, 3)), np.zeros((1, 5, 2)))  # < 6 points: solvePnP returns false
+
+
+# ---------------------------------------------------------------- f3: essential-matrix RANSAC
+def two_view(rng, n, outliers, noise=0.3):
+    R = rot(*rng.uniform(-0.15, 0.15, 3))
+    t = rng.uniform(-1, 1, 3)
+    t /= np.linalg.norm(t)
+    X = rng.uniform(-3, 3, (n, 3)) + np.array([0, 0, 9.0])
+    p1 = (K @ X.T).T
+    p2 = (K @ (R @ X.T + t[:, None])).T
+    uv1 = p1[:, :2] / p1[:, 2:] + rng.normal(0, noise, (n, 2))
+    uv2 = p2[:, :2] / p2[:, 2:] + rng.normal(0, noise, (n, 2))
+    bad = rng.choice(n, int(outliers * n), replace=False)
+    uv2[bad] = rng.uniform(0, 1000, (len(bad), 2))
+    return R, t, uv1.astype(np.float32), uv2.astype(np.float32), bad
+
+
+def fix_sign(E):
+    k = np.abs(E).argmax()
+    return E * np.sign(E.flat[k])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_essential_ransac_matches_cpu_restatement(gpu_ctx, oracle, seed):
+    """Same sampling, same algorithm on both sides: the winning hypothesis, its inlier set and the
+    matrix agree (the null vector comes from two different Jacobi iterations: 1e-6, not bit-exact)."""
+    rng = np.random.default_rng(seed)
+    R, t, uv1, uv2, bad = two_view(rng, 600, 0.25)
+    Eg, cg, mg = gpu_ctx.essential_ransac(uv1, uv2, K, iterations=400, threshold_px=1.0, seed=seed)
+    Eo, co, mo, best, E_all, counts = oracle.essential_ransac(uv1, uv2, K, iterations=400, threshold_px=1.0, seed=seed)
+    assert abs(cg - co) <= 2 and (mg != mo).sum() <= 2
+    assert np.abs(fix_sign(Eg) - fix_sign(Eo)).max() < 1e-6
+    s = np.linalg.svd(Eg, compute_uv=False)
+    assert abs(s[0] - 1) < 1e-9 and abs(s[1] - 1) < 1e-9 and s[2] < 1e-9
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.3, 0.5])
+def test_essential_ransac_recovers_the_motion(gpu_ctx, outliers):
+    """Self-consistency (the reference delegates this step to OpenCV): E -> simpleRecoverPose gives
+    back the simulated rotation and translation direction, outliers are flagged."""
+    rng = np.random.default_rng(17)
+    R, t, uv1, uv2, bad = two_view(rng, 800, outliers)
+    # 8-point samples: P(all inliers) = (1 - outliers)^8, so half outliers needs thousands of hypotheses
+    E, cnt, mask = gpu_ctx.essential_ransac(uv1, uv2, K, iterations=8192 if outliers >= 0.5 else 1024, threshold_px=1.5, seed=5)
+    good = np.ones(len(uv1), bool)
+    good[bad] = False
+    assert mask[good].mean() > 0.9 and (len(bad) == 0 or mask[~good].mean() < 0.1)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    n1 = np.stack([(uv1[:, 0] - cx) / fx, (uv1[:, 1] - cy) / fy], 1).astype(np.float32)[mask == 1]
+    n2 = np.stack([(uv2[:, 0] - cx) / fx, (uv2[:, 1] - cy) / fy], 1).astype(np.float32)[mask == 1]
+    Rg, tg, front = gpu_ctx.recover_pose(E, n1, n2, K)
+    ang = np.arccos(np.clip((np.trace(Rg.T @ R) - 1) / 2, -1, 1))
+    assert ang < 5e-3
+    assert np.arccos(np.clip(abs(tg @ t), -1, 1)) < 3e-2
+
+
+def test_essential_ransac_needs_eight_matches(gpu_ctx):
+    uv = np.zeros((7, 2), np.float32)
+    with pytest.raises(ValueError, match="Required at least 8"):
+        gpu_ctx.essential_ransac(uv, uv, K)

@@ -1,7 +1,8 @@
 // cli -- keeps the reference's flag surface (tools/cli/cli.cpp:20: getopt "hv:c:") but, unlike the
 // reference's stub SLAMModel (src/model/model.cpp:5-7 is empty, run() is never defined), actually
-// drives the hot path: frame directory -> detectAndCompute -> match(frame k, frame k-1).
-//   cli -c <config dir with feature_detector.yml + feature_matcher.yml> -v <directory of PNG frames>
+// drives the hot path: frame directory -> detectAndCompute -> match(frame k, frame k-1) and, when the
+// config directory also holds a camera.yml, PoseEstimator::estimate + triangulatePoints on the matches.
+//   cli -c <config dir with feature_detector.yml + feature_matcher.yml [+ camera.yml]> -v <directory of PNG frames>
 #include <getopt.h>
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 
 #include <slam/frontend/feature_detector.hpp>
 #include <slam/frontend/feature_matcher.hpp>
+#include <slam/frontend/pose_estimator.hpp>
 
 #include "../png_gray.hpp"
 
@@ -59,6 +61,9 @@ int main(int argc, char** argv) {
             }
         }
         std::sort(files.begin(), files.end());
+        const bool havePose = fs::exists(fs::path(configPath) / "camera.yml");
+        slam::Camera camera = havePose ? slam::Camera(fs::path(configPath) / "camera.yml") : slam::Camera();
+        slam::PoseEstimator poseEstimator(camera);
         std::vector<slam::Keypoint> prevKps;
         slam::DescriptorMatrix prevDesc;
         const auto t0 = std::chrono::steady_clock::now();
@@ -74,6 +79,23 @@ int main(int argc, char** argv) {
             }
             std::printf("frame %zu %s: %zu keypoints, %zu matches to previous\n", i, files[i].filename().c_str(),
                         kps.size(), matches.size());
+            if (havePose && matches.size() >= 8) {
+                std::vector<std::pair<int, int>> pairs;
+                for (const auto& m : matches) {
+                    pairs.emplace_back(m.trainIdx, m.queryIdx);  // (previous frame, this frame)
+                }
+                slam::Mat3d R{1, 0, 0, 0, 1, 0, 0, 0, 1};
+                slam::Vec3d t{0, 0, 0};
+                if (poseEstimator.estimate(prevKps, kps, pairs, R, t)) {
+                    std::vector<slam::Match> swapped;
+                    for (const auto& m : matches) {
+                        swapped.push_back({m.trainIdx, m.queryIdx, m.distance});
+                    }
+                    const auto pts = poseEstimator.triangulatePoints(prevKps, kps, swapped, R, t);
+                    std::printf("  pose: t = (%.4f %.4f %.4f), trace(R) = %.6f, %zu map points\n", t[0], t[1], t[2],
+                                R[0] + R[4] + R[8], pts.size());
+                }
+            }
             totalKps += kps.size();
             totalMatches += matches.size();
             prevKps = std::move(kps);
