@@ -84,3 +84,48 @@ def test_cli_estimates_the_pose_between_kitti_frames(ref_data):
     t = [float(x) for x in pose[0].split("(")[1].split(")")[0].split()]
     trace = float(pose[0].split("trace(R) =")[1].split(",")[0])
     assert trace > 2.99 and abs(t[2]) > 0.9
+
+
+def test_preprocessing_program(slamx, oracle, ref_data, tmp_path):
+    """Counterpart of the reference's test_preprocessing: Camera::undistortImage on one image, then
+    slam::Preprocessor over a frame directory with its timestamps.txt (preprocessor.cpp:24-141)."""
+    import calendar
+    import shutil
+    import time
+
+    frames = tmp_path / "frames"
+    frames.mkdir()
+    names = ["0000000000.png", "0000000001.png"]
+    for n in names:
+        shutil.copy(os.path.join(ref_data, "images", n), frames / n)
+    stamps = open(os.path.join(ref_data, "timestamps.txt")).read().splitlines()[:2]
+    (frames / "timestamps.txt").write_text("\n".join(stamps) + "\n")
+    prefix = str(tmp_path / "pre")
+    cam_yml = os.path.join(ref_data, "camera.yml")
+    text = _run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]), str(frames), "2",
+                 prefix])
+    cam = slamx.load_camera(cam_yml)
+    lines = [l for l in text.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 2
+    for k, n in enumerate(names):
+        img = load_gray(os.path.join(ref_data, "images", n))
+        ref = oracle.undistort(img, cam)
+        if k == 0:
+            got = np.fromfile(prefix + "_undistorted.f64", np.float64).reshape(img.shape)
+            assert np.array_equal(got, ref)
+        fields = lines[k].split()
+        assert int(fields[2]) == img.shape[0] and int(fields[4]) == img.shape[1]
+        assert abs(float(fields[8]) - ref.sum()) < 1e-6 * ref.sum()
+        # "2011-09-26 13:02:25.454043904": local-time mktime + nanoseconds, truncated to milliseconds
+        main, nano = stamps[k].split(".")
+        want_ms = int(time.mktime(time.strptime(main, "%Y-%m-%d %H:%M:%S"))) * 1000 + int(nano) // 1000000
+        assert int(fields[6]) == want_ms
+    # a third yield is past the end of the stream: the program reports it and fails, as the reference's does
+    p = subprocess.run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]),
+                        str(frames), "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"No frames yielded" in p.stderr
+    # frame count / timestamp count mismatch is an error (preprocessor.cpp:79-81)
+    (frames / "timestamps.txt").write_text(stamps[0] + "\n")
+    p = subprocess.run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]),
+                        str(frames), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"Number of timestamps does not match" in p.stderr

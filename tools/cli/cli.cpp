@@ -16,7 +16,7 @@
 #include <slam/frontend/feature_matcher.hpp>
 #include <slam/frontend/pose_estimator.hpp>
 
-#include "../png_gray.hpp"
+#include <slam/preprocessing/png_gray.hpp>
 
 static void printHelp() {
     std::printf("cli -c <config_dir> -v <stream_path>\n"

@@ -8,7 +8,7 @@
 #include <slam/frontend/feature_detector.hpp>
 #include <slam/frontend/feature_matcher.hpp>
 
-#include "png_gray.hpp"
+#include <slam/preprocessing/png_gray.hpp>
 
 int main(int argc, char** argv) {
     if (argc < 6) {
