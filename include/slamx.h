@@ -66,6 +66,18 @@ typedef struct slamx_matcher_config {
     float ratio_test_threshold;
 } slamx_matcher_config;
 
+/* The eight YAML keys slam::LoopClosure reads, src/backend/loop_closure.cpp:30-80. */
+typedef struct slamx_loop_closure_config {
+    int32_t min_db_size;
+    int32_t min_frames_difference;
+    double min_absolute_score;
+    double relative_score_factor;
+    int32_t min_matches_for_pnp;
+    int32_t min_inliers_for_pnp;
+    int32_t ransac_max_iterations;
+    double ransac_reprojection_threshold;
+} slamx_loop_closure_config;
+
 /* Capacities of a device-resident frame batch (all per frame except max_frames). */
 typedef struct slamx_batch_shape {
     int32_t rows, cols;
@@ -98,6 +110,8 @@ int slamx_ctx_timer_stop_ms(slamx_ctx* ctx, float* ms); /* synchronizes */
 int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out);
 /* replaces feature_matcher.cpp:18-59 */
 int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out);
+/* LoopClosure::loadParameters (loop_closure.cpp:27-95): same keys, same range checks, same messages. */
+int slamx_loop_closure_config_load(const char* yaml_path, slamx_loop_closure_config* out);
 
 /* ---- slam::FeatureDetector ---- */
 /* FeatureDetector::FeatureDetector, feature_detector.hpp:53-107 (validation + pattern). */

@@ -59,6 +59,13 @@ class MatcherConfig(C.Structure):
     ]
 
 
+class LoopClosureConfig(C.Structure):
+    _fields_ = [("min_db_size", C.c_int32), ("min_frames_difference", C.c_int32), ("min_absolute_score", C.c_double),
+                ("relative_score_factor", C.c_double), ("min_matches_for_pnp", C.c_int32),
+                ("min_inliers_for_pnp", C.c_int32), ("ransac_max_iterations", C.c_int32),
+                ("ransac_reprojection_threshold", C.c_double)]
+
+
 class Camera(C.Structure):
     """slam::Camera (common.hpp:67-190): intrinsics, distortion, image size."""
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("k1", C.c_double),
@@ -80,7 +87,7 @@ class BatchShape(C.Structure):
 EXPORTS = [
     "slamx_last_error", "slamx_version", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
     "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
-    "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_detector_create", "slamx_detector_destroy",
+    "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
     "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
@@ -211,6 +218,12 @@ def load_camera(path, camera_index=0):
 def load_matcher_config(path):
     cfg = MatcherConfig()
     _check(load_library().slamx_matcher_config_load(os.fsencode(path), C.byref(cfg)))
+    return cfg
+
+
+def load_loop_closure_config(path):
+    cfg = LoopClosureConfig()
+    _check(load_library().slamx_loop_closure_config_load(os.fsencode(path), C.byref(cfg)))
     return cfg
 
 

@@ -466,6 +466,50 @@ int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out) 
     return SLAMX_OK;  // range checks happen in slamx_matcher_create, as in the constructor
 }
 
+int slamx_loop_closure_config_load(const char* yaml_path, slamx_loop_closure_config* out) {
+    YamlFile y;
+    if (yaml_path == nullptr || out == nullptr || !y.open(yaml_path)) {
+        return fail(SLAMX_ERR_RUNTIME,
+                    std::string("Could not open Loop Closure config file: ") + (yaml_path ? yaml_path : "(null)"));
+    }
+    out->min_db_size = y.get_int("MinDbSize");
+    if (out->min_db_size < 0) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinDbSize' must be a non-negative integer.");
+    }
+    out->min_frames_difference = y.get_int("MinFramesDifference");
+    if (out->min_frames_difference <= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinFramesDifference' must be a positive integer.");
+    }
+    out->min_absolute_score = y.get_double("MinAbsoluteScore");
+    if (out->min_absolute_score < 0.0) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinAbsoluteScore' must be non-negative.");
+    }
+    out->relative_score_factor = y.get_double("RelativeScoreFactor");
+    if (out->relative_score_factor < 0.0) {
+        return fail(SLAMX_ERR_RUNTIME, "'RelativeScoreFactor' must be non-negative.");
+    }
+    out->min_matches_for_pnp = y.get_int("MinMatchesForPnP");
+    if (out->min_matches_for_pnp <= 3) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinMatchesForPnP' must be greater than 3 for PnP.");
+    }
+    out->min_inliers_for_pnp = y.get_int("MinInliersForPnP");
+    if (out->min_inliers_for_pnp <= 3) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinInliersForPnP' must be greater than 3 for PnP.");
+    }
+    if (out->min_inliers_for_pnp > out->min_matches_for_pnp) {
+        return fail(SLAMX_ERR_RUNTIME, "'MinInliersForPnP' cannot be greater than 'MinMatchesForPnP'.");
+    }
+    out->ransac_max_iterations = y.get_int("RansacMaxIterations");
+    if (out->ransac_max_iterations <= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "'RansacMaxIterations' must be a positive integer.");
+    }
+    out->ransac_reprojection_threshold = y.get_double("RansacReprojectionThreshold");
+    if (out->ransac_reprojection_threshold <= 0.0) {
+        return fail(SLAMX_ERR_RUNTIME, "'RansacReprojectionThreshold' must be a positive value.");
+    }
+    return SLAMX_OK;
+}
+
 int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slamx_detector** out) {
     if (ctx == nullptr || cfg == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");

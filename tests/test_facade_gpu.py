@@ -129,3 +129,75 @@ def test_preprocessing_program(slamx, oracle, ref_data, tmp_path):
     p = subprocess.run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]),
                         str(frames), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and b"Number of timestamps does not match" in p.stderr
+
+
+@pytest.mark.parametrize("min_matches", [20, 4])
+def test_loop_closure_program(slamx, ref_data, tmp_path, min_matches):
+    """slam::LoopClosure (facade) on the reference's loop-test images, replayed step by step through
+    the Python binding: same candidate scores, same verdict, same transform."""
+    cfg = open(os.path.join(ref_data, "loop_closure.yml")).read().replace("MinMatchesForPnP: 20", "MinMatchesForPnP: %d" % min_matches)
+    cfg = cfg.replace("MinInliersForPnP: 5", "MinInliersForPnP: 4")
+    yml = tmp_path / "loop_closure.yml"
+    yml.write_text(cfg)
+    det_yml = os.path.join(ref_data, "feature_detector.yml")
+    mat_yml = os.path.join(ref_data, "feature_matcher.yml")
+    cam_yml = os.path.join(ref_data, "camera.yml")
+    images = os.path.join(ref_data, "images_test_loop")
+    seed = 7
+    text = _run([os.path.join(BIN, "test_loop_closure"), str(yml), det_yml, mat_yml, cam_yml, images, "4", str(seed)])
+    # replay
+    P = slamx.load_loop_closure_config(str(yml))
+    det = slamx.FeatureDetector(det_yml)
+    mat = slamx.FeatureMatcher(mat_yml)
+    cam = slamx.load_camera(cam_yml)
+    K = np.array(cam.K).reshape(3, 3)
+    frames = [det.detectAndCompute(load_gray(os.path.join(images, "%d.png" % i))) for i in range(4)]
+    for i, (k, _) in enumerate(frames):
+        assert "keyframe %d: %d keypoints" % (i, len(k)) in text
+    kq, dq = frames[3]
+    best, max_score, second = -1, 0.0, 0.0
+    for i in range(4):
+        if abs(3 - i) < P.min_frames_difference:
+            continue
+        score = len(mat.match(dq, frames[i][1])) / len(dq)
+        if score > max_score:
+            second, max_score, best = max_score, score, i
+        elif score > second:
+            second = score
+    want = None
+    if best != -1 and max_score >= P.min_absolute_score and max_score >= P.relative_score_factor * second:
+        kt, dt = frames[best]
+        m = mat.match(dq, dt, kq, kt)
+        if len(m) >= P.min_matches_for_pnp:
+            p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float64)
+            p3 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]], np.ones(len(m))], 1).astype(np.float64)
+            R, t, inl = det.ctx.pnp_ransac(p3, p2, K, P.ransac_max_iterations, P.ransac_reprojection_threshold, seed)
+            if inl >= P.min_inliers_for_pnp:
+                want = (best, R, t)
+    if want is None:
+        assert "no loop" in text
+    else:
+        assert "loop with keyframe %d" % want[0] in text
+        rows = [list(map(float, l.split()[1:])) for l in text.splitlines() if l.startswith("T ")]
+        T = np.array(rows)
+        assert np.abs(T[:3, :3] - want[1]).max() < 1e-9 and np.abs(T[:3, 3] - want[2]).max() < 1e-9
+        assert np.array_equal(T[3], [0, 0, 0, 1])
+
+
+def test_loop_closure_config_checks(slamx, ref_data, tmp_path):
+    good = open(os.path.join(ref_data, "loop_closure.yml")).read()
+    for old, new, msg in [("MinDbSize: 2", "MinDbSize: -1", "'MinDbSize' must be a non-negative integer."),
+                          ("MinFramesDifference: 2", "MinFramesDifference: 0", "'MinFramesDifference' must be a positive integer."),
+                          ("MinMatchesForPnP: 20", "MinMatchesForPnP: 3", "'MinMatchesForPnP' must be greater than 3 for PnP."),
+                          ("MinInliersForPnP: 5", "MinInliersForPnP: 30", "'MinInliersForPnP' cannot be greater than 'MinMatchesForPnP'."),
+                          ("RansacMaxIterations: 100", "RansacMaxIterations: 0", "'RansacMaxIterations' must be a positive integer."),
+                          ("RansacReprojectionThreshold: 2.0", "RansacReprojectionThreshold: 0.0",
+                           "'RansacReprojectionThreshold' must be a positive value.")]:
+        assert old in good
+        p = tmp_path / "bad.yml"
+        p.write_text(good.replace(old, new))
+        with pytest.raises(RuntimeError, match=msg.replace("(", ".").replace(")", ".")):
+            slamx.load_loop_closure_config(str(p))
+    ok = slamx.load_loop_closure_config(os.path.join(ref_data, "loop_closure.yml"))
+    assert (ok.min_db_size, ok.min_frames_difference, ok.min_matches_for_pnp, ok.min_inliers_for_pnp, ok.ransac_max_iterations) == (2, 2, 20, 5, 100)
+    assert ok.min_absolute_score == 0.005 and ok.relative_score_factor == 1.5 and ok.ransac_reprojection_threshold == 2.0
