@@ -34,6 +34,10 @@ constexpr int HALO = 3;
 constexpr int LDS_ROW_DW = TILE_W / 4 + 2;   // 264 bytes: columns [x0-4, x0+260)
 constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 38
 constexpr int ROWS_PER_WAVE = TILE_H / 4;
+// survivors of the pretest listed per tile (about 100 of 8192 pixels on the bench frames); a tile with
+// more keeps them in the lanes' own flag registers instead (slower, any count) -- the short list
+// is what lets 8 workgroups share a CU's LDS
+constexpr int SURVIVOR_CAP = 2048;
 
 // The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels.
 __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
@@ -96,7 +100,7 @@ __device__ __forceinline__ uint32_t cardinal_test(us2 c, us2 u, us2 d, us2 l, us
 // Pixels that fail the pretest can never be corners, so the bitmap is the reference's.
 __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc, int nframes, int tiles_x, int tiles_y) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
-    __shared__ uint16_t survivors[TILE_W * TILE_H];
+    __shared__ uint16_t survivors[SURVIVOR_CAP];
     __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
     __shared__ int n_survivors;
     int f, tile_id;
@@ -212,14 +216,15 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         if (cnt != 0) {
             int pos = atomicAdd(&n_survivors, cnt);
             const uint32_t ent0 = static_cast<uint32_t>((wave * ROWS_PER_WAVE) << 8) | static_cast<uint32_t>(lane * 4);
-            while (acc01 != 0) {
-                const int b = __ffs(static_cast<int>(acc01)) - 1;
-                acc01 &= acc01 - 1;
+            uint32_t m01 = acc01, m23 = acc23;
+            while (m01 != 0 && pos < SURVIVOR_CAP) {
+                const int b = __ffs(static_cast<int>(m01)) - 1;
+                m01 &= m01 - 1;
                 survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + (b >> 4));
             }
-            while (acc23 != 0) {
-                const int b = __ffs(static_cast<int>(acc23)) - 1;
-                acc23 &= acc23 - 1;
+            while (m23 != 0 && pos < SURVIVOR_CAP) {
+                const int b = __ffs(static_cast<int>(m23)) - 1;
+                m23 &= m23 - 1;
                 survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + 2 + (b >> 4));
             }
         }
@@ -228,11 +233,7 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     // ---- phase 2: the 16-pixel segment test
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
     constexpr int RS = LDS_ROW_DW * 4;  // LDS row stride in bytes
-    const int total = n_survivors;
-    for (int s = threadIdx.x; s < total; s += 256) {
-        const int e = survivors[s];
-        const int ry = e >> 8;
-        const int col = e & 255;
+    auto test_pixel = [&](int ry, int col) {
         const uint8_t* p = t8 + (ry + HALO) * RS + (col + 4);
         const int c = p[0];
         const int hi = c + threshold;
@@ -247,6 +248,25 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         }
         if (segment_test(B, D, arc)) {
             atomicOr(&row_mask[ry][col >> 5], 1u << (col & 31));
+        }
+    };
+    const int total = n_survivors;
+    if (total <= SURVIVOR_CAP) {  // block-uniform
+        for (int s = threadIdx.x; s < total; s += 256) {
+            const int e = survivors[s];
+            test_pixel(e >> 8, e & 255);
+        }
+    } else {
+        // dense tile: every lane tests the pixels it flagged itself
+        while (acc01 != 0) {
+            const int b = __ffs(static_cast<int>(acc01)) - 1;
+            acc01 &= acc01 - 1;
+            test_pixel(wave * ROWS_PER_WAVE + (b & 15), lane * 4 + (b >> 4));
+        }
+        while (acc23 != 0) {
+            const int b = __ffs(static_cast<int>(acc23)) - 1;
+            acc23 &= acc23 - 1;
+            test_pixel(wave * ROWS_PER_WAVE + (b & 15), lane * 4 + 2 + (b >> 4));
         }
     }
     __syncthreads();

@@ -73,6 +73,19 @@ def test_fast_candidates_shapes_and_thresholds(slamx, oracle, shape, arc, t):
     assert_records_equal(d.fast_candidates(img), oracle.fast_candidates(img, Pp), "candidates %s arc=%d t=%d" % (shape, arc, t))
 
 
+@pytest.mark.parametrize("arc,t", [(16, 8), (12, 30), (14, 20)])
+def test_fast_candidates_dense_noise(slamx, oracle, arc, t):
+    """Uniform noise: 55-75 % of the pixels survive the cardinal pretest, far more than the per-tile
+    survivor list holds, so the tiles take the register fallback of fast_detect_kernel."""
+    rng = np.random.default_rng(arc * 100 + t)
+    img = rng.integers(0, 256, (200, 700), dtype=np.uint8)
+    d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=arc))
+    Pp = oracle.det_params(d.cfg)
+    got, ref = d.fast_candidates(img), oracle.fast_candidates(img, Pp)
+    assert len(ref) > 2000
+    assert_records_equal(got, ref, "dense noise arc=%d t=%d" % (arc, t))
+
+
 def test_fast_candidates_strided_input(det, oracle, P, slamx):
     big = synth(slamx, 3, 200, 300, 120, rmin=8, rmax=30)
     view = big[10:150, 17:260]  # non-contiguous rows
