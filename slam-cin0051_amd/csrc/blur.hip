@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     const int ty = blockIdx.y;
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // scalar: row addresses on the SALU
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     uint8_t* out = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const int x = tx * TILE_W - 4 + lane * 4;  // first of this lane's 4 columns
@@ -104,14 +104,15 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         constexpr int NLOAD = LDS_ROWS / 4;
         static_assert(LDS_ROWS % 4 == 0, "rows are dealt to 4 waves");
         const bool ca = x >= 0 && x + 4 <= v.pitch;
+        const int xoff = ca ? x : 0;  // lanes outside the frame read a valid address and drop the value
         uint32_t va[NLOAD];
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int yy = y0 + wave + 4 * i;
-            const bool ok = ca && yy >= 0 && yy < v.rows;
-            const uint8_t* src = ok ? img + static_cast<size_t>(yy) * v.pitch + x : img;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(src);
-            va[i] = ok ? w : 0u;
+            const int yy = y0 + wave + 4 * i;  // wave-uniform
+            const bool row_ok = yy >= 0 && yy < v.rows;
+            const uint8_t* row = img + static_cast<size_t>(row_ok ? yy : 0) * v.pitch;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(row + xoff);
+            va[i] = row_ok && ca ? w : 0u;
         }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     const int ty = tile_id / tiles_x;
     const int tx = tile_id - ty * tiles_x;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // scalar: row addresses on the SALU
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
     const int x0 = tx * TILE_W - 4;
     const int y0 = ty * TILE_H - HALO;
@@ -120,15 +120,16 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         constexpr int NLOAD = (LDS_ROWS + 3) / 4;
         const int xa = x0 + lane * 4;
         const bool ca = xa >= 0 && xa + 4 <= v.pitch;
+        const int xoff = ca ? xa : 0;  // lanes outside the frame read a valid address and drop the value
         uint32_t va[NLOAD];
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int r = wave + 4 * i;
+            const int r = wave + 4 * i;  // wave-uniform from here to `row`
             const int yy = y0 + r;
-            const bool ok = ca && r < LDS_ROWS && yy >= 0 && yy < v.rows;
-            const uint8_t* src = ok ? img + static_cast<size_t>(yy) * v.pitch + xa : img;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(src);
-            va[i] = ok ? w : 0u;
+            const bool row_ok = r < LDS_ROWS && yy >= 0 && yy < v.rows;
+            const uint8_t* row = img + static_cast<size_t>(row_ok ? yy : 0) * v.pitch;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(row + xoff);
+            va[i] = row_ok && ca ? w : 0u;
         }
         const int hr = static_cast<int>(threadIdx.x) >> 1;
         const int hx = x0 + (64 + (static_cast<int>(threadIdx.x) & 1)) * 4;
