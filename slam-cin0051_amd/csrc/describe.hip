@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void describe_kernel(BatchView v, DetectorPara
     __shared__ unsigned long long dbuf[4][DESC_WORDS];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.n_kp[f];
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.n_kp[f];
     const int radius = P.patch / 2;
     const int stride = blocks_per_frame * 4;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.n_kp[f];
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile[wave]);

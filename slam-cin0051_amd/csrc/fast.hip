@@ -294,7 +294,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
     const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
     uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (threadIdx.x == 0) {
         carry = 0;
     }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.rows * v.nw;
     const unsigned long long* __restrict__ masks = v.masks + static_cast<size_t>(f) * n;
     const uint32_t* __restrict__ off = v.wordoff + static_cast<size_t>(f) * n;

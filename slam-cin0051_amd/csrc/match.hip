@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     const bool wave_has_queries = block_first + static_cast<int>(threadIdx.x & ~63u) < n1;
     // LDS address space spelled out: the queue cursor then is a 32-bit offset, not a 64-bit flat pointer
     typedef __attribute__((address_space(3))) uint16_t lds_u16;
-    lds_u16* const myq = (lds_u16*)(evq[threadIdx.x >> 6] + lane);
+    lds_u16* const myq = (lds_u16*)(evq[__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))] + lane);
     lds_u16* qend = myq;  // one past this lane's last queue entry (entries are 64 elements apart)
     // one (query u, train t) pair through the reference's update (feature_matcher.cpp:132-141,
     // penalty :161-170); t is tile-relative
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[qf == 0 ? first_train_frame : qf - 1];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (threadIdx.x == 0) {
         carry = 0;
     }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(BatchView v, int windo
     }
     // compaction of KEPT in rank order
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (threadIdx.x == 0) {
         carry = 0;
     }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         return;  // scan_kernel already set n_kp = 0
     }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const uint32_t* __restrict__ sorted = v.sorted + static_cast<size_t>(f) * v.maxM;
     const uint32_t* __restrict__ sorted_xy = v.keys + static_cast<size_t>(f) * v.maxM;  // left there by sort_kernel
     uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;

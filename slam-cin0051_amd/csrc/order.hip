@@ -376,7 +376,7 @@ template <typename PosT>
 __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
     if (tid == 0) {
         // __move_median_to_first(first, first+1, mid, last-1)
@@ -624,7 +624,7 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q
                                  int bit_base, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < SORT_QCAP; i += blockDim.x) {
         q.seq[i] = static_cast<uint32_t>(i);
     }

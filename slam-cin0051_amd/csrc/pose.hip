@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void pnp_dlt_kernel(const double* __restrict__
                                                       double* __restrict__ t_out, double* __restrict__ null_out) {
     extern __shared__ double pose_lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork) / sizeof(double)));
     const int rows = 2 * n_points;
     for (int h = blockIdx.x * 4 + wave; h < n_hyp; h += gridDim.x * 4) {  // wave-uniform
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void essential_8pt_kernel(const double* __rest
                                                             int n_hyp, double* __restrict__ E_out) {
     extern __shared__ double pose_lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork) / sizeof(double)));
     for (int h = blockIdx.x * 4 + wave; h < n_hyp; h += gridDim.x * 4) {  // wave-uniform
         const double* a = x1 + static_cast<size_t>(h) * 16;
