@@ -190,9 +190,11 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
             const us2 r_hi = __builtin_bit_cast(us2, __builtin_amdgcn_perm(Nx, C, 0x0c060c05u));
             const uint32_t p01 = cardinal_test(clo[jc], clo[k], clo[jn], l_lo, r_lo, t2);
             const uint32_t p23 = cardinal_test(chi[jc], chi[k], chi[jn], l_hi, r_hi, t2);
-            const us2 one = {1, 1};
-            const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, p01), one));
-            const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, p23), one));
+            // non-zero u16 -> 1: one v_pk_min_u16 each (spelled as asm: the compiler otherwise turns
+            // min(x, 1) into two compares, two selects and a permute)
+            uint32_t b01, b23;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(b01) : "v"(p01), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(b23) : "v"(p23), "v"(0x00010001u));
             acc01 |= b01 << k;
             acc23 |= b23 << k;
         }
