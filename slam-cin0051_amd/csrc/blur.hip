@@ -43,12 +43,6 @@ constexpr int FIX_CAP = 2048;                // uncertain pixels listed per tile
 constexpr float UNC_LO = 0.5f - 6.5e-4f;
 constexpr float UNC_SPAN = 1.3e-3f;
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float ub(uint32_t w, int k) {  // byte k of w as float (v_cvt_f32_ubyteK)
-    return static_cast<float>((w >> (8 * k)) & 0xffu);
-}
-
 // the reference's sum for the pixel whose centre byte is at pc in the LDS tile
 __device__ __forceinline__ uint32_t exact_pixel(const uint8_t* pc, const double* wgt) {
     double acc = 0.0;
@@ -121,7 +115,6 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     }
     __syncthreads();
     const float g0 = g[0], g1 = g[1], g2 = g[2];  // g[3] == g[1], g[4] == g[0]
-    const f2 G0 = {g0, g0}, G1 = {g1, g1}, G2 = {g2, g2};
     // bytes of the output dword that are image border (columns < 2 or >= cols - 2): copied (:355-361)
     uint32_t keep = 0;
 #pragma unroll
@@ -132,13 +125,18 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     }
     const bool writer = lane >= 1 && lane <= 62 && x < v.cols;
     {
-        // rolling window of 5 input rows x this lane's 4 columns as 2 float pairs, converted once per row
-        f2 win[5][2];
+        // rolling window of 5 input rows x this lane's 4 columns, converted once per row
+        // (v_cvt_f32_ubyte0..3).  Scalar VOP2 float math on purpose: v_add_f32 / v_fmac_f32 issue at
+        // twice the rate of the packed VOP3P forms, which makes them cheaper than v_pk_* even per lane
+        // (tools/microbench/op_rates.hip).
+        float win[5][4];
         uint32_t centre[5];
-        auto load_row = [&](int lds_row, f2* dst, uint32_t* mid) {
+        auto load_row = [&](int lds_row, float* dst, uint32_t* mid) {
             const uint32_t w = tile[lds_row * LDS_ROW_DW + lane];
-            dst[0] = f2{ub(w, 0), ub(w, 1)};
-            dst[1] = f2{ub(w, 2), ub(w, 3)};
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(dst[0]) : "v"(w));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(dst[1]) : "v"(w));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(dst[2]) : "v"(w));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(dst[3]) : "v"(w));
             *mid = w;
         };
         const int ry0 = wave * ROWS_PER_WAVE;  // this wave's output rows ry0 .. ry0+RPW-1 (tile-relative)
@@ -157,17 +155,15 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
             const uint32_t src = centre[(k + 2) % 5];
             uint32_t packed = src;
             if (y >= HALO && y < v.rows - HALO) {  // wave-uniform
-                const f2* rm2 = win[(k + 0) % 5];
-                const f2* rm1 = win[(k + 1) % 5];
-                const f2* rc = win[(k + 2) % 5];
-                const f2* rp1 = win[(k + 3) % 5];
-                const f2* rp2 = win[(k + 4) % 5];
+                const float* rm2 = win[(k + 0) % 5];
+                const float* rm1 = win[(k + 1) % 5];
+                const float* rc = win[(k + 2) % 5];
+                const float* rp1 = win[(k + 3) % 5];
+                const float* rp2 = win[(k + 4) % 5];
                 float h[8];  // vertical pass of columns x-2 .. x+5; h[2..5] are this lane's own
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f2 hv = __builtin_elementwise_fma(G0, rm2[c] + rp2[c], __builtin_elementwise_fma(G1, rm1[c] + rp1[c], G2 * rc[c]));
-                    h[2 + 2 * c] = hv.x;
-                    h[3 + 2 * c] = hv.y;
+                for (int c = 0; c < 4; ++c) {
+                    h[2 + c] = fmaf(g0, rm2[c] + rp2[c], fmaf(g1, rm1[c] + rp1[c], g2 * rc[c]));
                 }
                 h[0] = from_left(h[4]);
                 h[1] = from_left(h[5]);
