@@ -271,6 +271,15 @@ struct TilePrefetch {
     }
 };
 
+// value of lane `src` (wave-uniform index) as a scalar: v_readlane_b32, so that everything derived
+// from it (tile base address, alignment, bounds tests) stays on the SALU
+__device__ __forceinline__ int lane_value(int v, int src) {
+    return __builtin_amdgcn_readlane(v, src);
+}
+__device__ __forceinline__ float lane_value(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
 // sum over the 64 lanes (DPP row reductions + row broadcasts; the total lands in lane 63)
 __device__ __forceinline__ int wave_sum_dpp(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
@@ -348,15 +357,15 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
             issue(x, y, nxt);
         }
         for (int k = 0; k < cnt; ++k) {
-            const int slot = __shfl(kslot, k);
+            const int slot = lane_value(kslot, k);
             const bool inside = is_inside(x, y);  // wave-uniform
             uint32_t cur[SLOTS];
 #pragma unroll
             for (int q = 0; q < SLOTS; ++q) {
                 cur[q] = nxt[q];
             }
-            const int xn = __shfl(kx, (k + 1) & 63);
-            const int yn = __shfl(ky, (k + 1) & 63);
+            const int xn = lane_value(kx, (k + 1) & 63);
+            const int yn = lane_value(ky, (k + 1) & 63);
             if (k + 1 < cnt && is_inside(xn, yn)) {
                 issue(xn, yn, nxt);
             }
@@ -499,15 +508,15 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
             ks = r.y;
         }
         const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
-        int x = __shfl(kx, 0);
-        int y = __shfl(ky, 0);
-        float ca = __shfl(kc, 0);
-        float sa = __shfl(ks, 0);
+        int x = lane_value(kx, 0);
+        int y = lane_value(ky, 0);
+        float ca = lane_value(kc, 0);
+        float sa = lane_value(ks, 0);
         if (ca == ca) {
             fetch(x, y);
         }
         for (int k = 0; k < cnt; ++k) {
-            const int i = __shfl(kslot, k);
+            const int i = lane_value(kslot, k);
             uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
             const bool inside = ca == ca;  // NaN cos marks "patch leaves the image" (wave-uniform)
             if (!one_chunk && lane < words) {
@@ -517,10 +526,10 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
             if (inside) {
                 pf.commit(tile[wave], lane);
             }
-            const int xn = __shfl(kx, (k + 1) & 63);
-            const int yn = __shfl(ky, (k + 1) & 63);
-            const float can = __shfl(kc, (k + 1) & 63);
-            const float san = __shfl(ks, (k + 1) & 63);
+            const int xn = lane_value(kx, (k + 1) & 63);
+            const int yn = lane_value(ky, (k + 1) & 63);
+            const float can = lane_value(kc, (k + 1) & 63);
+            const float san = lane_value(ks, (k + 1) & 63);
             if (k + 1 < cnt && can == can) {
                 fetch(xn, yn);
             }
