@@ -213,6 +213,10 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
 #define SLAMX_STAGE_EMIT 11      /* emit_kernel                                */
 #define SLAMX_STAGE_COUNT 12
 int slamx_batch_set_profiling(slamx_batch* b, int n_sets);
+/* Same, but only every `every`-th detect_and_compute call (and the match that follows it) records:
+ * an event between two kernels keeps the second from starting while the first drains, which costs
+ * ~9 % of a 13-kernel step; call k * every lands in set k % n_sets. */
+int slamx_batch_set_profiling_every(slamx_batch* b, int n_sets, int every);
 int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms /* SLAMX_STAGE_COUNT entries */);
 
 /* ---- small dense pose solves (src/backend/loop_closure.cpp, src/frontend/simple_pose_recover.cpp) ----

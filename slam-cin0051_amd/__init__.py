@@ -93,7 +93,7 @@ EXPORTS = [
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
+    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
 ]
@@ -154,6 +154,7 @@ def load_library():
     lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
+    lib.slamx_batch_set_profiling_every.argtypes = [vp, C.c_int, C.c_int]
     lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     lib.slamx_pnp_dlt_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.slamx_count_inliers_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, vp]
@@ -602,8 +603,8 @@ class Batch:
                                                      out.shape[0], C.byref(n)))
         return out[: n.value].copy()
 
-    def set_profiling(self, n_sets=1):
-        _check(self.lib.slamx_batch_set_profiling(self.h, n_sets))
+    def set_profiling(self, n_sets=1, every=1):
+        _check(self.lib.slamx_batch_set_profiling_every(self.h, n_sets, every))
 
     def stage_ms(self, set_index=0):
         ms = (C.c_float * len(STAGES))()

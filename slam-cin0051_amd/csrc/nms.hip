@@ -496,7 +496,17 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             const int xr = x - cx * w;
             const int yr = y - cy * w;
             const uint32_t* cell = nms_grid + (cy + 1) * gx2 + (cx + 1);  // the grid has a one-cell empty rim
-            // 3 x 3 cells, two entries per cell at once
+            // 3 x 3 cells, two entries per cell at once.  All nine reads are issued before the first is
+            // used (the wave is alone on its SIMD: every separate wait is a full LDS round trip).
+            uint32_t cw[9];
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+#pragma unroll
+                for (int i = -1; i <= 1; ++i) {
+                    cw[(j + 1) * 3 + (i + 1)] = cell[j * gx2 + i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             u2 hit = {0, 0};
 #pragma unroll
             for (int j = -1; j <= 1; ++j) {
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                 const s2 YR = {yj, yj};
 #pragma unroll
                 for (int i = -1; i <= 1; ++i) {
-                    const uint32_t word = cell[j * gx2 + i];
+                    const uint32_t word = cw[(j + 1) * 3 + (i + 1)];
                     const short xi = static_cast<short>(xr - i * w);
                     const s2 XR = {xi, xi};
                     const s2 OX = __builtin_bit_cast(s2, word & 0x00ff00ffu);
@@ -525,13 +535,19 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             if (alive) {
                 atomicAdd(&tab[cidx & tab_mask], 1u);
             }
-            uint32_t crowd = 0;
+            uint32_t tw[9];
 #pragma unroll
             for (int j = -1; j <= 1; ++j) {
 #pragma unroll
                 for (int i = -1; i <= 1; ++i) {
-                    crowd += tab[(cidx + j * gx2 + i) & tab_mask];
+                    tw[(j + 1) * 3 + (i + 1)] = tab[(cidx + j * gx2 + i) & tab_mask];
                 }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint32_t crowd = 0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                crowd += tw[q];
             }
             const bool lonely = alive && crowd == 1u;
             if (alive) {

@@ -113,6 +113,9 @@ struct slamx_batch {
     std::vector<char> ev_valid;
     long long calls = 0;  // detect_and_compute calls since profiling was switched on
     int cur_set = 0;
+    int every = 1;        // only every `every`-th call records events (an event between two kernels keeps
+                          // the second from ramping up while the first drains: ~9 % on the bench step)
+    bool active = false;  // the current call records
     int last_frames = 0;
 };
 
@@ -213,14 +216,14 @@ int status_to_error(int st, int frame) {
 }
 
 void record(slamx_batch* b, int idx) {
-    if (b->n_sets > 0) {
+    if (b->n_sets > 0 && b->active) {
         const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx;
         (void)hipEventRecord(b->ev[k], b->det->ctx->stream);
         b->ev_valid[k] = 1;
     }
 }
 hipEvent_t event_slot(slamx_batch* b, int idx) {  // mark as recorded by a launcher
-    if (b->n_sets <= 0) {
+    if (b->n_sets <= 0 || !b->active) {
         return nullptr;
     }
     const size_t k = static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx;
@@ -228,15 +231,18 @@ hipEvent_t event_slot(slamx_batch* b, int idx) {  // mark as recorded by a launc
     return b->ev[k];
 }
 bool recorded(const slamx_batch* b, int idx) {
-    return b->n_sets > 0 && b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx] != 0;
+    return b->n_sets > 0 && b->active && b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + idx] != 0;
 }
 void begin_set(slamx_batch* b) {
     if (b->n_sets > 0) {
-        b->cur_set = static_cast<int>(b->calls % b->n_sets);
-        b->calls++;
-        for (int i = 0; i < slamx_batch::NEV; ++i) {
-            b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + i] = 0;
+        b->active = b->calls % b->every == 0;
+        if (b->active) {
+            b->cur_set = static_cast<int>((b->calls / b->every) % b->n_sets);
+            for (int i = 0; i < slamx_batch::NEV; ++i) {
+                b->ev_valid[static_cast<size_t>(b->cur_set) * slamx_batch::NEV + i] = 0;
+            }
         }
+        b->calls++;
     }
 }
 
@@ -890,6 +896,13 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
 }
 
 int slamx_batch_set_profiling(slamx_batch* b, int n_sets) {
+    return slamx_batch_set_profiling_every(b, n_sets, 1);
+}
+
+int slamx_batch_set_profiling_every(slamx_batch* b, int n_sets, int every) {
+    if (every < 1) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "profiling stride must be at least 1");
+    }
     if (n_sets < 0 || n_sets > 4096) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "n_sets out of range");
     }
@@ -905,6 +918,8 @@ int slamx_batch_set_profiling(slamx_batch* b, int n_sets) {
     b->n_sets = n_sets;
     b->calls = 0;
     b->cur_set = 0;
+    b->every = every;
+    b->active = false;
     for (auto& e : b->ev) {
         HIP_TRY(hipEventCreate(&e));
     }
