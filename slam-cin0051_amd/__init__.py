@@ -16,6 +16,7 @@ Context constructor raise -- there is no CPU fallback.
 The directory name contains a hyphen, so load it with importlib (see __graft_entry__.py /
 tests/conftest.py) under the module name ``slam_cin0051_amd``.
 """
+import atexit
 import ctypes as C
 import os
 import weakref
@@ -234,6 +235,22 @@ def _close_children(parent):
         child.close()
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def _close_all_contexts():
+    """Handles are released while the HIP runtime is still up: objects that survive until interpreter
+    shutdown would otherwise call hipFree after the runtime's own teardown."""
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all_contexts)
+
+
 class Context:
     """One per GPU: owns the HIP stream every call is enqueued on."""
 
@@ -242,6 +259,7 @@ class Context:
         self.h = C.c_void_p()
         _check(self.lib.slamx_ctx_create(device, stream, C.byref(self.h)))
         self._children = weakref.WeakSet()  # detectors / matchers: destroyed before the context
+        _live_contexts.add(self)
 
     def close(self):
         if self.h:
