@@ -271,14 +271,15 @@ def main():
             "nms_build": 9.0 * M + 28.0 * N,       # greedy NMS: sorted key + (x,y) read, state byte, keypoint + slot written
             "nms_rounds": 4.0 * M,                 # (only the generic NMS path has rounds: ~0 on the greedy path)
             "blur": 2.0 * px,                      # frame read, blurred frame written
-            "moments": 961.0 * N + 8 * N, "trig": 16.0 * N + 12 * N,
-            "brief": 43 * 48.0 * N + 32 * N,       # 43 x 48-byte neighbourhood read, descriptor written
+            # orientation + BRIEF are one kernel (describe_fused_kernel, reported under "moments"): the
+            # 43 x 48-byte neighbourhood of every keypoint read once, angle + descriptor written
+            "moments": 43 * 48.0 * N + 8 * N + 4 * N + 32 * N, "trig": 0.0, "brief": 0.0,
             "emit": 24.0 * N,
         }
         dom = max(stage, key=lambda k: stage[k])
         kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
                      "brief": "brief_kernel", "nms_build": "nms_greedy_kernel", "sort": "sort_kernel",
-                     "moments": "moments_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
+                     "moments": "describe_fused_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
         if dom == "match":
             # executed algorithmic work: xor + popcount-accumulate per live 32-bit word per pair;
             # SURVEY.md 8d's figure (16 ops per 256-bit pair) is reported next to it
@@ -308,7 +309,7 @@ def main():
             if k == "match":
                 o = 2.0 * live_words * N * N * B / (stage[k] * 1e-3) / 1e9
                 others[k] = {"ms": stage[k], "achieved": o, "unit": "Gop/s", "frac": o / VALU_HAMMING_PEAK_GOPS}
-            else:
+            elif hbm_bytes[k] > 0:
                 g = hbm_bytes[k] * B / (stage[k] * 1e-3) / 1e9
                 others[k] = {"ms": stage[k], "achieved": g, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}
         # the HBM-bound front-end as a whole: B_fe = 4WH + 16M + 52N bytes per frame

@@ -17,6 +17,8 @@
 //    advancing bitIndex, :268-280): per 64-pair chunk the wave ballots `valid` and `bit`, lane k
 //    picks the k-th valid pair's bit (select on the ballot) and a second ballot is the packed
 //    run, appended at the running bit offset.
+#include <cstdlib>
+
 #include "glibc_trig.h"
 #include "slamx_internal.h"
 
@@ -609,6 +611,210 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     }
 }
 
+// ---- orientation + BRIEF in ONE pass over the blurred frame (PatchSize <= 31, <= 64 surviving pairs) ----
+// moments_kernel and brief_kernel each read every blurred frame from HBM once (the patches of ~2k
+// keypoints cover a 1080p frame), which is all their time.  Here a wave takes 4 keypoints per round and
+// keeps their 43 x 48-byte tiles in LDS across three phases (no workgroup barriers):
+//   A  per keypoint: tile -> LDS; the moments patch is dword-aligned inside that tile (its first
+//      column (x-15) & ~3 is 4 or 8 bytes right of the tile's (x-21) & ~3), so the moments are the
+//      same v_dot4 sums as in moments_kernel, read from LDS
+//   B  atan2f -> degrees -> cosf, sinf, one keypoint per lane (the serial glibc chain)
+//   C  per keypoint: the BRIEF samples from the tile that is still in LDS
+// One HBM read of the frame instead of two; results identical to the three-kernel path.
+constexpr int FUSED_PER_WAVE = 4;  // keypoints (= LDS tiles) a wave carries through the three phases
+
+__global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
+                                                             int nframes, int blocks_per_frame, int use_visit) {
+    __shared__ uint32_t tiles[4][FUSED_PER_WAVE][TILE_ROWS * TILE_DW];
+    int f, bx;
+    if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int n = v.n_kp[f];
+    const int radius = P.patch / 2;
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+    const int words = v.width / 8;
+    // per-lane constants: tile dword offsets, moments slots and weights, this lane's pattern pair
+    TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
+    int tile_off[TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF>::PER_LANE];
+    pf.init_offsets(v.pitch, lane, tile_off);
+    constexpr int SLOTS = 5;
+    int mom_idx[SLOTS], vrow[SLOTS];  // tile dword of moments slot k (before the 1- or 2-dword column shift)
+    uint2 wgt[4][SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int e = lane + 64 * k;
+        const int ee = e < MOM_ROWS * MOM_DW ? e : 0;
+        const int r = ee / MOM_DW;
+        mom_idx[k] = (r + (TILE_HALF - MOM_HALF)) * TILE_DW + (ee - r * MOM_DW);
+        vrow[k] = r - MOM_HALF;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            wgt[a][k] = P.moment_weights[(a * SLOTS + k) * 64 + lane];
+        }
+    }
+    float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f;
+    if (lane < P.pattern_len) {
+        q1x = static_cast<float>(pattern[4 * lane + 0]);
+        q1y = static_cast<float>(pattern[4 * lane + 1]);
+        q2x = static_cast<float>(pattern[4 * lane + 2]);
+        q2y = static_cast<float>(pattern[4 * lane + 3]);
+    }
+    const unsigned long long all_pairs = low_mask_d(P.pattern_len);
+    auto fetch = [&](int x, int y) {  // wave-uniform choice: no per-element bounds checks when the tile is inside
+        const int xa = (x - TILE_HALF) & ~3;
+        if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
+            pf.issue_inside(img, v.pitch, x, y, tile_off);
+        } else {
+            pf.issue(v, img, x, y, lane);
+        }
+    };
+    auto patch_inside = [&](int x, int y) {
+        return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
+    };
+    auto wave_fence = [] {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // the waves are independent: wave `gw` of the frame takes keypoint groups gw, gw + nwaves, ...
+    const int nwaves = blocks_per_frame * 4;
+    for (int g = bx * 4 + wave; g * FUSED_PER_WAVE < n; g += nwaves) {  // wave-uniform
+        // lane q < FUSED_PER_WAVE holds keypoint q of the group
+        int kslot = -1, kx = 0, ky = 0;
+        {
+            const int idx = g * FUSED_PER_WAVE + lane;
+            if (lane < FUSED_PER_WAVE && idx < n) {
+                kslot = use_visit ? static_cast<int>(visit[idx]) : idx;
+                kx = static_cast<int>(kps[kslot].x);
+                ky = static_cast<int>(kps[kslot].y);
+            }
+        }
+        // ---- phase A: tiles into LDS, moments (lane q keeps m01, m10 of keypoint q)
+        int my_m01 = 0, my_m10 = 0x7fffffff;
+        {
+            int xq = lane_value(kx, 0), yq = lane_value(ky, 0), sq = lane_value(kslot, 0);
+            if (sq >= 0 && patch_inside(xq, yq)) {
+                fetch(xq, yq);
+            }
+#pragma unroll
+            for (int q = 0; q < FUSED_PER_WAVE; ++q) {
+                const int x = xq, y = yq, slot = sq;
+                const bool inside = slot >= 0 && patch_inside(x, y);  // wave-uniform
+                if (inside) {
+                    pf.commit(tiles[wave][q], lane);
+                }
+                if (q + 1 < FUSED_PER_WAVE) {
+                    xq = lane_value(kx, q + 1);
+                    yq = lane_value(ky, q + 1);
+                    sq = lane_value(kslot, q + 1);
+                    if (sq >= 0 && patch_inside(xq, yq)) {
+                        fetch(xq, yq);  // in flight while the moments of keypoint q are reduced
+                    }
+                }
+                if (inside) {
+                    wave_fence();
+                    const int a = (x - MOM_HALF) & 3;
+                    const int shift = a < 2 ? 2 : 1;  // ((x-15) & ~3) - ((x-21) & ~3) is 8 or 4 bytes
+                    uint32_t cur[SLOTS];
+#pragma unroll
+                    for (int k = 0; k < SLOTS; ++k) {
+                        cur[k] = tiles[wave][q][mom_idx[k] + shift];
+                    }
+                    uint32_t su = 0, s = 0;
+                    int sv = 0;
+                    auto reduce = [&](const uint2* w) {
+#pragma unroll
+                        for (int k = 0; k < SLOTS; ++k) {
+                            su = __builtin_amdgcn_udot4(cur[k], w[k].x, su, false);
+                            const uint32_t row = __builtin_amdgcn_udot4(cur[k], w[k].y, 0u, false);
+                            s += row;
+                            sv += vrow[k] * static_cast<int>(row);
+                        }
+                    };
+                    switch (a) {  // wave-uniform
+                        case 0: reduce(wgt[0]); break;
+                        case 1: reduce(wgt[1]); break;
+                        case 2: reduce(wgt[2]); break;
+                        default: reduce(wgt[3]); break;
+                    }
+                    const int m10 = wave_sum_dpp(static_cast<int>(su) - MOM_HALF * static_cast<int>(s));
+                    const int m01 = wave_sum_dpp(sv);
+                    if (lane == q) {
+                        my_m01 = m01;
+                        my_m10 = m10;
+                    }
+                }
+            }
+        }
+        // ---- phase B: angle, cos, sin -- lane q for keypoint q (the serial glibc chain)
+        float my_cos = __uint_as_float(0x7fc00000u);  // NaN cos marks "outside"
+        float my_sin = 0.0f;
+        if (kslot >= 0) {
+            float angle = 0.0f;
+            if (my_m10 != 0x7fffffff) {
+                angle = __fmul_rn(glibc_atan2f(static_cast<float>(my_m01), static_cast<float>(my_m10)), rad_to_deg());
+                const float ar = __fmul_rn(angle, deg_to_rad());
+                my_cos = glibc_cosf(ar);
+                my_sin = glibc_sinf(ar);
+            }
+            kps[kslot].angle = angle;  // feature_detector.cpp:37-38
+        }
+        // ---- phase C: BRIEF from the tiles still in LDS
+#pragma unroll
+        for (int q = 0; q < FUSED_PER_WAVE; ++q) {
+            const int slot = lane_value(kslot, q);
+            if (slot < 0) {
+                continue;  // wave-uniform
+            }
+            const int x = lane_value(kx, q);
+            const int y = lane_value(ky, q);
+            const float ca = lane_value(my_cos, q);
+            const float sa = lane_value(my_sin, q);
+            unsigned long long packed = 0;
+            if (ca == ca) {
+                const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tiles[wave][q]);
+                const int cx = x - ((x - TILE_HALF) & ~3);  // pixel (x+du, y+dv) at t8[(dv+21)*48 + cx + du]
+                bool valid = false;
+                bool bit = false;
+                if (lane < P.pattern_len) {
+                    const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(q1x, ca), __fmul_rn(q1y, sa)));
+                    const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(q1x, sa), __fmul_rn(q1y, ca)));
+                    const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(q2x, ca), __fmul_rn(q2y, sa)));
+                    const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(q2x, sa), __fmul_rn(q2y, ca)));
+                    const int x1 = dx1 + x, y1 = dy1 + y, x2 = dx2 + x, y2 = dy2 + y;
+                    valid = x1 >= 0 && x1 < v.cols && y1 >= 0 && y1 < v.rows && x2 >= 0 && x2 < v.cols && y2 >= 0 &&
+                            y2 < v.rows;
+                    if (valid) {
+                        const uint8_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
+                        const uint8_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
+                        bit = I1 < I2;
+                    }
+                }
+                const unsigned long long vm = __ballot(valid);
+                const unsigned long long bm = __ballot(valid && bit);
+                packed = bm;  // every pair valid: nothing to close up
+                if (vm != all_pairs) {
+                    const int c2 = __popcll(vm);
+                    bool outbit = false;
+                    if (lane < c2) {
+                        outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                    }
+                    packed = __ballot(outbit);
+                }
+            }
+            if (lane < words) {  // descriptor rows are 8-byte aligned (width % 8 == 0)
+                uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + slot) * v.width;
+                reinterpret_cast<unsigned long long*>(desc)[lane] = lane == 0 ? packed : 0ull;
+            }
+        }
+        wave_fence();  // the tiles are overwritten by the next group
+    }
+}
+
 }  // namespace
 
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
@@ -626,6 +832,19 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     }
     const int exact_int = (255LL * sum_abs < (1LL << 24)) ? 1 : 0;
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
+    if (radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 && v.width % 8 == 0 &&
+        getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr) {
+        const int bpf = static_cast<int>(grid.x);
+        hipLaunchKernelGGL(describe_fused_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, p, pattern_dev, nframes,
+                           bpf, use_visit ? 1 : 0);
+        if (ev_after_moments != nullptr) {
+            (void)hipEventRecord(ev_after_moments, stream);
+        }
+        if (ev_after_trig != nullptr) {
+            (void)hipEventRecord(ev_after_trig, stream);
+        }
+        return;
+    }
     if (radius <= 15 && exact_int != 0 && v.moments != nullptr) {
         const int bpf = static_cast<int>(grid.x);
         const dim3 grid1d(frame_grid(nframes, bpf));
