@@ -832,8 +832,10 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     }
     const int exact_int = (255LL * sum_abs < (1LL << 24)) ? 1 : 0;
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
-    if (radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 && v.width % 8 == 0 &&
-        getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr) {
+    // SLAMX_NO_FUSED_DESCRIBE=1 keeps the three-kernel path (used by the tests to cover it)
+    static const bool fused_allowed = getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr;
+    if (fused_allowed && radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 &&
+        v.width % 8 == 0) {
         const int bpf = static_cast<int>(grid.x);
         hipLaunchKernelGGL(describe_fused_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, p, pattern_dev, nframes,
                            bpf, use_visit ? 1 : 0);

@@ -14,16 +14,20 @@ pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "tools", "bin")
 
 
-def _run(args):
-    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+def _run(args, env=None):
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env=dict(os.environ, **env) if env else None)
     assert p.returncode == 0, p.stderr.decode()
     return p.stdout.decode()
 
 
-def test_feature_detector_program(slamx, oracle, ref_data, tmp_path):
+@pytest.mark.parametrize("env", [None, {"SLAMX_NO_FUSED_DESCRIBE": "1"}], ids=["fused-describe", "three-kernel-describe"])
+def test_feature_detector_program(slamx, oracle, ref_data, tmp_path, env):
+    """Both describe paths (the fused orientation + BRIEF kernel and the moments / trig / brief kernels
+    it replaces for the standard pattern) give the oracle's keypoints and descriptors."""
     img_path = os.path.join(ref_data, "images", "0000000000.png")
     out = str(tmp_path / "det.bin")
-    text = _run([os.path.join(BIN, "test_feature_detector"), os.path.join(ref_data, "feature_detector.yml"), img_path, out])
+    text = _run([os.path.join(BIN, "test_feature_detector"), os.path.join(ref_data, "feature_detector.yml"), img_path, out], env)
     assert "Detected" in text and "DetectAndCompute" in text
     img = load_gray(img_path)
     P = oracle.det_params(slamx.load_detector_config(os.path.join(ref_data, "feature_detector.yml")))
