@@ -21,7 +21,8 @@ namespace slamx {
 
 namespace {
 
-constexpr int TILE = 256;
+constexpr int TILE = 256;        // queries per workgroup and query slot (= threads)
+constexpr int TRAIN_TILE = 256;  // train descriptors staged in LDS at a time; the queues are drained at its end
 constexpr int EVQ_DEPTH = 32;  // deferred-update queue entries per lane
 
 // WORDS = 32-bit words compared per descriptor (the "live" prefix: words that can be non-zero in
@@ -44,8 +45,8 @@ template <int WORDS, int QPL>
 __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_query_frame, int first_train_frame,
                                                     int stride, int npairs, int qblocks) {
     static_assert(QPL == 2 || QPL == 4, "queries are filtered in packed pairs");
-    __shared__ uint32_t tdesc[TILE * WORDS];
-    __shared__ float2 txy[TILE];
+    __shared__ uint32_t tdesc[TRAIN_TILE * WORDS];
+    __shared__ float2 txy[TRAIN_TILE];
     __shared__ uint16_t evq[4][EVQ_DEPTH * 64];  // per wave: entry k of lane l at [k * 64 + l]
     // 1-D grid, pair index fastest: workgroups are dealt to the 8 XCDs round-robin in launch order,
     // so a grid with the query-block index fastest (8 blocks per pair, the last ones empty) would
@@ -185,17 +186,19 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
     const int t_begin = split * chunk;
     const int t_end = min(n2, t_begin + chunk);
-    for (int t0 = t_begin; t0 < t_end; t0 += TILE) {
-        const int tn = min(TILE, t_end - t0);
+    for (int t0 = t_begin; t0 < t_end; t0 += TRAIN_TILE) {
+        const int tn = min(TRAIN_TILE, t_end - t0);
         __syncthreads();
         for (int e = threadIdx.x; e < tn * WORDS; e += 256) {
             const int j = e / WORDS;
             const int w = e - j * WORDS;
             tdesc[e] = td[static_cast<size_t>(t0 + j) * stride + w];
         }
-        if (use_kp && static_cast<int>(threadIdx.x) < tn) {
-            const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + t0 + threadIdx.x];
-            txy[threadIdx.x] = make_float2(k.x, k.y);
+        if (use_kp) {
+            for (int e = threadIdx.x; e < tn; e += 256) {
+                const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + t0 + e];
+                txy[e] = make_float2(k.x, k.y);
+            }
         }
         __syncthreads();
         if (!wave_has_queries) {
