@@ -457,6 +457,27 @@ def test_camera_yaml_and_undistort(slamx, gpu_ctx, oracle, ref_data):
         gpu_ctx.undistort(cam, img[:100])
 
 
+@pytest.mark.parametrize("shape", [(37, 53), (64, 64), (45, 700), (101, 257), (250, 1000), (333, 249), (500, 47)])
+@pytest.mark.parametrize("window", [3, 12])
+def test_pipeline_odd_shapes(slamx, oracle, shape, window):
+    """detectAndCompute + match on image sizes that are not multiples of any tile (ragged last tiles,
+    keypoints within 21 pixels of every border, images narrower than one tile)."""
+    rows, cols = shape
+    d = slamx.FeatureDetector(cfg_of(slamx, window=window))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 20, 1, 0.7))
+    mp = oracle.match_params(m.cfg)
+    imgs = [np.ascontiguousarray(synth(slamx, k, 512, 1024, 2500, rmin=3, rmax=14)[:rows, :cols]) for k in range(2)]
+    got = [d.detectAndCompute(i) for i in imgs]
+    ref = [oracle.detect_and_compute(i, Pp) for i in imgs]
+    for k in range(2):
+        assert_records_equal(got[k][0], ref[k][0], "%s window %d frame %d keypoints" % (shape, window, k))
+        assert np.array_equal(got[k][1], ref[k][1])
+    if len(ref[0][0]) and len(ref[1][0]):
+        want = oracle.match(ref[1][1], ref[0][1], ref[1][0], ref[0][0], mp)
+        assert_records_equal(m.match(got[1][1], got[0][1], got[1][0], got[0][0]), want, "%s matches" % (shape,))
+
+
 # ---------------------------------------------------------------- BASELINE.json full-size workloads
 @pytest.mark.parametrize("name,rows,cols,window,n_rect,rmin,rmax", [
     ("1080p_2k", 1080, 1920, 12, 6800, 3, 24),   # bench.py default workload (the metric's config)
