@@ -28,8 +28,8 @@ namespace {
 __device__ __constant__ int8_t CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 __device__ __constant__ int8_t CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 
-constexpr int TILE_W = 256;
-constexpr int TILE_H = 32;
+constexpr int TILE_W = FAST_TILE_W;
+constexpr int TILE_H = FAST_TILE_H;
 constexpr int HALO = 3;
 constexpr int LDS_ROW_DW = TILE_W / 4 + 2;   // 264 bytes: columns [x0-4, x0+260)
 constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 38
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint16_t survivors[SURVIVOR_CAP];
     __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
+    __shared__ uint32_t corners[CORNER_LIST_CAP];  // score << 16 | row in tile << 8 | column in tile
     __shared__ int n_survivors;
+    __shared__ int n_corners;
     int f, tile_id;
     if (!frame_block(nframes, tiles_x * tiles_y, &f, &tile_id)) {
         return;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     }
     if (threadIdx.x == 0) {
         n_survivors = 0;
+        n_corners = 0;
     }
     __syncthreads();
     const int x = tx * TILE_W + lane * 4;
@@ -243,14 +246,20 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         const int lo = c - threshold;
         uint32_t B = 0;
         uint32_t D = 0;
+        uint32_t score = 0;  // computeFASTScore: sum of |circle pixel - centre| (feature_detector.cpp:190-203)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = p[CIRC_DY[q] * RS + CIRC_DX[q]];
             B |= static_cast<uint32_t>(n > hi) << q;
             D |= static_cast<uint32_t>(n < lo) << q;
+            score = __builtin_amdgcn_sad_u16(static_cast<uint32_t>(n), static_cast<uint32_t>(c), score);
         }
         if (segment_test(B, D, arc)) {
             atomicOr(&row_mask[ry][col >> 5], 1u << (col & 31));
+            const int slot = atomicAdd(&n_corners, 1);
+            if (slot < CORNER_LIST_CAP) {
+                corners[slot] = (score << 16) | static_cast<uint32_t>((ry << 8) | col);
+            }
         }
     };
     const int total = n_survivors;
@@ -284,6 +293,16 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
             masks[static_cast<size_t>(y) * v.nw + wx] = static_cast<unsigned long long>(row_mask[ry][2 * wq]) |
                                                         (static_cast<unsigned long long>(row_mask[ry][2 * wq + 1]) << 32);
         }
+    }
+    // the tile's corners with their scores, for expand_kernel (which falls back to the bitmap and the
+    // image when a tile holds more than the list does)
+    const int nc = n_corners;
+    const size_t tile_slot = static_cast<size_t>(f) * v.fast_tiles + tile_id;
+    if (threadIdx.x == 0) {
+        v.tile_count[tile_slot] = static_cast<uint32_t>(nc);
+    }
+    if (nc <= CORNER_LIST_CAP && static_cast<int>(threadIdx.x) < nc) {
+        v.tile_list[tile_slot * CORNER_LIST_CAP + threadIdx.x] = corners[threadIdx.x];
     }
 }
 
@@ -401,8 +420,8 @@ __device__ __forceinline__ int corner_score(const uint8_t* img, int pitch, int x
 // bitmap words at a time (coalesced 8-byte loads; about a quarter of the words hold corners, in
 // clusters), every lane peels off the set bits of its word and the wave compacts them into an LDS
 // list, so that the score of 64 corners at a time is computed on full waves.
-__global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, int blocks_per_frame) {
-    __shared__ uint2 list[4][128];  // per wave: {y << 16 | x, raster index}
+__global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, int blocks_per_frame, int tiles_x) {
+    __shared__ uint2 list[4][128];  // per wave: {y << 16 | x, raster index} (bitmap path only)
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
         return;
@@ -417,56 +436,89 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
     const unsigned long long* __restrict__ masks = v.masks + static_cast<size_t>(f) * n;
     const uint32_t* __restrict__ off = v.wordoff + static_cast<size_t>(f) * n;
     const uint8_t* __restrict__ img = v.frames + static_cast<size_t>(f) * v.frame_stride;
+    const uint32_t* __restrict__ tcount = v.tile_count + static_cast<size_t>(f) * v.fast_tiles;
+    const uint32_t* __restrict__ tlist = v.tile_list + static_cast<size_t>(f) * v.fast_tiles * CORNER_LIST_CAP;
     uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
     uint2* q = list[wave];
-    int cnt = 0;  // entries waiting in q (wave-uniform)
-    auto emit = [&](int count) {  // the first `count` (<= 64) entries of q
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < count) {
-            const uint2 e = q[lane];
-            const int x = static_cast<int>(e.x & 0xffffu);
-            const int y = static_cast<int>(e.x >> 16);
-            const int score = corner_score(img, v.pitch, x, y);
-            xy[e.y] = e.x;
-            keys[e.y] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | e.y;
+    for (int t = bx * 4 + wave; t < v.fast_tiles; t += blocks_per_frame * 4) {  // wave-uniform
+        const int nc = __builtin_amdgcn_readfirstlane(static_cast<int>(tcount[t]));
+        if (nc == 0) {
+            continue;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    for (int wbase = bx * 256 + wave * 64; wbase < n; wbase += blocks_per_frame * 256) {  // wave-uniform
-        const int w = wbase + lane;
-        unsigned long long m = w < n ? masks[w] : 0ull;
-        const int row = w / v.nw;
-        const int x0 = (w - row * v.nw) * 64;
-        uint32_t idx = m != 0 ? off[w] : 0u;
-        while (true) {
-            const bool has = m != 0;
-            const unsigned long long bal = __ballot(has);
-            if (bal == 0) {
-                break;
+        const int ty = t / tiles_x;
+        const int tx = t - ty * tiles_x;
+        if (nc <= CORNER_LIST_CAP) {
+            // the detector left position and score of every corner of the tile: the raster index is the
+            // word's prefix plus the corners before it in its bitmap word
+            for (int base = 0; base < nc; base += 64) {
+                const int i = base + lane;
+                if (i < nc) {
+                    const uint32_t e = tlist[static_cast<size_t>(t) * CORNER_LIST_CAP + i];
+                    const int x = tx * FAST_TILE_W + static_cast<int>(e & 0xffu);
+                    const int y = ty * FAST_TILE_H + static_cast<int>((e >> 8) & 0xffu);
+                    const int w = y * v.nw + (x >> 6);
+                    const unsigned long long below = masks[w] & ((1ull << (x & 63)) - 1ull);
+                    const uint32_t idx = off[w] + static_cast<uint32_t>(__popcll(below));
+                    xy[idx] = (static_cast<uint32_t>(y) << 16) | static_cast<uint32_t>(x);
+                    keys[idx] = ((e >> 16) << SCORE_SHIFT) | idx;
+                }
             }
-            if (has) {
-                const int b = __ffsll(static_cast<long long>(m)) - 1;
-                m &= m - 1;
-                const int slot = cnt + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
-                                           static_cast<uint32_t>(bal >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u)));
-                q[slot] = make_uint2((static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x0 + b), idx);
-                ++idx;
+            continue;
+        }
+        // crowded tile: walk its bitmap words and score the corners from the image
+        int cnt = 0;  // entries waiting in q (wave-uniform)
+        auto emit = [&](int count) {  // the first `count` (<= 64) entries of q
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < count) {
+                const uint2 e = q[lane];
+                const int x = static_cast<int>(e.x & 0xffffu);
+                const int y = static_cast<int>(e.x >> 16);
+                const int score = corner_score(img, v.pitch, x, y);
+                xy[e.y] = e.x;
+                keys[e.y] = (static_cast<uint32_t>(score) << SCORE_SHIFT) | e.y;
             }
-            cnt += __popcll(bal);
-            if (cnt >= 64) {
-                emit(64);
-                cnt -= 64;
-                if (lane < cnt) {  // move the tail to the front
-                    const uint2 e = q[64 + lane];
-                    q[lane] = e;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        constexpr int WPR = FAST_TILE_W / 64;  // bitmap words per tile row
+        for (int wbase = 0; wbase < FAST_TILE_H * WPR; wbase += 64) {
+            const int wi = wbase + lane;
+            const int row = ty * FAST_TILE_H + wi / WPR;
+            const int wx = tx * WPR + wi % WPR;
+            const bool inside = row < v.rows && wx < v.nw;
+            const int w = row * v.nw + wx;
+            unsigned long long m = inside ? masks[w] : 0ull;
+            const int x0 = wx * 64;
+            uint32_t idx = m != 0 ? off[w] : 0u;
+            while (true) {
+                const bool has = m != 0;
+                const unsigned long long bal = __ballot(has);
+                if (bal == 0) {
+                    break;
+                }
+                if (has) {
+                    const int b = __ffsll(static_cast<long long>(m)) - 1;
+                    m &= m - 1;
+                    const int slot = cnt + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                                               static_cast<uint32_t>(bal >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u)));
+                    q[slot] = make_uint2((static_cast<uint32_t>(row) << 16) | static_cast<uint32_t>(x0 + b), idx);
+                    ++idx;
+                }
+                cnt += __popcll(bal);
+                if (cnt >= 64) {
+                    emit(64);
+                    cnt -= 64;
+                    if (lane < cnt) {  // move the tail to the front
+                        const uint2 e = q[64 + lane];
+                        q[lane] = e;
+                    }
                 }
             }
         }
+        emit(cnt);
     }
-    emit(cnt);
 }
 
 }  // namespace
@@ -484,9 +536,9 @@ void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {
 
 void launch_expand(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
     (void)p;
-    const int n = v.rows * v.nw;
-    const int bpf = grid_x(n, 256, nframes);
-    hipLaunchKernelGGL(expand_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, nframes, bpf);
+    const int tiles_x = (v.cols + TILE_W - 1) / TILE_W;
+    const int bpf = grid_x(v.fast_tiles, 4, nframes);
+    hipLaunchKernelGGL(expand_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, nframes, bpf, tiles_x);
 }
 
 }  // namespace slamx

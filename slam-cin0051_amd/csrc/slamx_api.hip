@@ -627,6 +627,9 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&blurred, F * v.frame_stride + 64);
     A(&v.masks, F * nwords);
     A(&v.wordoff, F * nwords);
+    v.fast_tiles = ((v.cols + FAST_TILE_W - 1) / FAST_TILE_W) * ((v.rows + FAST_TILE_H - 1) / FAST_TILE_H);
+    A(&v.tile_count, F * v.fast_tiles);
+    A(&v.tile_list, F * v.fast_tiles * CORNER_LIST_CAP);
     A(&v.n_cand, F);
     A(&v.cand_xy, F * v.maxM);
     A(&v.keys, F * v.maxM);
@@ -683,6 +686,8 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.blurred);
     dev_free(v.masks);
     dev_free(v.wordoff);
+    dev_free(v.tile_count);
+    dev_free(v.tile_list);
     dev_free(v.n_cand);
     dev_free(v.cand_xy);
     dev_free(v.keys);

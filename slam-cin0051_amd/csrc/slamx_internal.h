@@ -29,6 +29,11 @@ constexpr int STATUS_CAND_OVERFLOW = 1;
 constexpr int STATUS_KP_OVERFLOW = 2;
 constexpr int STATUS_SEG_OVERFLOW = 4;
 
+// FAST tile geometry, shared by the detector (fast.hip) and the buffers sized for it (slamx_api.hip)
+constexpr int FAST_TILE_W = 256;
+constexpr int FAST_TILE_H = 32;
+constexpr int CORNER_LIST_CAP = 256;
+
 // Device view of a frame batch in HBM.  All per-frame arrays are [frame][capacity].
 struct BatchView {
     const uint8_t* frames;   // [F][rows][pitch] uint8, pitch % 64 == 0
@@ -38,6 +43,10 @@ struct BatchView {
     int nw;                  // 64-pixel words per row = ceil(cols/64)
     unsigned long long* masks;  // [F][rows*nw]  FAST corner bitmap, bit l of word w = pixel 64w+l
     uint32_t* wordoff;       // [F][rows*nw]  exclusive prefix of popcount(masks) in raster order
+    uint32_t* tile_count;    // [F][fast_tiles]  corners FAST found in each of its 256 x 32 tiles
+    uint32_t* tile_list;     // [F][fast_tiles][CORNER_LIST_CAP]  score<<16 | row-in-tile<<8 | column-in-tile;
+                             // not written for a tile whose count exceeds the capacity
+    int fast_tiles;          // tiles per frame
     int* n_cand;             // [F]  M
     uint32_t* cand_xy;       // [F][maxM]  y<<16|x, raster order
     uint32_t* keys;          // [F][maxM]  score<<20|raster idx; permuted in place by the sort
