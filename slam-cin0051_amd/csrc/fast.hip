@@ -39,14 +39,15 @@ constexpr int ROWS_PER_WAVE = TILE_H / 4;
 // is what lets 8 workgroups share a CU's LDS
 constexpr int SURVIVOR_CAP = 2048;
 
-// The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels.
+// The segment test of isFASTCorner on brighter/darker bit masks of the 16 circle pixels; circle pixel q
+// is bit 15 - q (the masks are built by shifting sign bits in), which a circular run does not mind.
 __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
     // pretest A (feature_detector.cpp:81-96): pixels 0 and 8
-    if (((B | D) & 0x0101u) == 0) {
+    if (((B | D) & 0x8080u) == 0) {
         return false;
     }
     // pretest B (:98-113): pixels 0,4,8,12 -- applied for every arc length, as the reference does
-    if (__popc(B & 0x1111u) < 3 && __popc(D & 0x1111u) < 3) {
+    if (__popc(B & 0x8888u) < 3 && __popc(D & 0x8888u) < 3) {
         return false;
     }
     // 32-step circular walk (:118-142): true iff the doubled sequence has a run >= arc.
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = p[CIRC_DY[q] * RS + CIRC_DX[q]];
-            B |= static_cast<uint32_t>(n > hi) << q;
-            D |= static_cast<uint32_t>(n < lo) << q;
+            // shift the sign of (hi - n) / (n - lo) in from the right: no compare, no select
+            B = __builtin_amdgcn_alignbit(B, static_cast<uint32_t>(hi - n), 31);
+            D = __builtin_amdgcn_alignbit(D, static_cast<uint32_t>(n - lo), 31);
             score = __builtin_amdgcn_sad_u16(static_cast<uint32_t>(n), static_cast<uint32_t>(c), score);
         }
         if (segment_test(B, D, arc)) {
@@ -289,9 +291,10 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         const int y = ty * TILE_H + ry;
         const int wx = tx * (TILE_W / 64) + wq;
         if (y < v.rows && wx < v.nw) {
-            unsigned long long* masks = v.masks + static_cast<size_t>(f) * v.rows * v.nw;
-            masks[static_cast<size_t>(y) * v.nw + wx] = static_cast<unsigned long long>(row_mask[ry][2 * wq]) |
-                                                        (static_cast<unsigned long long>(row_mask[ry][2 * wq + 1]) << 32);
+            const size_t w = static_cast<size_t>(f) * v.rows * v.nw + static_cast<size_t>(y) * v.nw + wx;
+            const uint32_t m_lo = row_mask[ry][2 * wq], m_hi = row_mask[ry][2 * wq + 1];
+            v.masks[w] = static_cast<unsigned long long>(m_lo) | (static_cast<unsigned long long>(m_hi) << 32);
+            v.wordcnt[w] = static_cast<uint8_t>(__popc(m_lo) + __popc(m_hi));
         }
     }
     // the tile's corners with their scores, for expand_kernel (which falls back to the bitmap and the
@@ -306,48 +309,58 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     }
 }
 
-// One workgroup per frame: exclusive scan of popcount(masks) over rows*nw words.
+// One workgroup per frame: exclusive scan of the per-word corner counts over rows*nw words.  A thread owns four
+// consecutive words per step; the running total lives in a register of every thread (all of them add up
+// the same 16 wave sums), so a step needs one barrier (the wave sums are double-buffered).
 __global__ __launch_bounds__(1024) void scan_kernel(BatchView v) {
-    __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t wave_sums[2][16];
     const int f = blockIdx.x;
     const int n = v.rows * v.nw;
-    const unsigned long long* masks = v.masks + static_cast<size_t>(f) * n;
-    uint32_t* off = v.wordoff + static_cast<size_t>(f) * n;
+    const uint8_t* __restrict__ cnt = v.wordcnt + static_cast<size_t>(f) * n;
+    uint32_t* __restrict__ off = v.wordoff + static_cast<size_t>(f) * n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    if (threadIdx.x == 0) {
-        carry = 0;
-    }
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t c = i < n ? static_cast<uint32_t>(__popcll(masks[i])) : 0u;
-        // inclusive wave scan
-        uint32_t s = c;
+    constexpr int PER = 4;
+    uint32_t carry = 0;  // corners before `base`, identical in all threads
+    int buf = 0;
+    for (int base = 0; base < n; base += 1024 * PER) {
+        const int i0 = base + static_cast<int>(threadIdx.x) * PER;
+        uint32_t c[PER];
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            c[k] = i0 + k < n ? static_cast<uint32_t>(cnt[i0 + k]) : 0u;
+            t += c[k];
+        }
+        uint32_t s = t;  // inclusive wave scan
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(s, d);
+            const uint32_t u = __shfl_up(s, d);
             if (lane >= d) {
-                s += t;
+                s += u;
             }
         }
         if (lane == 63) {
-            wave_sums[wave] = s;
+            wave_sums[buf][wave] = s;
         }
         __syncthreads();
-        uint32_t wbase = carry;
-        for (int w = 0; w < wave; ++w) {
-            wbase += wave_sums[w];
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t ws = wave_sums[buf][w];
+            before += w < wave ? ws : 0u;
+            total += ws;
         }
-        if (i < n) {
-            off[i] = wbase + s - c;
+        uint32_t run = carry + before + s - t;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (i0 + k < n) {
+                off[i0 + k] = run;
+            }
+            run += c[k];
         }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            carry = wbase + s;
-        }
-        __syncthreads();
+        carry += total;
+        buf ^= 1;
     }
     if (threadIdx.x == 0) {
         int m = static_cast<int>(carry);

@@ -21,6 +21,8 @@
 //                      emits the kept keypoints in rank order (feature_detector.cpp:170, :187).
 #include "slamx_internal.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace slamx {
@@ -445,8 +447,9 @@ typedef unsigned short u2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ uint32_t nms_grid[];
 
-__global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic, int tab_mask) {
-    __shared__ uint32_t wave_sums[4];
+__global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic, int tab_mask,
+                                                         int bitmap_words) {
+    __shared__ uint32_t wave_sums[2][4];
     __shared__ uint32_t carry;
     __shared__ int kept_total;
     const int f = blockIdx.x;
@@ -468,6 +471,16 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     uint32_t* tab = nms_grid + gx2 * gy2;
     for (int i = threadIdx.x; i <= tab_mask; i += 256) {
         tab[i] = 0;
+    }
+    // kept candidates as a bitmap over the raster index (for the visiting list at the end); candidate
+    // sets too large for it take the route through `state` in global memory
+    uint32_t* kept_bits = tab + tab_mask + 1;
+    const int n_words = (n + 31) >> 5;
+    const bool use_bits = n_words <= bitmap_words;  // block-uniform
+    if (use_bits) {
+        for (int i = threadIdx.x; i < n_words; i += 256) {
+            kept_bits[i] = 0;
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                     grid_overflow = grid_overflow || (prev >> 16) != 0x7f7fu;
                 }
                 const int pos = count + __popcll(kept & low_mask(lane));
+                const uint32_t idx = key & INDEX_MASK;
                 if (pos < v.maxK) {
                     slamx_keypoint kp;
                     kp.x = static_cast<float>(x);
@@ -584,10 +598,17 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                     kp.angle = 0.0f;
                     kp.response = static_cast<float>(key >> SCORE_SHIFT);
                     kps[pos] = kp;
-                    slot_of[key & INDEX_MASK] = static_cast<uint32_t>(pos);
+                    if (use_bits) {
+                        slot_of[pos] = idx;  // slot -> raster index, contiguous
+                    } else {
+                        slot_of[idx] = static_cast<uint32_t>(pos);
+                    }
+                }
+                if (use_bits) {
+                    atomicOr(&kept_bits[idx >> 5], 1u << (idx & 31u));
                 }
             }
-            if (valid) {
+            if (valid && !use_bits) {
                 state[key & INDEX_MASK] = mine ? NMS_KEPT : NMS_SUPPRESSED;
             }
             count += __popcll(kept);
@@ -608,7 +629,61 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     __syncthreads();
     const int total_kept = kept_total;
     // raster-order visiting list for the describe kernels (see nms_finish_kernel)
-    if (total_kept <= v.maxK) {
+    if (total_kept <= v.maxK && use_bits) {
+        // rank of a kept candidate among the kept ones = kept bits before it: exclusive prefix of the word
+        // popcounts (into the survivor table, which is dead now), then one independent lookup per keypoint
+        uint32_t* word_prefix = tab;
+        constexpr int PER = 8;
+        uint32_t run_total = 0;  // identical in all threads
+        int buf = 0;
+        for (int base = 0; base < n_words; base += 256 * PER) {
+            const int i0 = base + static_cast<int>(threadIdx.x) * PER;
+            uint32_t c[PER];
+            uint32_t t = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                c[k] = i0 + k < n_words ? static_cast<uint32_t>(__popc(kept_bits[i0 + k])) : 0u;
+                t += c[k];
+            }
+            uint32_t s = t;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(s, d);
+                if (lane >= d) {
+                    s += u;
+                }
+            }
+            if (lane == 63) {
+                wave_sums[buf][wave] = s;
+            }
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t ws = wave_sums[buf][q];
+                before += q < wave ? ws : 0u;
+                total += ws;
+            }
+            uint32_t run = run_total + before + s - t;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (i0 + k < n_words) {
+                    word_prefix[i0 + k] = run;
+                }
+                run += c[k];
+            }
+            run_total += total;
+            buf ^= 1;
+        }
+        __syncthreads();
+        uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+        for (int pos = threadIdx.x; pos < total_kept; pos += 256) {
+            const uint32_t idx = slot_of[pos];
+            const uint32_t w = idx >> 5;
+            const uint32_t below = kept_bits[w] & ((1u << (idx & 31u)) - 1u);
+            visit[word_prefix[w] + static_cast<uint32_t>(__popc(below))] = static_cast<uint32_t>(pos);
+        }
+    } else if (total_kept <= v.maxK) {
         uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
         for (int base = 0; base < n; base += 256) {
             const int i = base + threadIdx.x;
@@ -616,12 +691,12 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             const unsigned long long bm = __ballot(keep);
             const uint32_t c = static_cast<uint32_t>(__popcll(bm));
             if (lane == 0) {
-                wave_sums[wave] = c;
+                wave_sums[0][wave] = c;
             }
             __syncthreads();
             uint32_t wbase = carry;
             for (int q = 0; q < wave; ++q) {
-                wbase += wave_sums[q];
+                wbase += wave_sums[0][q];
             }
             if (keep) {
                 visit[wbase + static_cast<uint32_t>(__popcll(bm & low_mask(lane)))] = slot_of[i];
@@ -676,13 +751,23 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
             // (a power of two of dwords), but at most half of a CU's 160 KB when that is within reach, so that
             // two frames share a CU in batches of more than 256 frames
             const size_t budget = bytes + 4096 * 4 <= 80 * 1024 ? 80 * 1024 : static_cast<size_t>(GREEDY_LDS_BUDGET);
+            // the kept-candidate bitmap (one bit per candidate, up to 65536 of them) sits behind the table; its
+            // word prefix is built in the table, which therefore has at least as many entries as the bitmap words
+            int bitmap_words = (std::min(v.maxM, 65536) + 31) / 32;
             int tab_entries = 256;
-            while (tab_entries < 16384 && bytes + static_cast<size_t>(tab_entries) * 8 <= budget) {
+            while (tab_entries < bitmap_words) {
                 tab_entries *= 2;
             }
-            const size_t total = bytes + static_cast<size_t>(tab_entries) * 4;
+            if (bytes + static_cast<size_t>(tab_entries + bitmap_words) * 4 > budget) {
+                bitmap_words = 0;  // no room: the kernel goes through `state` in global memory
+                tab_entries = 256;
+            }
+            while (tab_entries < 16384 && bytes + static_cast<size_t>(bitmap_words) * 4 + static_cast<size_t>(tab_entries) * 8 <= budget) {
+                tab_entries *= 2;
+            }
+            const size_t total = bytes + static_cast<size_t>(tab_entries + bitmap_words) * 4;
             hipLaunchKernelGGL(nms_greedy_kernel, dim3(nframes), dim3(256), total, stream, v, p.window, gx2, gy2, magic,
-                               tab_entries - 1);
+                               tab_entries - 1, bitmap_words);
             if (ev_mid != nullptr) {
                 (void)hipEventRecord(ev_mid, stream);
             }

@@ -627,6 +627,7 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&blurred, F * v.frame_stride + 64);
     A(&v.masks, F * nwords);
     A(&v.wordoff, F * nwords);
+    A(&v.wordcnt, F * nwords);
     v.fast_tiles = ((v.cols + FAST_TILE_W - 1) / FAST_TILE_W) * ((v.rows + FAST_TILE_H - 1) / FAST_TILE_H);
     A(&v.tile_count, F * v.fast_tiles);
     A(&v.tile_list, F * v.fast_tiles * CORNER_LIST_CAP);
@@ -686,6 +687,7 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.blurred);
     dev_free(v.masks);
     dev_free(v.wordoff);
+    dev_free(v.wordcnt);
     dev_free(v.tile_count);
     dev_free(v.tile_list);
     dev_free(v.n_cand);

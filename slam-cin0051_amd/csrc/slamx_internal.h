@@ -43,6 +43,7 @@ struct BatchView {
     int nw;                  // 64-pixel words per row = ceil(cols/64)
     unsigned long long* masks;  // [F][rows*nw]  FAST corner bitmap, bit l of word w = pixel 64w+l
     uint32_t* wordoff;       // [F][rows*nw]  exclusive prefix of popcount(masks) in raster order
+    uint8_t* wordcnt;        // [F][rows*nw]  popcount(masks), written with the bitmap: all the prefix scan reads
     uint32_t* tile_count;    // [F][fast_tiles]  corners FAST found in each of its 256 x 32 tiles
     uint32_t* tile_list;     // [F][fast_tiles][CORNER_LIST_CAP]  score<<16 | row-in-tile<<8 | column-in-tile;
                              // not written for a tile whose count exceeds the capacity
