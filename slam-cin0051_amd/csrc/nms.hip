@@ -29,6 +29,16 @@ namespace slamx {
 
 namespace {
 
+__device__ __forceinline__ void wave_mem_fence() {  // LDS traffic of one wave: order it, keep the compiler from moving it
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int rank_below_mask(unsigned long long m) {  // set bits of m below this lane
+    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+}
+
 __device__ __forceinline__ unsigned long long low_mask(int nbits) {  // bits [0, nbits)
     return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
 }
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     __shared__ uint32_t wave_sums[2][4];
     __shared__ uint32_t carry;
     __shared__ int kept_total;
+    __shared__ uint2 stage[64];  // {y << 16 | x, key} of the candidates that passed the grid test, in rank order
     const int f = blockIdx.x;
     const int n = v.n_cand[f];
     if (n == 0) {
@@ -490,20 +501,17 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         int count = 0;
         bool grid_overflow = false;
         const int nchunks = (n + 63) / 64;
-        // software pipeline: the loads of chunk k+2 are in flight while chunk k is processed
-        uint32_t key_a = lane < n ? sorted[lane] : 0u;
-        uint32_t xy_a = lane < n ? sorted_xy[lane] : 0u;
-        uint32_t key_b = 64 + lane < n ? sorted[64 + lane] : 0u;
-        uint32_t xy_b = 64 + lane < n ? sorted_xy[64 + lane] : 0u;
-        for (int k = 0; k < nchunks; ++k) {
-            const int r = k * 64 + lane;
-            const int r2 = r + 128;
-            const uint32_t key_c = r2 < n ? sorted[r2] : 0u;
-            const uint32_t xy_c = r2 < n ? sorted_xy[r2] : 0u;
-            const bool valid = r < n;
-            const uint32_t key = key_a;
-            const int x = static_cast<int>(xy_a & 0xffffu);
-            const int y = static_cast<int>(xy_a >> 16);
+        // A candidate closer than `window` to a kept point of the grid is dropped at once; the others wait
+        // (in rank order) in `stage` until 64 of them are together or nearly so, and are then resolved
+        // among themselves and inserted in one pass.  A candidate is kept iff no earlier kept point is
+        // near: the earlier kept points are either in the grid when the candidate is tested against it,
+        // or wait with it in the same batch, or were inserted by a flush in between -- which is why a
+        // flush forced by a full batch is followed by a second grid test of the chunk at hand.
+        int pend = 0;  // wave-uniform
+        constexpr int FLUSH_AT = 44;
+        auto near_kept = [&](uint32_t xy) {  // the grid test: true when a kept point is closer than w
+            const int x = static_cast<int>(xy & 0xffffu);
+            const int y = static_cast<int>(xy >> 16);
             const int cx = static_cast<int>(__umulhi(static_cast<uint32_t>(x), magic));  // x / w (exact below 65536)
             const int cy = static_cast<int>(__umulhi(static_cast<uint32_t>(y), magic));
             const int xr = x - cx * w;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            u2 hit = {0, 0};
+            u2 nearest = {0xffff, 0xffff};  // smallest squared distance seen, per entry slot
 #pragma unroll
             for (int j = -1; j <= 1; ++j) {
                 const short yj = static_cast<short>(yr - j * w);
@@ -531,18 +539,34 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                     const short xi = static_cast<short>(xr - i * w);
                     const s2 XR = {xi, xi};
                     const s2 OX = __builtin_bit_cast(s2, word & 0x00ff00ffu);
-                    const s2 OY = __builtin_bit_cast(s2, (word >> 8) & 0x00ff00ffu);
+                    const s2 OY = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, word, 0x0c030c01u));
                     const s2 DX = XR - OX;
                     const s2 DY = YR - OY;
                     const u2 D2 = __builtin_bit_cast(u2, DX * DX + DY * DY);  // <= 2 * 175^2 < 65536
-                    hit |= __builtin_elementwise_sub_sat(W2, D2);             // non-zero <=> d^2 < w^2
+                    nearest = __builtin_elementwise_min(nearest, D2);
                 }
             }
-            bool alive = valid && __builtin_bit_cast(uint32_t, hit) == 0u;
-            // Survivors among themselves.  Two survivors can only interact when they sit in
-            // neighbouring cells, which is rare for 64 candidates on ~10^4 cells: every survivor
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(W2, nearest)) != 0u;  // d^2 < w^2
+        };
+        auto flush = [&]() {
+            if (pend == 0) {
+                return;
+            }
+            wave_mem_fence();
+            const bool have = lane < pend;
+            const uint2 e = stage[lane];
+            const uint32_t key = e.y;
+            const int x = static_cast<int>(e.x & 0xffffu);
+            const int y = static_cast<int>(e.x >> 16);
+            const int cx = static_cast<int>(__umulhi(static_cast<uint32_t>(x), magic));
+            const int cy = static_cast<int>(__umulhi(static_cast<uint32_t>(y), magic));
+            const int xr = x - cx * w;
+            const int yr = y - cy * w;
+            bool alive = have;
+            // The batch among itself.  Two of its members can only interact when they sit in
+            // neighbouring cells, which is rare for 64 candidates on ~10^4 cells: every member
             // counts itself into a table slot hashed from its cell and sums the slots of its
-            // 3 x 3 cells; a sum of 1 means no other survivor is near (a hash collision only makes
+            // 3 x 3 cells; a sum of 1 means no other member is near (a hash collision only makes
             // a lonely one look crowded), so it is kept without entering the rank-order loop.
             const int cidx = (cy + 1) * gx2 + (cx + 1);
             if (alive) {
@@ -581,7 +605,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             const bool mine = (kept >> lane) & 1ull;
             if (mine) {
                 const uint32_t entry = static_cast<uint32_t>((yr << 8) | xr);
-                uint32_t* c = nms_grid + (cy + 1) * gx2 + (cx + 1);
+                uint32_t* c = nms_grid + cidx;
                 const uint32_t old = atomicCAS(c, CELL_EMPTY, (CELL_EMPTY & 0xffff0000u) | entry);
                 if (old != CELL_EMPTY) {
                     // first slot taken (now or in an earlier step): the second one must be free
@@ -608,15 +632,47 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                     atomicOr(&kept_bits[idx >> 5], 1u << (idx & 31u));
                 }
             }
-            if (valid && !use_bits) {
+            if (have && !use_bits) {
                 state[key & INDEX_MASK] = mine ? NMS_KEPT : NMS_SUPPRESSED;
             }
             count += __popcll(kept);
+            pend = 0;
+            wave_mem_fence();
+        };
+        // software pipeline: the loads of chunk k+2 are in flight while chunk k is processed
+        uint32_t key_a = lane < n ? sorted[lane] : 0u;
+        uint32_t xy_a = lane < n ? sorted_xy[lane] : 0u;
+        uint32_t key_b = 64 + lane < n ? sorted[64 + lane] : 0u;
+        uint32_t xy_b = 64 + lane < n ? sorted_xy[64 + lane] : 0u;
+        for (int k = 0; k < nchunks; ++k) {
+            const int r = k * 64 + lane;
+            const int r2 = r + 128;
+            const uint32_t key_c = r2 < n ? sorted[r2] : 0u;
+            const uint32_t xy_c = r2 < n ? sorted_xy[r2] : 0u;
+            const bool valid = r < n;
+            if (pend > FLUSH_AT) {
+                flush();
+            }
+            bool alive = valid && !near_kept(xy_a);
+            unsigned long long am = __ballot(alive);
+            if (pend + __popcll(am) > 64) {
+                flush();  // new kept points: test the chunk again
+                alive = alive && !near_kept(xy_a);
+                am = __ballot(alive);
+            }
+            if (alive) {
+                stage[pend + rank_below_mask(am)] = make_uint2(xy_a, key_a);
+            }
+            pend += __popcll(am);
+            if (valid && !alive && !use_bits) {
+                state[key_a & INDEX_MASK] = NMS_SUPPRESSED;
+            }
             key_a = key_b;
             key_b = key_c;
             xy_a = xy_b;
             xy_b = xy_c;
         }
+        flush();
         if (__ballot(grid_overflow) != 0 && lane == 0) {
             atomicOr(&v.status[f], STATUS_KP_OVERFLOW);  // cannot happen for window <= GREEDY_MAX_WINDOW; fail loudly
         }
