@@ -451,6 +451,8 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 constexpr int GREEDY_MAX_WINDOW = 24;
 constexpr int GREEDY_LDS_BUDGET = 150 * 1024;
 constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
+constexpr int LOOKAHEAD = 3;               // filter waves of the greedy kernel (its workgroup has 1 + LOOKAHEAD waves)
+constexpr int GREEDY_STATIC_LDS = 4 * 1024;  // stage + look + counters, rounded up
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
@@ -463,6 +465,8 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     __shared__ uint32_t carry;
     __shared__ int kept_total;
     __shared__ uint2 stage[64];  // {y << 16 | x, key} of the candidates that passed the grid test, in rank order
+    __shared__ uint2 look[2][LOOKAHEAD][64];  // chunks filtered ahead of wave 0 (double-buffered by group)
+    __shared__ unsigned long long look_mask[2][LOOKAHEAD];
     const int f = blockIdx.x;
     const int n = v.n_cand[f];
     if (n == 0) {
@@ -494,19 +498,20 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         }
     }
     __syncthreads();
-    if (wave == 0) {
+    {
         const int w = window;
         const int w2 = w * w;
         const u2 W2 = {static_cast<unsigned short>(w2), static_cast<unsigned short>(w2)};
         int count = 0;
         bool grid_overflow = false;
         const int nchunks = (n + 63) / 64;
-        // A candidate closer than `window` to a kept point of the grid is dropped at once; the others wait
-        // (in rank order) in `stage` until 64 of them are together or nearly so, and are then resolved
-        // among themselves and inserted in one pass.  A candidate is kept iff no earlier kept point is
-        // near: the earlier kept points are either in the grid when the candidate is tested against it,
-        // or wait with it in the same batch, or were inserted by a flush in between -- which is why a
-        // flush forced by a full batch is followed by a second grid test of the chunk at hand.
+        // Waves 1..3 run ahead of wave 0, one chunk of 64 candidates (in std::sort order) each: a candidate
+        // closer than `window` to a kept point already in the grid can be dropped at once -- kept points
+        // never leave the grid, so a test against an older state of it is a valid filter.  Wave 0 collects
+        // what passes, in rank order, in `stage`; when 64 are together or nearly so it tests them against
+        // the grid as it is now (which holds every kept point of the earlier batches), resolves them among
+        // themselves in rank order and inserts the kept ones.  A candidate is kept iff no earlier kept point
+        // is near, and every earlier kept point is either in the grid at that moment or in the same batch.
         int pend = 0;  // wave-uniform
         constexpr int FLUSH_AT = 44;
         auto near_kept = [&](uint32_t xy) {  // the grid test: true when a kept point is closer than w
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             }
             wave_mem_fence();
             const bool have = lane < pend;
-            const uint2 e = stage[lane];
+            const uint2 e = have ? stage[lane] : make_uint2(0u, 0u);  // idle lanes: a valid cell
             const uint32_t key = e.y;
             const int x = static_cast<int>(e.x & 0xffffu);
             const int y = static_cast<int>(e.x >> 16);
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             const int cy = static_cast<int>(__umulhi(static_cast<uint32_t>(y), magic));
             const int xr = x - cx * w;
             const int yr = y - cy * w;
-            bool alive = have;
+            bool alive = have && !near_kept(e.x);  // the grid has grown since the filter ran
             // The batch among itself.  Two of its members can only interact when they sit in
             // neighbouring cells, which is rare for 64 candidates on ~10^4 cells: every member
             // counts itself into a table slot hashed from its cell and sums the slots of its
@@ -639,46 +644,70 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             pend = 0;
             wave_mem_fence();
         };
-        // software pipeline: the loads of chunk k+2 are in flight while chunk k is processed
-        uint32_t key_a = lane < n ? sorted[lane] : 0u;
-        uint32_t xy_a = lane < n ? sorted_xy[lane] : 0u;
-        uint32_t key_b = 64 + lane < n ? sorted[64 + lane] : 0u;
-        uint32_t xy_b = 64 + lane < n ? sorted_xy[64 + lane] : 0u;
-        for (int k = 0; k < nchunks; ++k) {
-            const int r = k * 64 + lane;
-            const int r2 = r + 128;
-            const uint32_t key_c = r2 < n ? sorted[r2] : 0u;
-            const uint32_t xy_c = r2 < n ? sorted_xy[r2] : 0u;
-            const bool valid = r < n;
-            if (pend > FLUSH_AT) {
-                flush();
+        // filter waves: chunk (wave - 1) + LOOKAHEAD * j at step j, loads two steps ahead
+        const int hc0 = wave - 1;
+        auto chunk_load = [&](const uint32_t* src, int chunk) {
+            const int r = chunk * 64 + lane;
+            return wave != 0 && chunk < nchunks && r < n ? src[r] : 0u;
+        };
+        uint32_t key_a = chunk_load(sorted, hc0);
+        uint32_t xy_a = chunk_load(sorted_xy, hc0);
+        uint32_t key_b = chunk_load(sorted, hc0 + LOOKAHEAD);
+        uint32_t xy_b = chunk_load(sorted_xy, hc0 + LOOKAHEAD);
+        const int ngroups = (nchunks + LOOKAHEAD - 1) / LOOKAHEAD;
+        for (int g = -1; g < ngroups; ++g) {
+            if (wave != 0) {
+                // group g + 1 into look[(g + 1) & 1]
+                const int c = (g + 1) * LOOKAHEAD + hc0;
+                const uint32_t key_c = chunk_load(sorted, c + 2 * LOOKAHEAD);
+                const uint32_t xy_c = chunk_load(sorted_xy, c + 2 * LOOKAHEAD);
+                if (c < nchunks) {
+                    const bool valid = c * 64 + lane < n;
+                    const bool alive = valid && !near_kept(xy_a);
+                    const unsigned long long am = __ballot(alive);
+                    look[(g + 1) & 1][hc0][lane] = make_uint2(xy_a, key_a);
+                    if (lane == 0) {
+                        look_mask[(g + 1) & 1][hc0] = am;
+                    }
+                    if (valid && !alive && !use_bits) {
+                        state[key_a & INDEX_MASK] = NMS_SUPPRESSED;
+                    }
+                }
+                key_a = key_b;
+                key_b = key_c;
+                xy_a = xy_b;
+                xy_b = xy_c;
+            } else if (g >= 0) {
+                for (int h = 0; h < LOOKAHEAD; ++h) {
+                    if (g * LOOKAHEAD + h >= nchunks) {
+                        break;
+                    }
+                    const unsigned long long am = look_mask[g & 1][h];
+                    const int na = __popcll(am);
+                    if (na == 0) {
+                        continue;
+                    }
+                    if (pend > FLUSH_AT || pend + na > 64) {
+                        flush();
+                    }
+                    if ((am >> lane) & 1ull) {
+                        stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
+                    }
+                    pend += na;
+                }
             }
-            bool alive = valid && !near_kept(xy_a);
-            unsigned long long am = __ballot(alive);
-            if (pend + __popcll(am) > 64) {
-                flush();  // new kept points: test the chunk again
-                alive = alive && !near_kept(xy_a);
-                am = __ballot(alive);
-            }
-            if (alive) {
-                stage[pend + rank_below_mask(am)] = make_uint2(xy_a, key_a);
-            }
-            pend += __popcll(am);
-            if (valid && !alive && !use_bits) {
-                state[key_a & INDEX_MASK] = NMS_SUPPRESSED;
-            }
-            key_a = key_b;
-            key_b = key_c;
-            xy_a = xy_b;
-            xy_b = xy_c;
+            __threadfence_block();
+            __syncthreads();
         }
-        flush();
-        if (__ballot(grid_overflow) != 0 && lane == 0) {
-            atomicOr(&v.status[f], STATUS_KP_OVERFLOW);  // cannot happen for window <= GREEDY_MAX_WINDOW; fail loudly
-        }
-        if (lane == 0) {
-            kept_total = count;
-            carry = 0;
+        if (wave == 0) {
+            flush();
+            if (__ballot(grid_overflow) != 0 && lane == 0) {
+                atomicOr(&v.status[f], STATUS_KP_OVERFLOW);  // cannot happen for window <= GREEDY_MAX_WINDOW; fail loudly
+            }
+            if (lane == 0) {
+                kept_total = count;
+                carry = 0;
+            }
         }
     }
     __threadfence_block();
@@ -806,7 +835,8 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
             // the hashed survivor table takes what is left of the LDS budget (a power of two of dwords)
             // (a power of two of dwords), but at most half of a CU's 160 KB when that is within reach, so that
             // two frames share a CU in batches of more than 256 frames
-            const size_t budget = bytes + 4096 * 4 <= 80 * 1024 ? 80 * 1024 : static_cast<size_t>(GREEDY_LDS_BUDGET);
+            const size_t budget =
+                (bytes + 4096 * 4 <= 80 * 1024 ? 80 * 1024 : static_cast<size_t>(GREEDY_LDS_BUDGET)) - GREEDY_STATIC_LDS;
             // the kept-candidate bitmap (one bit per candidate, up to 65536 of them) sits behind the table; its
             // word prefix is built in the table, which therefore has at least as many entries as the bitmap words
             int bitmap_words = (std::min(v.maxM, 65536) + 31) / 32;
