@@ -451,17 +451,25 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 constexpr int GREEDY_MAX_WINDOW = 24;
 constexpr int GREEDY_LDS_BUDGET = 150 * 1024;
 constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
-constexpr int LOOKAHEAD = 3;               // filter waves of the greedy kernel (its workgroup has 1 + LOOKAHEAD waves)
-constexpr int GREEDY_STATIC_LDS = 4 * 1024;  // stage + look + counters, rounded up
+#ifndef SLAMX_NMS_LOOKAHEAD
+#define SLAMX_NMS_LOOKAHEAD 3
+#endif
+#ifndef SLAMX_NMS_FLUSH_AT
+#define SLAMX_NMS_FLUSH_AT 44
+#endif
+constexpr int LOOKAHEAD = SLAMX_NMS_LOOKAHEAD;  // filter waves of the greedy kernel (its workgroup has 1 + LOOKAHEAD waves)
+constexpr int GREEDY_WAVES = 1 + LOOKAHEAD;
+constexpr int GREEDY_THREADS = 64 * GREEDY_WAVES;
+constexpr int GREEDY_STATIC_LDS = 1024 + 2 * LOOKAHEAD * 64 * 8;  // stage + look + counters, rounded up
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ uint32_t nms_grid[];
 
-__global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic, int tab_mask,
+__global__ __launch_bounds__(GREEDY_THREADS) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic, int tab_mask,
                                                          int bitmap_words) {
-    __shared__ uint32_t wave_sums[2][4];
+    __shared__ uint32_t wave_sums[2][GREEDY_WAVES];
     __shared__ uint32_t carry;
     __shared__ int kept_total;
     __shared__ uint2 stage[64];  // {y << 16 | x, key} of the candidates that passed the grid test, in rank order
@@ -479,12 +487,12 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     uint8_t* state = v.state + static_cast<size_t>(f) * v.maxM;
     uint32_t* slot_of = v.rank_of + static_cast<size_t>(f) * v.maxM;  // rank_of is not needed on this path
     slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
-    for (int i = threadIdx.x; i < gx2 * gy2; i += 256) {
+    for (int i = threadIdx.x; i < gx2 * gy2; i += GREEDY_THREADS) {
         nms_grid[i] = CELL_EMPTY;
     }
     // occupancy counters of the survivors of the current step, hashed by cell index (see below)
     uint32_t* tab = nms_grid + gx2 * gy2;
-    for (int i = threadIdx.x; i <= tab_mask; i += 256) {
+    for (int i = threadIdx.x; i <= tab_mask; i += GREEDY_THREADS) {
         tab[i] = 0;
     }
     // kept candidates as a bitmap over the raster index (for the visiting list at the end); candidate
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
     const int n_words = (n + 31) >> 5;
     const bool use_bits = n_words <= bitmap_words;  // block-uniform
     if (use_bits) {
-        for (int i = threadIdx.x; i < n_words; i += 256) {
+        for (int i = threadIdx.x; i < n_words; i += GREEDY_THREADS) {
             kept_bits[i] = 0;
         }
     }
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         // themselves in rank order and inserts the kept ones.  A candidate is kept iff no earlier kept point
         // is near, and every earlier kept point is either in the grid at that moment or in the same batch.
         int pend = 0;  // wave-uniform
-        constexpr int FLUSH_AT = 44;
+        constexpr int FLUSH_AT = SLAMX_NMS_FLUSH_AT;
         auto near_kept = [&](uint32_t xy) {  // the grid test: true when a kept point is closer than w
             const int x = static_cast<int>(xy & 0xffffu);
             const int y = static_cast<int>(xy >> 16);
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         constexpr int PER = 8;
         uint32_t run_total = 0;  // identical in all threads
         int buf = 0;
-        for (int base = 0; base < n_words; base += 256 * PER) {
+        for (int base = 0; base < n_words; base += GREEDY_THREADS * PER) {
             const int i0 = base + static_cast<int>(threadIdx.x) * PER;
             uint32_t c[PER];
             uint32_t t = 0;
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
             __syncthreads();
             uint32_t before = 0, total = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GREEDY_WAVES; ++q) {
                 const uint32_t ws = wave_sums[buf][q];
                 before += q < wave ? ws : 0u;
                 total += ws;
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         }
         __syncthreads();
         uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
-        for (int pos = threadIdx.x; pos < total_kept; pos += 256) {
+        for (int pos = threadIdx.x; pos < total_kept; pos += GREEDY_THREADS) {
             const uint32_t idx = slot_of[pos];
             const uint32_t w = idx >> 5;
             const uint32_t below = kept_bits[w] & ((1u << (idx & 31u)) - 1u);
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
         }
     } else if (total_kept <= v.maxK) {
         uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
-        for (int base = 0; base < n; base += 256) {
+        for (int base = 0; base < n; base += GREEDY_THREADS) {
             const int i = base + threadIdx.x;
             const bool keep = i < n && state[i] == NMS_KEPT;
             const unsigned long long bm = __ballot(keep);
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(BatchView v, int window
                 visit[wbase + static_cast<uint32_t>(__popcll(bm & low_mask(lane)))] = slot_of[i];
             }
             __syncthreads();
-            if (threadIdx.x == 255) {
+            if (threadIdx.x == GREEDY_THREADS - 1) {
                 carry = wbase + c;
             }
             __syncthreads();
@@ -852,7 +860,7 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
                 tab_entries *= 2;
             }
             const size_t total = bytes + static_cast<size_t>(tab_entries + bitmap_words) * 4;
-            hipLaunchKernelGGL(nms_greedy_kernel, dim3(nframes), dim3(256), total, stream, v, p.window, gx2, gy2, magic,
+            hipLaunchKernelGGL(nms_greedy_kernel, dim3(nframes), dim3(GREEDY_THREADS), total, stream, v, p.window, gx2, gy2, magic,
                                tab_entries - 1, bitmap_words);
             if (ev_mid != nullptr) {
                 (void)hipEventRecord(ev_mid, stream);
