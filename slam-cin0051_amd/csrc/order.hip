@@ -534,7 +534,7 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     return cut;
 }
 
-__device__ int SORT_BLOCK_MIN = 2048;  // segments at least this long are partitioned by the whole workgroup
+__device__ int SORT_BLOCK_MIN = 3072;  // segments at least this long are partitioned by the whole workgroup
 
 // Work queue of the wave-level segments of one introsort_levels call (LDS): a bounded ring with a
 // sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
