@@ -264,11 +264,11 @@ def main():
         # Bytes for the HBM-bound kernels, int32 ops for the Hamming kernel.
         live_words = 2  # 46 surviving BRIEF pairs -> 2 non-zero 32-bit words per descriptor
         hbm_bytes = {
-            "fast": px + px / 8.0,                 # frame read, corner bitmap written
-            "scan": 12.0 * px / 64,                # bitmap words read, prefix written
-            "expand": 8.0 * px / 64 + 17 * M + 8 * M,
+            "fast": px + px / 8.0 + px / 64.0 + 4.0 * M,  # frame read; bitmap, per-word counts, per-tile corner lists written
+            "scan": 5.0 * px / 64,                 # per-word count bytes read, prefix written
+            "expand": 24.0 * M,                    # list entry read, bitmap word + prefix gathered, (x,y) + key written
             "sort": 16.0 * M,                      # keys read, sorted keys + sorted (x,y) written, (x,y) gathered
-            "nms_build": 9.0 * M + 28.0 * N,       # greedy NMS: sorted key + (x,y) read, state byte, keypoint + slot written
+            "nms_build": 8.0 * M + 32.0 * N,       # greedy NMS: sorted key + (x,y) read; keypoint, slot and visiting list written
             "nms_rounds": 4.0 * M,                 # (only the generic NMS path has rounds: ~0 on the greedy path)
             "blur": 2.0 * px,                      # frame read, blurred frame written
             # orientation + BRIEF are one kernel (describe_fused_kernel, reported under "moments"): the
