@@ -134,6 +134,40 @@ def pmc_traffic_bytes(kernel, batch):
     return None
 
 
+def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=6):
+    """The same step with every frame coming from the host: the batch is copied from page-locked host
+    memory (slamx_batch_upload_async) before it is processed.  Two contexts (two streams, two batches)
+    alternate, so the copy of one batch overlaps the kernels of the other.  Reported next to `value`,
+    never as it (the timed region of `value` starts with the frames resident in HBM)."""
+    pin = mod.pinned_array(frames.shape)
+    pin[...] = frames
+    ctx2 = mod.Context(local_rank)
+    det2 = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), ctx2)
+    matcher2 = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx2)
+    batch2 = mod.Batch(det2, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
+    lanes = [main, (ctx2, batch2, matcher2)]
+
+    def step(i):
+        _, b, m = lanes[i % 2]
+        b.upload_async(pin)
+        b.detect_and_compute(B)
+        b.match_consecutive(m, B, use_keypoints=use_keypoints, first_train_frame=B - 1)
+
+    for i in range(2):
+        step(i)
+    for c, _, _ in lanes:
+        c.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    for c, _, _ in lanes:
+        c.synchronize()
+    dt = time.perf_counter() - t0
+    gb = steps * frames.nbytes / 1e9
+    return {"value": steps * B / dt, "unit": "frames/s", "steps": steps, "host_to_hbm_GBps": gb / dt,
+            "note": "every batch uploaded from pinned host memory before it is processed; two contexts alternate"}
+
+
 def cpu_baseline(mod, wl, frames, budget_s=15.0):
     """The restated reference CPU path (oracle/, single thread) on a bounded sample of the SAME
     frames: detectAndCompute + match(frame k, frame k-1) with keypoints."""
@@ -172,6 +206,7 @@ def main():
     ap.add_argument("--workload", default="1080p_2k", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-upload-inclusive leg (N == 1 only)")
     ap.add_argument("--no-keypoints", action="store_true", help="diagnostic: match without the jump-radius penalty")
     args = ap.parse_args()
 
@@ -332,6 +367,10 @@ def main():
                              "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
             "device": ctx.device_name,
         }
+        if n_gpus == 1 and not args.no_pcie:
+            batch.set_profiling(0, 1)
+            out["pcie_inclusive"] = pcie_inclusive(mod, wl, B, frames, (ctx, batch, matcher), local_rank,
+                                                   not args.no_keypoints)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mod, wl, frames)
         print(json.dumps(out), flush=True)

@@ -175,6 +175,16 @@ uint8_t* slamx_batch_frames(slamx_batch* b, size_t* pitch, size_t* frame_stride)
  * the work already queued on the batch; the host buffer may be reused as soon as the call returns. */
 int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
                        ptrdiff_t frame_stride);
+/* Streaming ingest (the reference hands every frame over as a host cv::Mat, preprocessor.cpp:24-82):
+ * page-locked host memory, and the same copy as slamx_batch_upload that does NOT wait -- it is queued on
+ * the context stream, ordered before the compute calls that follow, and reads `host` at PCIe speed while
+ * other contexts compute.  `host` must come from slamx_host_alloc and stay untouched until
+ * slamx_ctx_synchronize (or any download) on this context has returned; anything else is refused
+ * with SLAMX_ERR_INVALID_ARGUMENT, because the runtime stages pageable memory lazily (see above). */
+int slamx_host_alloc(size_t bytes, void** out);
+void slamx_host_free(void* p);
+int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                             ptrdiff_t frame_stride);
 /* detectAndCompute on frames 0..nframes-1 (async on the context stream). */
 int slamx_batch_detect_and_compute(slamx_batch* b, int nframes);
 /* match(desc[k], desc[k-1], kps[k], kps[k-1]) for k = 1..nframes-1; frame 0 is matched against

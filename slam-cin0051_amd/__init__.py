@@ -93,6 +93,7 @@ EXPORTS = [
     "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
+    "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
@@ -148,6 +149,10 @@ def load_library():
     lib.slamx_batch_destroy.argtypes = [vp]
     lib.slamx_batch_frames.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.slamx_batch_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
+    lib.slamx_batch_upload_async.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
+    lib.slamx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.slamx_host_free.argtypes = [vp]
+    lib.slamx_host_free.restype = None
     lib.slamx_batch_detect_and_compute.argtypes = [vp, C.c_int]
     lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     lib.slamx_batch_counts.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -203,6 +208,31 @@ def synth_frame(seed, k, rows, cols, n_rect, rect_min=16, rect_max=64):
     out = np.empty((rows, cols), np.uint8)
     _check(load_library().slamx_synth_frame(seed, k, rows, cols, n_rect, rect_min, rect_max, _ptr(out)))
     return out
+
+
+class _PinnedOwner:
+    """Keeps a slamx_host_alloc block alive for as long as a numpy view of it exists."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.slamx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (slamx_host_alloc): the source of Batch.upload_async."""
+    lib = load_library()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _check(lib.slamx_host_alloc(n, C.byref(p)))
+    owner = _PinnedOwner(lib, p)
+    buf = (C.c_uint8 * n).from_address(p.value)
+    buf._owner = owner  # the ctypes block (and through numpy's base chain every view) holds the owner
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def load_detector_config(path):
@@ -579,6 +609,14 @@ class Batch:
         if f.ndim == 2:
             f = f[None]
         _check(self.lib.slamx_batch_upload(self.h, first, f.shape[0], _ptr(f), f.strides[1], f.strides[0]))
+
+    def upload_async(self, frames, first=0):
+        """Queue the copy and return; `frames` must be (a view of) a pinned_array() and stay untouched
+        until the context has been synchronised."""
+        f = frames if frames.ndim == 3 else frames[None]
+        if f.dtype != np.uint8 or f.strides[2] != 1:
+            raise ValueError("upload_async: uint8 frames with unit pixel stride")
+        _check(self.lib.slamx_batch_upload_async(self.h, first, f.shape[0], f.ctypes.data, f.strides[1], f.strides[0]))
 
     def detect_and_compute(self, nframes):
         _check(self.lib.slamx_batch_detect_and_compute(self.h, nframes))

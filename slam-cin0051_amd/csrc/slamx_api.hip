@@ -746,6 +746,50 @@ int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, pt
     return SLAMX_OK;
 }
 
+int slamx_host_alloc(size_t bytes, void** out) {
+    if (out == nullptr || bytes == 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "host_alloc: out is null or size is 0");
+    }
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SLAMX_OK;
+}
+
+void slamx_host_free(void* p) {
+    if (p != nullptr) {
+        (void)hipHostFree(p);
+    }
+}
+
+int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                             ptrdiff_t frame_stride) {
+    if (first < 0 || n < 0 || first + n > b->shape.max_frames || host == nullptr || stride < b->v.cols) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload range/stride invalid");
+    }
+    if (n == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload_async needs page-locked host memory (slamx_host_alloc)");
+    }
+    hipStream_t s = b->det->ctx->stream;
+    uint8_t* dst = b->frames + static_cast<size_t>(first) * b->v.frame_stride;
+    const bool dense = stride == b->v.pitch && frame_stride == static_cast<ptrdiff_t>(b->v.frame_stride);
+    if (dense) {  // rows and frames back to back on both sides: one copy
+        HIP_TRY(hipMemcpyAsync(dst, host, static_cast<size_t>(n) * b->v.frame_stride, hipMemcpyHostToDevice, s));
+        return SLAMX_OK;
+    }
+    for (int f = 0; f < n; ++f) {
+        HIP_TRY(hipMemcpy2DAsync(dst + static_cast<size_t>(f) * b->v.frame_stride, static_cast<size_t>(b->v.pitch),
+                                 host + static_cast<ptrdiff_t>(f) * frame_stride, static_cast<size_t>(stride),
+                                 static_cast<size_t>(b->v.cols), static_cast<size_t>(b->v.rows), hipMemcpyHostToDevice, s));
+    }
+    return SLAMX_OK;
+}
+
 int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
     if (nframes < 0 || nframes > b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");

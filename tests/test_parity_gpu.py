@@ -153,6 +153,19 @@ def test_detect_windows_synthetic(slamx, oracle, window):
         assert_records_equal(d.detect(img), oracle.detect(img, Pp), "detect window=%d %dx%d" % (window, rows, cols))
 
 
+@pytest.mark.parametrize("window", [2, 3, 5, 12, 24])
+@pytest.mark.parametrize("arc,t", [(12, 30), (9, 25)])
+def test_detect_dense_candidates(slamx, oracle, window, arc, t):
+    """Uniform noise: thousands of candidates, crowded everywhere and heavily tied -- the filter waves of
+    the greedy NMS run on a grid that changes under them, and early batches fill on every chunk."""
+    rng = np.random.default_rng(window * 1000 + arc * 10 + t)
+    img = rng.integers(0, 256, (150, 420), dtype=np.uint8)
+    d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=arc, window=window))
+    Pp = oracle.det_params(d.cfg)
+    assert len(oracle.fast_candidates(img, Pp)) > 1500
+    assert_records_equal(d.detect(img), oracle.detect(img, Pp), "dense detect window=%d arc=%d t=%d" % (window, arc, t))
+
+
 def test_detect_without_nms(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, nms=0))
     img = synth(slamx, 1, 300, 400, 1500, rmin=3, rmax=20)
@@ -427,6 +440,32 @@ def test_batch_upload_host_buffer_reusable_on_return(slamx):
         tmp[:] = 0
         for k in range(2):
             assert np.array_equal(b.download_image(k), frames[k])
+
+
+def test_batch_upload_async_from_pinned_memory(slamx, oracle):
+    """Streaming ingest: the copy is queued, not waited for; pageable memory is refused."""
+    det = slamx.FeatureDetector(cfg_of(slamx))
+    Pp = oracle.det_params(det.cfg)
+    frames = np.stack([synth(slamx, k, 120, 200, 300, rmin=3, rmax=16) for k in range(3)])
+    pin = slamx.pinned_array(frames.shape)
+    pin[...] = frames
+    batch = slamx.Batch(det, 120, 200, 3, 8192, 4096)
+    batch.upload_async(pin)
+    batch.detect_and_compute(3)
+    for k in range(3):
+        kps, desc = batch.download(k)
+        rk, rd = oracle.detect_and_compute(frames[k], Pp)
+        assert_records_equal(kps, rk, "async upload frame %d" % k)
+        assert np.array_equal(desc, rd)
+    # rows with padding (a cropped view of a wider pinned image): the strided copy path
+    wide = slamx.pinned_array((3, 120, 300))
+    wide[:, :, :200] = frames
+    batch.upload_async(wide[:, :, :200])
+    batch.detect_and_compute(3)
+    kps, _ = batch.download(1)
+    assert_records_equal(kps, oracle.detect_and_compute(frames[1], Pp)[0], "async strided upload")
+    with pytest.raises(ValueError):
+        batch.upload_async(frames)  # pageable
 
 
 def test_batch_capacity_overflow_is_loud(slamx):
