@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     if (threadIdx.x == 0) {
         v.tile_count[tile_slot] = static_cast<uint32_t>(nc);
     }
-    if (nc <= CORNER_LIST_CAP && static_cast<int>(threadIdx.x) < nc) {
-        v.tile_list[tile_slot * CORNER_LIST_CAP + threadIdx.x] = corners[threadIdx.x];
+    if (nc <= CORNER_LIST_CAP) {
+        for (int i = threadIdx.x; i < nc; i += 256) {
+            v.tile_list[tile_slot * CORNER_LIST_CAP + i] = corners[i];
+        }
     }
 }
 

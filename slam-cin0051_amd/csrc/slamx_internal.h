@@ -32,7 +32,7 @@ constexpr int STATUS_SEG_OVERFLOW = 4;
 // FAST tile geometry, shared by the detector (fast.hip) and the buffers sized for it (slamx_api.hip)
 constexpr int FAST_TILE_W = 256;
 constexpr int FAST_TILE_H = 32;
-constexpr int CORNER_LIST_CAP = 256;
+constexpr int CORNER_LIST_CAP = 1024;
 
 // Device view of a frame batch in HBM.  All per-frame arrays are [frame][capacity].
 struct BatchView {
