@@ -273,6 +273,67 @@ struct TilePrefetch {
     }
 };
 
+// The same tile moved in 12-byte pieces (a 48-byte tile row = 4 pieces): the texture-address unit spends
+// ~16 cycles on a wave's load instruction whatever its width, and it is the busiest unit of the fused
+// describe kernel -- 3 instructions per tile instead of 9.  Piece e = lane + 64 k covers tile dwords
+// 3 e .. 3 e + 2 (row e / 4), so the LDS image is the same row-major tile.
+template <int ROWS, int HALF>
+struct TilePrefetch12 {
+    static constexpr int DW = 12;
+    static constexpr int PIECES = ROWS * 4;
+    static constexpr int PER_LANE = (PIECES + 63) / 64;
+    uint32_t reg[PER_LANE][3];
+    __device__ __forceinline__ void init_offsets(int pitch, int lane, int* off) const {
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            const int ee = e < PIECES ? e : 0;
+            off[k] = (ee >> 2) * pitch + (ee & 3) * 12;
+        }
+    }
+    // tile entirely inside the padded frame (the caller checks)
+    __device__ __forceinline__ void issue_inside(const uint8_t* img, int pitch, int x, int y, const int* off) {
+        const uint8_t* base = img + static_cast<size_t>(y - HALF) * pitch + ((x - HALF) & ~3);
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(base + off[k]);
+            reg[k][0] = p[0];
+            reg[k][1] = p[1];
+            reg[k][2] = p[2];
+        }
+    }
+    // any tile: dwords outside the padded frame read as 0
+    __device__ __forceinline__ void issue(const BatchView& v, const uint8_t* img, int x, int y, int lane) {
+        const int x0a = (x - HALF) & ~3;
+        const int y0 = y - HALF;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            const int yy = y0 + (e >> 2);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int xx = x0a + (e & 3) * 12 + j * 4;
+                uint32_t val = 0;
+                if (e < PIECES && yy >= 0 && yy < v.rows && xx >= 0 && xx + 4 <= v.pitch) {
+                    val = *reinterpret_cast<const uint32_t*>(img + static_cast<size_t>(yy) * v.pitch + xx);
+                }
+                reg[k][j] = val;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(uint32_t* tile, int lane) const {
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const int e = lane + 64 * k;
+            if (e < PIECES) {
+                tile[3 * e + 0] = reg[k][0];
+                tile[3 * e + 1] = reg[k][1];
+                tile[3 * e + 2] = reg[k][2];
+            }
+        }
+    }
+};
+
 // value of lane `src` (wave-uniform index) as a scalar: v_readlane_b32, so that everything derived
 // from it (tile base address, alignment, bounds tests) stays on the SALU
 __device__ __forceinline__ int lane_value(int v, int src) {
@@ -428,6 +489,27 @@ void moment_weight_table(int radius, uint32_t* out_xy) {
                 out_xy[2 * idx] = wu;
                 out_xy[2 * idx + 1] = wm;
             }
+        }
+    }
+    // the patch itself, 31 rows x 8 dwords starting AT column x - 15 (describe_fused_kernel shifts the
+    // data into place with v_alignbyte instead of choosing among four weight sets)
+    for (int k = 0; k < MOMENT_ALIGNED_SLOTS; ++k) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int e = lane + 64 * k;
+            uint32_t wu = 0, wm = 0;
+            if (e < MOM_ROWS * 8) {
+                const int vv = e / 8 - MOM_HALF;
+                for (int b = 0; b < 4; ++b) {
+                    const int uu = 4 * (e % 8) + b - MOM_HALF;
+                    if (uu <= MOM_HALF && uu * uu + vv * vv <= radius * radius) {
+                        wu |= static_cast<uint32_t>(uu + MOM_HALF) << (8 * b);
+                        wm |= 1u << (8 * b);
+                    }
+                }
+            }
+            const size_t idx = static_cast<size_t>(4 * 5 * 64) + static_cast<size_t>(k) * 64 + lane;
+            out_xy[2 * idx] = wu;
+            out_xy[2 * idx + 1] = wm;
         }
     }
 }
@@ -621,11 +703,15 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
 //   B  atan2f -> degrees -> cosf, sinf, one keypoint per lane (the serial glibc chain)
 //   C  per keypoint: the BRIEF samples from the tile that is still in LDS
 // One HBM read of the frame instead of two; results identical to the three-kernel path.
-constexpr int FUSED_PER_WAVE = 4;  // keypoints (= LDS tiles) a wave carries through the three phases
-
-__global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
-                                                             int nframes, int blocks_per_frame, int use_visit) {
-    __shared__ uint32_t tiles[4][FUSED_PER_WAVE][TILE_ROWS * TILE_DW];
+// FUSED_PER_WAVE keypoints (= LDS tiles) travel with a wave through the three phases; WPB waves per
+// workgroup; OCC = waves per SIMD the register allocation must leave room for.
+#ifndef FUSED_EARLY_TILES
+#define FUSED_EARLY_TILES 1
+#endif
+template <int FUSED_PER_WAVE, int WPB, int OCC>
+__global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
+                                                                      int nframes, int blocks_per_frame, int use_visit) {
+    __shared__ uint32_t tiles[WPB][FUSED_PER_WAVE][TILE_ROWS * TILE_DW];
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
         return;
@@ -639,23 +725,24 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, Detect
     const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
     const int words = v.width / 8;
     // per-lane constants: tile dword offsets, moments slots and weights, this lane's pattern pair
-    TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
-    int tile_off[TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF>::PER_LANE];
-    pf.init_offsets(v.pitch, lane, tile_off);
-    constexpr int SLOTS = 5;
-    int mom_idx[SLOTS], vrow[SLOTS];  // tile dword of moments slot k (before the 1- or 2-dword column shift)
-    uint2 wgt[4][SLOTS];
+    using Prefetch = TilePrefetch12<TILE_ROWS, TILE_HALF>;
+    static_assert(TILE_DW == Prefetch::DW, "tile rows are four 12-byte pieces");
+    Prefetch pf[FUSED_PER_WAVE];  // the tiles of the NEXT group travel in registers while this one is worked on
+    int tile_off[Prefetch::PER_LANE];
+    pf[0].init_offsets(v.pitch, lane, tile_off);
+    // orientation patch = 31 rows x 8 dwords that start AT column x - 15: slot k of a lane is patch dword
+    // e = lane + 64 k (row e / 8, dword e % 8), whose bytes straddle two tile dwords
+    constexpr int SLOTS = MOMENT_ALIGNED_SLOTS;
+    int mom_idx[SLOTS], vrow[SLOTS];
+    uint2 wal[SLOTS];
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int e = lane + 64 * k;
-        const int ee = e < MOM_ROWS * MOM_DW ? e : 0;
-        const int r = ee / MOM_DW;
-        mom_idx[k] = (r + (TILE_HALF - MOM_HALF)) * TILE_DW + (ee - r * MOM_DW);
+        const int ee = e < MOM_ROWS * 8 ? e : 0;  // surplus slots carry zero weights
+        const int r = ee / 8;
+        mom_idx[k] = (r + (TILE_HALF - MOM_HALF)) * TILE_DW + (ee - r * 8);
         vrow[k] = r - MOM_HALF;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            wgt[a][k] = P.moment_weights[(a * SLOTS + k) * 64 + lane];
-        }
+        wal[k] = P.moment_weights[4 * 5 * 64 + k * 64 + lane];
     }
     float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f;
     if (lane < P.pattern_len) {
@@ -665,14 +752,6 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, Detect
         q2y = static_cast<float>(pattern[4 * lane + 3]);
     }
     const unsigned long long all_pairs = low_mask_d(P.pattern_len);
-    auto fetch = [&](int x, int y) {  // wave-uniform choice: no per-element bounds checks when the tile is inside
-        const int xa = (x - TILE_HALF) & ~3;
-        if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
-            pf.issue_inside(img, v.pitch, x, y, tile_off);
-        } else {
-            pf.issue(v, img, x, y, lane);
-        }
-    };
     auto patch_inside = [&](int x, int y) {
         return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
     };
@@ -680,73 +759,76 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, Detect
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // the waves are independent: wave `gw` of the frame takes keypoint groups gw, gw + nwaves, ...
-    const int nwaves = blocks_per_frame * 4;
-    for (int g = bx * 4 + wave; g * FUSED_PER_WAVE < n; g += nwaves) {  // wave-uniform
-        // lane q < FUSED_PER_WAVE holds keypoint q of the group
-        int kslot = -1, kx = 0, ky = 0;
-        {
-            const int idx = g * FUSED_PER_WAVE + lane;
-            if (lane < FUSED_PER_WAVE && idx < n) {
-                kslot = use_visit ? static_cast<int>(visit[idx]) : idx;
-                kx = static_cast<int>(kps[kslot].x);
-                ky = static_cast<int>(kps[kslot].y);
+    // lane q < FUSED_PER_WAVE of a group's (slot, x, y) holds keypoint q; slot < 0 = no keypoint
+    auto load_group = [&](int g, int& kslot, int& kx, int& ky) {
+        kslot = -1;
+        kx = 0;
+        ky = 0;
+        const int idx = g * FUSED_PER_WAVE + lane;
+        if (lane < FUSED_PER_WAVE && idx < n) {
+            kslot = use_visit ? static_cast<int>(visit[idx]) : idx;
+            kx = static_cast<int>(kps[kslot].x);
+            ky = static_cast<int>(kps[kslot].y);
+        }
+    };
+    auto issue_group = [&](int kslot, int kx, int ky, int q_first, int q_end) {  // global loads of tiles, no waiting
+#pragma unroll
+        for (int q = 0; q < FUSED_PER_WAVE; ++q) {
+            if (q < q_first || q >= q_end) {
+                continue;
+            }
+            const int x = lane_value(kx, q), y = lane_value(ky, q);
+            if (lane_value(kslot, q) >= 0 && patch_inside(x, y)) {  // wave-uniform
+                const int xa = (x - TILE_HALF) & ~3;
+                if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
+                    pf[q].issue_inside(img, v.pitch, x, y, tile_off);  // no per-element bounds checks
+                } else {
+                    pf[q].issue(v, img, x, y, lane);
+                }
             }
         }
-        // ---- phase A: tiles into LDS, moments (lane q keeps m01, m10 of keypoint q)
+    };
+    // The waves are independent: wave `gw` of the frame takes keypoint groups gw, gw + nwaves, ...  The
+    // coordinates of the next group are loaded a round ahead and its tiles are requested -- all at once,
+    // into registers -- before the BRIEF phase of the current group (the phase with the fewest live
+    // registers), so that no chain of coordinate and tile loads is left on a wave's critical path.
+    constexpr int EARLY_TILES = FUSED_EARLY_TILES;  // tiles requested a phase early (register budget)
+    const int nwaves = blocks_per_frame * WPB;
+    int g = bx * WPB + wave;
+    int kslot, kx, ky;
+    load_group(g, kslot, kx, ky);
+    issue_group(kslot, kx, ky, 0, EARLY_TILES);
+    for (; g * FUSED_PER_WAVE < n; g += nwaves) {  // wave-uniform
+        issue_group(kslot, kx, ky, EARLY_TILES, FUSED_PER_WAVE);
+        int kslot1, kx1, ky1;
+        load_group(g + nwaves, kslot1, kx1, ky1);
+        // ---- phase A: tiles registers -> LDS, moments (lane q keeps m01, m10 of keypoint q)
         int my_m01 = 0, my_m10 = 0x7fffffff;
-        {
-            int xq = lane_value(kx, 0), yq = lane_value(ky, 0), sq = lane_value(kslot, 0);
-            if (sq >= 0 && patch_inside(xq, yq)) {
-                fetch(xq, yq);
-            }
 #pragma unroll
-            for (int q = 0; q < FUSED_PER_WAVE; ++q) {
-                const int x = xq, y = yq, slot = sq;
-                const bool inside = slot >= 0 && patch_inside(x, y);  // wave-uniform
-                if (inside) {
-                    pf.commit(tiles[wave][q], lane);
+        for (int q = 0; q < FUSED_PER_WAVE; ++q) {
+            const int x = lane_value(kx, q), y = lane_value(ky, q);
+            if (lane_value(kslot, q) >= 0 && patch_inside(x, y)) {  // wave-uniform
+                pf[q].commit(tiles[wave][q], lane);
+                wave_fence();
+                const int po = (x - MOM_HALF) - ((x - TILE_HALF) & ~3);  // patch column 0 inside the tile: 6..9
+                const uint32_t* t = tiles[wave][q] + (po >> 2);
+                const uint32_t sh = static_cast<uint32_t>(po & 3);
+                uint32_t su = 0, srow = 0;
+                int sv = 0;
+#pragma unroll
+                for (int k = 0; k < SLOTS; ++k) {
+                    const uint32_t lo = t[mom_idx[k]], hi = t[mom_idx[k] + 1];
+                    const uint32_t cur = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    su = __builtin_amdgcn_udot4(cur, wal[k].x, su, false);
+                    const uint32_t row = __builtin_amdgcn_udot4(cur, wal[k].y, 0u, false);
+                    srow += row;
+                    sv += vrow[k] * static_cast<int>(row);
                 }
-                if (q + 1 < FUSED_PER_WAVE) {
-                    xq = lane_value(kx, q + 1);
-                    yq = lane_value(ky, q + 1);
-                    sq = lane_value(kslot, q + 1);
-                    if (sq >= 0 && patch_inside(xq, yq)) {
-                        fetch(xq, yq);  // in flight while the moments of keypoint q are reduced
-                    }
-                }
-                if (inside) {
-                    wave_fence();
-                    const int a = (x - MOM_HALF) & 3;
-                    const int shift = a < 2 ? 2 : 1;  // ((x-15) & ~3) - ((x-21) & ~3) is 8 or 4 bytes
-                    uint32_t cur[SLOTS];
-#pragma unroll
-                    for (int k = 0; k < SLOTS; ++k) {
-                        cur[k] = tiles[wave][q][mom_idx[k] + shift];
-                    }
-                    uint32_t su = 0, s = 0;
-                    int sv = 0;
-                    auto reduce = [&](const uint2* w) {
-#pragma unroll
-                        for (int k = 0; k < SLOTS; ++k) {
-                            su = __builtin_amdgcn_udot4(cur[k], w[k].x, su, false);
-                            const uint32_t row = __builtin_amdgcn_udot4(cur[k], w[k].y, 0u, false);
-                            s += row;
-                            sv += vrow[k] * static_cast<int>(row);
-                        }
-                    };
-                    switch (a) {  // wave-uniform
-                        case 0: reduce(wgt[0]); break;
-                        case 1: reduce(wgt[1]); break;
-                        case 2: reduce(wgt[2]); break;
-                        default: reduce(wgt[3]); break;
-                    }
-                    const int m10 = wave_sum_dpp(static_cast<int>(su) - MOM_HALF * static_cast<int>(s));
-                    const int m01 = wave_sum_dpp(sv);
-                    if (lane == q) {
-                        my_m01 = m01;
-                        my_m10 = m10;
-                    }
+                const int m10 = wave_sum_dpp(static_cast<int>(su) - MOM_HALF * static_cast<int>(srow));
+                const int m01 = wave_sum_dpp(sv);
+                if (lane == q) {
+                    my_m01 = m01;
+                    my_m10 = m10;
                 }
             }
         }
@@ -763,6 +845,8 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, Detect
             }
             kps[kslot].angle = angle;  // feature_detector.cpp:37-38
         }
+        // the next group's tiles: in flight (in registers) while this group's descriptors are sampled
+        issue_group(kslot1, kx1, ky1, 0, EARLY_TILES);
         // ---- phase C: BRIEF from the tiles still in LDS
 #pragma unroll
         for (int q = 0; q < FUSED_PER_WAVE; ++q) {
@@ -812,6 +896,7 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(BatchView v, Detect
             }
         }
         wave_fence();  // the tiles are overwritten by the next group
+        kslot = kslot1, kx = kx1, ky = ky1;
     }
 }
 
@@ -836,9 +921,13 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     static const bool fused_allowed = getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr;
     if (fused_allowed && radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 &&
         v.width % 8 == 0) {
-        const int bpf = static_cast<int>(grid.x);
-        hipLaunchKernelGGL(describe_fused_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, v, p, pattern_dev, nframes,
-                           bpf, use_visit ? 1 : 0);
+        const int waves_per_frame = static_cast<int>(grid.x) * 4;
+        // Measured alternatives (more waves per SIMD by capping the registers at 96 / 80 / 64 with 4, 3 or 2
+        // tiles per wave and 1-, 2- or 4-wave workgroups) all spill and ran 25 % to 2.4x slower.
+        const int wpb = 4;
+        const int bpf = (waves_per_frame + wpb - 1) / wpb;
+        hipLaunchKernelGGL((describe_fused_kernel<4, 4, 4>), dim3(frame_grid(nframes, bpf)), dim3(64 * wpb), 0, stream, v, p,
+                           pattern_dev, nframes, bpf, use_visit ? 1 : 0);
         if (ev_after_moments != nullptr) {
             (void)hipEventRecord(ev_after_moments, stream);
         }

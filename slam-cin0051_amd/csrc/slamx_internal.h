@@ -79,7 +79,10 @@ struct DetectorParams {
 // dwords e = l + 64 k (k < 5, e = row * 9 + dword column).  Entry ((a * 5 + k) * 64 + l) of the
 // table holds, for alignment a = (x - 15) & 3, the four per-byte weights u + 15 (.x) and the four
 // disc-membership flags (.y) of that dword, zero outside the disc of the given radius.
-constexpr int MOMENT_TABLE_ENTRIES = 4 * 5 * 64;
+// Behind those 4 * 5 * 64 entries: the same pair for the 31-row x 8-dword patch that starts exactly at
+// column x - 15 (entry k * 64 + l = patch dword l + 64 k), used by describe_fused_kernel.
+constexpr int MOMENT_ALIGNED_SLOTS = 4;
+constexpr int MOMENT_TABLE_ENTRIES = 4 * 5 * 64 + MOMENT_ALIGNED_SLOTS * 64;
 void moment_weight_table(int radius, uint32_t* out_xy /* 2 * MOMENT_TABLE_ENTRIES words */);
 
 // Correctly rounded float sqrt.  NOTE: HIP's __fsqrt_rn() is __ocml_native_sqrt_f32 (1 ulp,
