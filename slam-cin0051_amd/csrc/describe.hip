@@ -862,22 +862,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
             if (ca == ca) {
                 const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tiles[wave][q]);
                 const int cx = x - ((x - TILE_HALF) & ~3);  // pixel (x+du, y+dv) at t8[(dv+21)*48 + cx + du]
-                bool valid = false;
-                bool bit = false;
-                if (lane < P.pattern_len) {
-                    const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(q1x, ca), __fmul_rn(q1y, sa)));
-                    const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(q1x, sa), __fmul_rn(q1y, ca)));
-                    const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(q2x, ca), __fmul_rn(q2y, sa)));
-                    const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(q2x, sa), __fmul_rn(q2y, ca)));
-                    const int x1 = dx1 + x, y1 = dy1 + y, x2 = dx2 + x, y2 = dy2 + y;
-                    valid = x1 >= 0 && x1 < v.cols && y1 >= 0 && y1 < v.rows && x2 >= 0 && x2 < v.cols && y2 >= 0 &&
-                            y2 < v.rows;
-                    if (valid) {
-                        const uint8_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
-                        const uint8_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
-                        bit = I1 < I2;
-                    }
-                }
+                // Straight-line code: a rotated offset stays within +-21 of the keypoint, i.e. inside the tile,
+                // whether or not the pixel is inside the image, so both samples are read unconditionally and
+                // the image test only masks the result (written with short-circuit && / nested ifs this body
+                // compiled to four levels of exec-mask branches; lanes >= pattern_len carry zero offsets).
+                const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(q1x, ca), __fmul_rn(q1y, sa)));
+                const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(q1x, sa), __fmul_rn(q1y, ca)));
+                const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(q2x, ca), __fmul_rn(q2y, sa)));
+                const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(q2x, sa), __fmul_rn(q2y, ca)));
+                const uint32_t I1 = t8[(dy1 + TILE_HALF) * (TILE_DW * 4) + cx + dx1];
+                const uint32_t I2 = t8[(dy2 + TILE_HALF) * (TILE_DW * 4) + cx + dx2];
+                const bool valid = static_cast<int>(static_cast<uint32_t>(dx1 + x) < static_cast<uint32_t>(v.cols)) &
+                                   static_cast<int>(static_cast<uint32_t>(dy1 + y) < static_cast<uint32_t>(v.rows)) &
+                                   static_cast<int>(static_cast<uint32_t>(dx2 + x) < static_cast<uint32_t>(v.cols)) &
+                                   static_cast<int>(static_cast<uint32_t>(dy2 + y) < static_cast<uint32_t>(v.rows)) &
+                                   static_cast<int>(lane < P.pattern_len);
+                const bool bit = I1 < I2;
                 const unsigned long long vm = __ballot(valid);
                 const unsigned long long bm = __ballot(valid && bit);
                 packed = bm;  // every pair valid: nothing to close up
