@@ -18,8 +18,9 @@ __global__ void trig_kernel(const float* m01, const float* m10, int n, float* de
     const float angle = __fmul_rn(glibc_atan2f(m01[i], m10[i]), rad_to_deg());
     const float a = __fmul_rn(angle, deg_to_rad());
     deg[i] = angle;
-    c[i] = glibc_cosf(a);
-    s[i] = glibc_sinf(a);
+    // the combined routine of the describe kernels; the generic describe_kernel keeps the two separate
+    // functions, and test_compute_other_patterns compares that path with the oracle as well
+    glibc_sincosf(a, &s[i], &c[i]);
 }
 
 // the penalty arithmetic of match.hip (feature_matcher.cpp:161-170), one tuple per lane

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void trig_kernel(BatchView v, const int2* __re
         if (m.y != 0x7fffffff) {
             angle = __fmul_rn(glibc_atan2f(static_cast<float>(m.x), static_cast<float>(m.y)), rad_to_deg());
             const float a = __fmul_rn(angle, deg_to_rad());
-            r = make_float2(glibc_cosf(a), glibc_sinf(a));
+            glibc_sincosf(a, &r.y, &r.x);
         } else {
             r.x = __uint_as_float(0x7fc00000u);  // NaN cos marks "outside" for brief_kernel
         }
@@ -840,8 +840,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
             if (my_m10 != 0x7fffffff) {
                 angle = __fmul_rn(glibc_atan2f(static_cast<float>(my_m01), static_cast<float>(my_m10)), rad_to_deg());
                 const float ar = __fmul_rn(angle, deg_to_rad());
-                my_cos = glibc_cosf(ar);
-                my_sin = glibc_sinf(ar);
+                glibc_sincosf(ar, &my_sin, &my_cos);
             }
             kps[kslot].angle = angle;  // feature_detector.cpp:37-38
         }

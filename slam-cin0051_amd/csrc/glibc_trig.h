@@ -274,6 +274,41 @@ __device__ inline float glibc_cosf(float y) {
     return __uint_as_float(0x7fc00000u);
 }
 
+// cosf(y) and sinf(y) together, without divergent branches: both functions reduce the argument the same
+// way and evaluate the same two polynomials -- sinf returns the sine polynomial for even n and the cosine
+// polynomial for odd n, cosf the other way round -- so one reduction and one evaluation of each serve both.
+// Table entry 1 is entry 0 with c0..c4 negated, and every operation involved is odd-symmetric (fma,
+// multiply, the final conversion, all round-to-nearest), so "entry 1" is a sign flip of the entry-0
+// result.  The small-argument path (|y| < pi/4) is the general one with n = 0 and no reduction.
+// Bit-identical to glibc_cosf / glibc_sinf above (tests/test_parity_gpu.py, test_trig_*).
+__device__ __forceinline__ void glibc_sincosf(float y, float* sin_out, float* cos_out) {
+    const double x = static_cast<double>(y);
+    const uint32_t top = abstop12(y);
+    const bool small = top < 0x3f4u;  // |y| < pi/4
+    int n;
+    const double reduced = sincos_reduce(x, &n);
+    n = small ? 0 : n;
+    const double xr = small ? x : reduced;
+    const double x2 = __dmul_rn(xr, xr);
+    const SinCosTab t = sincos_tab(0);
+    const double sgn = ((n & 3) == 0 || (n & 3) == 3) ? 1.0 : -1.0;
+    const float a = sincos_sin_poly(__dmul_rn(xr, sgn), x2, t);
+    const float b0 = sincos_cos_poly(x2, t);
+    const float b = (n & 2) ? -b0 : b0;
+    float sv = (n & 1) == 0 ? a : b;
+    float cv = (n & 1) == 0 ? b : a;
+    if (top < 0x398u) {  // |y| < 2^-12
+        sv = y;
+        cv = 1.0f;
+    }
+    if (top >= 0x42fu) {  // |y| >= 120: not reached from atan2f (see the header)
+        sv = __uint_as_float(0x7fc00000u);
+        cv = sv;
+    }
+    *sin_out = sv;
+    *cos_out = cv;
+}
+
 // constants::RADIANS_TO_DEGREES / DEGREES_TO_RADIANS, feature_detector.hpp:21-22
 __device__ __forceinline__ float rad_to_deg() { return __uint_as_float(0x42652ee1u); }
 __device__ __forceinline__ float deg_to_rad() { return __uint_as_float(0x3c8efa35u); }
