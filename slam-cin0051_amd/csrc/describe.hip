@@ -354,6 +354,24 @@ __device__ __forceinline__ int wave_sum_dpp(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// the same for N independent values at once, one reduction step of all of them after the other (the sums
+// land in lane 63 of x[i])
+template <int N>
+__device__ __forceinline__ void wave_sums_dpp(int* x) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x4E, 0xf, 0xf, false);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x141, 0xf, 0xf, false);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x140, 0xf, 0xf, false);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x142, 0xa, 0xf, false);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] += __builtin_amdgcn_update_dpp(0, x[i], 0x143, 0xc, 0xf, false);
+}
+
 // Wave per keypoint, no LDS: lane l loads the tile dwords e = l + 64 k (k < 5) of the 31 x 36-byte
 // tile straight into registers -- for the NEXT keypoint while the current one is reduced -- and
 // multiplies them with per-lane constant weights: v_dot4_u32_u8 with the per-byte weights u + 15
@@ -804,10 +822,15 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
         load_group(g + nwaves, kslot1, kx1, ky1);
         // ---- phase A: tiles registers -> LDS, moments (lane q keeps m01, m10 of keypoint q)
         int my_m01 = 0, my_m10 = 0x7fffffff;
+        int part[2 * FUSED_PER_WAVE];  // per-lane partial sums: m10 of keypoint q, then m01 of keypoint q
+        unsigned inside_mask = 0;      // wave-uniform
 #pragma unroll
         for (int q = 0; q < FUSED_PER_WAVE; ++q) {
             const int x = lane_value(kx, q), y = lane_value(ky, q);
+            part[q] = 0;
+            part[FUSED_PER_WAVE + q] = 0;
             if (lane_value(kslot, q) >= 0 && patch_inside(x, y)) {  // wave-uniform
+                inside_mask |= 1u << q;
                 pf[q].commit(tiles[wave][q], lane);
                 wave_fence();
                 const int po = (x - MOM_HALF) - ((x - TILE_HALF) & ~3);  // patch column 0 inside the tile: 6..9
@@ -824,12 +847,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
                     srow += row;
                     sv += vrow[k] * static_cast<int>(row);
                 }
-                const int m10 = wave_sum_dpp(static_cast<int>(su) - MOM_HALF * static_cast<int>(srow));
-                const int m01 = wave_sum_dpp(sv);
-                if (lane == q) {
-                    my_m01 = m01;
-                    my_m10 = m10;
-                }
+                part[q] = static_cast<int>(su) - MOM_HALF * static_cast<int>(srow);
+                part[FUSED_PER_WAVE + q] = sv;
+            }
+        }
+        // the 2 x FUSED_PER_WAVE wave sums together, step by step: a DPP add that reads the result of the
+        // previous one needs two idle issue slots, which the other chains fill
+        wave_sums_dpp<2 * FUSED_PER_WAVE>(part);
+#pragma unroll
+        for (int q = 0; q < FUSED_PER_WAVE; ++q) {
+            // readlane in uniform control flow: under `lane == q` the compiler may sink the last add into
+            // the branch, where lane 63 is switched off, and readlane would return a stale value
+            const int m10 = __builtin_amdgcn_readlane(part[q], 63);
+            const int m01 = __builtin_amdgcn_readlane(part[FUSED_PER_WAVE + q], 63);
+            if (((inside_mask >> q) & 1u) != 0 && lane == q) {
+                my_m10 = m10;
+                my_m01 = m01;
             }
         }
         // ---- phase B: angle, cos, sin -- lane q for keypoint q (the serial glibc chain)
