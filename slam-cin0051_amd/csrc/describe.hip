@@ -789,17 +789,27 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
             ky = static_cast<int>(kps[kslot].y);
         }
     };
-    auto issue_group = [&](int kslot, int kx, int ky, int q_first, int q_end) {  // global loads of tiles, no waiting
+    // Two wave-uniform bit masks of a group, evaluated once by the lanes that hold its keypoints: bit q =
+    // keypoint q exists and its orientation patch is inside the image / bit 16 + q = its whole tile lies
+    // inside the padded frame (no per-element bounds checks when loading it)
+    auto group_masks = [&](int kslot, int kx, int ky) {
+        const bool in = kslot >= 0 && patch_inside(kx, ky);
+        const int xa = (kx - TILE_HALF) & ~3;
+        const bool whole = kx - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && ky - TILE_HALF >= 0 && ky + TILE_HALF < v.rows;
+        const uint32_t a = static_cast<uint32_t>(__ballot(in)) & ((1u << FUSED_PER_WAVE) - 1u);
+        const uint32_t b = static_cast<uint32_t>(__ballot(in && whole)) & ((1u << FUSED_PER_WAVE) - 1u);
+        return a | (b << 16);
+    };
+    auto issue_group = [&](uint32_t masks, int kx, int ky, int q_first, int q_end) {  // global loads of tiles, no waiting
 #pragma unroll
         for (int q = 0; q < FUSED_PER_WAVE; ++q) {
             if (q < q_first || q >= q_end) {
                 continue;
             }
-            const int x = lane_value(kx, q), y = lane_value(ky, q);
-            if (lane_value(kslot, q) >= 0 && patch_inside(x, y)) {  // wave-uniform
-                const int xa = (x - TILE_HALF) & ~3;
-                if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
-                    pf[q].issue_inside(img, v.pitch, x, y, tile_off);  // no per-element bounds checks
+            if ((masks >> q) & 1u) {  // wave-uniform
+                const int x = lane_value(kx, q), y = lane_value(ky, q);
+                if ((masks >> (16 + q)) & 1u) {
+                    pf[q].issue_inside(img, v.pitch, x, y, tile_off);
                 } else {
                     pf[q].issue(v, img, x, y, lane);
                 }
@@ -815,22 +825,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
     int g = bx * WPB + wave;
     int kslot, kx, ky;
     load_group(g, kslot, kx, ky);
-    issue_group(kslot, kx, ky, 0, EARLY_TILES);
+    uint32_t masks = group_masks(kslot, kx, ky);
+    issue_group(masks, kx, ky, 0, EARLY_TILES);
     for (; g * FUSED_PER_WAVE < n; g += nwaves) {  // wave-uniform
-        issue_group(kslot, kx, ky, EARLY_TILES, FUSED_PER_WAVE);
+        issue_group(masks, kx, ky, EARLY_TILES, FUSED_PER_WAVE);
         int kslot1, kx1, ky1;
         load_group(g + nwaves, kslot1, kx1, ky1);
         // ---- phase A: tiles registers -> LDS, moments (lane q keeps m01, m10 of keypoint q)
         int my_m01 = 0, my_m10 = 0x7fffffff;
         int part[2 * FUSED_PER_WAVE];  // per-lane partial sums: m10 of keypoint q, then m01 of keypoint q
-        unsigned inside_mask = 0;      // wave-uniform
+        const uint32_t inside_mask = masks;
 #pragma unroll
         for (int q = 0; q < FUSED_PER_WAVE; ++q) {
-            const int x = lane_value(kx, q), y = lane_value(ky, q);
             part[q] = 0;
             part[FUSED_PER_WAVE + q] = 0;
-            if (lane_value(kslot, q) >= 0 && patch_inside(x, y)) {  // wave-uniform
-                inside_mask |= 1u << q;
+            if ((masks >> q) & 1u) {  // wave-uniform
+                const int x = lane_value(kx, q);
                 pf[q].commit(tiles[wave][q], lane);
                 wave_fence();
                 const int po = (x - MOM_HALF) - ((x - TILE_HALF) & ~3);  // patch column 0 inside the tile: 6..9
@@ -878,7 +888,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
             kps[kslot].angle = angle;  // feature_detector.cpp:37-38
         }
         // the next group's tiles: in flight (in registers) while this group's descriptors are sampled
-        issue_group(kslot1, kx1, ky1, 0, EARLY_TILES);
+        const uint32_t masks1 = group_masks(kslot1, kx1, ky1);
+        issue_group(masks1, kx1, ky1, 0, EARLY_TILES);
         // ---- phase C: BRIEF from the tiles still in LDS
 #pragma unroll
         for (int q = 0; q < FUSED_PER_WAVE; ++q) {
@@ -929,6 +940,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
         }
         wave_fence();  // the tiles are overwritten by the next group
         kslot = kslot1, kx = kx1, ky = ky1;
+        masks = masks1;
     }
 }
 
