@@ -174,7 +174,7 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            nr += __popcll(__ballot(base + u * 64 + lane < hi && sc[u] >= p));
+            nr += __popcll(__ballot(base + u * 64 + lane < hi) & __ballot(sc[u] >= p));
         }
     }
     // pass 2: classify, list the swapped positions by rank
@@ -199,8 +199,11 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
             const uint32_t sc = scs[u];
             const bool is_l = in && sc <= p;
             const bool is_r = in && sc >= p;
-            const unsigned long long ml = __ballot(is_l);
-            const unsigned long long mr = __ballot(is_r);
+            // ballots of single comparisons, combined on the scalar side: the ballot of a compound predicate
+            // compiles to v_cndmask + v_cmp_ne on top of the comparisons
+            const unsigned long long m_in = __ballot(in);
+            const unsigned long long ml = __ballot(sc <= p) & m_in;
+            const unsigned long long mr = __ballot(sc >= p) & m_in;
             const int l_left = run_l + rank_below(ml);                            // L stoppers left of i
             const int r_right = nr - (run_r + rank_below(mr) + (is_r ? 1 : 0));  // R stoppers right of i
             const bool swap_l = is_l && r_right >= l_left + 1;
@@ -211,9 +214,9 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
             if (swap_r) {
                 rpos[r_right] = static_cast<uint16_t>(i - first);
             }
-            const unsigned long long sl = __ballot(swap_l);
+            const unsigned long long sl = __ballot(r_right >= l_left + 1) & ml;
             const unsigned long long stay = ml & ~sl;
-            const unsigned long long moved = __ballot(swap_r);
+            const unsigned long long moved = __ballot(l_left >= r_right + 1) & mr;
             K += __popcll(sl);
             if (stay != 0 && cut_l == 0x7fffffff) {
                 cut_l = base + __ffsll(static_cast<long long>(stay)) - 1;
@@ -257,7 +260,7 @@ __device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth
         if (__ballot(active) == 0) {
             break;
         }
-        if (__ballot(active && dep == 0) != 0) {
+        if ((__ballot(active) & __ballot(dep == 0)) != 0) {
             // depth limit: __partial_sort(first, last, last) = heapsort, by the first lane of the range
             wave_mem_fence();
             if (lane < m) {
@@ -319,8 +322,12 @@ __device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth
         const bool is_l = in && score_of(v) <= p;
         const bool is_r = in && score_of(v) >= p;
         const unsigned long long range = low_mask(hi) & ~low_mask(lo + 1);
-        const unsigned long long ls = __ballot(is_l) & range;
-        const unsigned long long rs = __ballot(is_r) & range;
+        // Ballots of single comparisons (a compound predicate costs v_cndmask + v_cmp_ne on top).  Every lane
+        // compares against the pivot of its own sub-range, and inside `range` (lo, hi) all lanes belong to
+        // this lane's sub-range, share its `active` and lie right of its pivot: the masks below are the
+        // ballots of is_l / is_r wherever an active lane uses them.
+        const unsigned long long ls = __ballot(score_of(v) <= p) & range;
+        const unsigned long long rs = __ballot(score_of(v) >= p) & range;
         const int l_left = __popcll(ls & low_mask(lane));        // L stoppers of my range left of me
         const int r_right = __popcll(rs & ~low_mask(lane + 1));  // R stoppers of my range right of me
         const bool swap_l = is_l && r_right >= l_left + 1;
@@ -340,8 +347,8 @@ __device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth
         }
         wave_mem_fence();
         v = __shfl(v, partner);
-        const unsigned long long stay_l = __ballot(is_l && !swap_l) & range;
-        const unsigned long long moved_r = __ballot(swap_r) & range;
+        const unsigned long long stay_l = ls & ~__ballot(r_right >= l_left + 1);
+        const unsigned long long moved_r = rs & __ballot(l_left >= r_right + 1);
         const int cut_l = stay_l != 0 ? __ffsll(static_cast<long long>(stay_l)) - 1 : 64;
         const int cut_r = moved_r != 0 ? __ffsll(static_cast<long long>(moved_r)) - 1 : 64;
         const int cut = min(cut_l, cut_r);
@@ -435,16 +442,18 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
             const bool in = w_lo + c * 64 + lane < w_hi;
-            nl += static_cast<uint32_t>(__popcll(__ballot(in && held[c] <= p)));
-            nr += static_cast<uint32_t>(__popcll(__ballot(in && held[c] >= p)));
+            const unsigned long long m_in = __ballot(in);
+            nl += static_cast<uint32_t>(__popcll(__ballot(held[c] <= p) & m_in));
+            nr += static_cast<uint32_t>(__popcll(__ballot(held[c] >= p) & m_in));
         }
     } else {
         for (int base = w_lo; base < w_hi; base += 64) {
             const int i = base + lane;
             const bool in = i < w_hi;
             const uint32_t sc = in ? score_of(a[i]) : 0u;
-            nl += static_cast<uint32_t>(__popcll(__ballot(in && sc <= p)));
-            nr += static_cast<uint32_t>(__popcll(__ballot(in && sc >= p)));
+            const unsigned long long m_in = __ballot(in);
+            nl += static_cast<uint32_t>(__popcll(__ballot(sc <= p) & m_in));
+            nr += static_cast<uint32_t>(__popcll(__ballot(sc >= p) & m_in));
         }
     }
     if (lane == 0) {
@@ -470,8 +479,9 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
         const bool in = i < w_hi;
         const bool is_l = in && sc <= p;
         const bool is_r = in && sc >= p;
-        const unsigned long long ml = __ballot(is_l);
-        const unsigned long long mr = __ballot(is_r);
+        const unsigned long long m_in = __ballot(in);
+        const unsigned long long ml = __ballot(sc <= p) & m_in;
+        const unsigned long long mr = __ballot(sc >= p) & m_in;
         const uint32_t l_left = l_before + run_l + static_cast<uint32_t>(rank_below(ml));  // L at positions < i
         const uint32_t r_le = run_r + static_cast<uint32_t>(rank_below(mr)) + (is_r ? 1u : 0u);
         const uint32_t r_right = r_after + (nr - r_le);  // R at positions > i
@@ -485,9 +495,9 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
         if (swap_r) {
             rpos[r_right] = static_cast<PosT>(i - first);
         }
-        const unsigned long long sl = __ballot(swap_l);
+        const unsigned long long sl = __ballot(r_right >= l_left + 1u) & ml;
         const unsigned long long stay = ml & ~sl;
-        const unsigned long long moved = __ballot(swap_r);
+        const unsigned long long moved = __ballot(l_left >= r_right + 1u) & mr;
         my_swaps += __popcll(sl);
         if (stay != 0 && min_unswapped_l == 0x7fffffff) {
             min_unswapped_l = base + __ffsll(static_cast<long long>(stay)) - 1;
