@@ -9,15 +9,17 @@
 // MI355X design: integer-only, one image read.
 //   K1  fast_detect : one workgroup = 256 x 32 pixel tile, staged through LDS with a 3-px halo as
 //                     aligned dword loads; the cardinal pretest on 4 pixels per lane with packed
-//                     16-bit math, the segment test only on the compacted survivors; the corner
-//                     predicate of a 64-pixel row segment is one 64-bit word of a corner bitmap
-//                     (W*H/8 bytes), the only thing written.
-//   K1b scan        : per frame, exclusive prefix sum of the bitmap popcounts in raster order
+//                     16-bit math, the segment test (and the score, while the circle is in LDS)
+//                     only on the compacted survivors.  Written: the corner predicate of every
+//                     64-pixel row segment as one 64-bit word of a corner bitmap (W*H/8 bytes), the
+//                     popcount of every word, and the tile's corners as (position, score) entries.
+//   K1b scan        : per frame, exclusive prefix sum of the word popcounts in raster order
 //                     (row-major, word-major) -> the raster index of every corner is
-//                     wordoff[word] + popcount(bits below it).  This bitmap+prefix pair is also
-//                     the spatial index the NMS kernel uses, so no cell grid is ever built.
-//   K1c expand      : one lane per bitmap word walks its set bits; writes (x,y) and the
-//                     sort key score<<20|rasterIndex in raster order.
+//                     wordoff[word] + popcount(bits below it).  The generic NMS path uses this
+//                     bitmap + prefix pair as its spatial index as well.
+//   K1c expand      : a wave per tile list: every entry looks up its raster index and writes
+//                     (x,y) and the sort key score<<20|rasterIndex; tiles whose list overflowed
+//                     walk their bitmap words and score the corners from the image.
 #include "slamx_internal.h"
 
 namespace slamx {

@@ -431,7 +431,7 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 
 // ---------------------------------------------------------------------------------------------
 // Fast path (2 <= window <= GREEDY_MAX_WINDOW and the cell grid fits LDS): the reference's loop
-// itself, one wave per frame, 64 candidates per step.
+// itself, one workgroup of 1 + LOOKAHEAD waves per frame.
 //
 // The kept keypoints live in a grid of window x window pixel cells in LDS.  Kept points are at
 // least `window` apart, so a cell holds at most two of them (three points pairwise >= w apart
@@ -439,15 +439,18 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 // `window` to a pixel lies in the 3 x 3 cells around it.  A cell is one dword: two entries
 // (oy << 8 | ox, offsets inside the cell), 0x7f7f = empty -- chosen so that an empty entry fails
 // the distance test by itself (|127 - offset| - 2w >= w for w <= 24) and both entries of a cell are
-// tested at once in packed 16-bit arithmetic with no validity branch.
+// tested at once in packed 16-bit arithmetic with no validity branch.  The test is the reference's:
+// for integer coordinates sqrtf(dx^2+dy^2) < float(w) <=> dx^2+dy^2 < w^2.
 //
-// Per step the wave takes the next 64 candidates in std::sort order (lane = rank), drops those
-// with a kept point closer than `window` in the grid (exactly the reference's test: for integer
-// coordinates sqrtf(dx^2+dy^2) < float(w) <=> dx^2+dy^2 < w^2), then resolves the survivors among
-// themselves in rank order -- the lowest surviving lane is kept, it knocks out the later lanes
-// closer than `window`, repeat -- and inserts the kept ones into the grid.  That is the
-// sequential loop of feature_detector.cpp:165-185 with 64-wide steps; its cost is ~15 wave
-// instructions per candidate, against thousands of gathered loads for the dependency-round form.
+// The candidates are taken in std::sort order, 64 (one chunk) at a time.  Kept points never leave
+// the grid, so a test against ANY earlier state of the grid is a valid filter: the LOOKAHEAD filter
+// waves run a group of chunks ahead and drop what the grid already suppresses; wave 0 collects the
+// rest, in rank order, in a 64-entry batch, tests a full batch against the grid as it is then,
+// resolves its members among themselves in rank order -- the lowest surviving lane is kept, it
+// knocks out the later lanes closer than `window`, repeat -- and inserts the kept ones.  That is
+// the sequential loop of feature_detector.cpp:165-185: a candidate is kept iff no earlier kept
+// point is near, and every earlier kept point is either in the grid at the batch test or in the
+// same batch.  (The dependency-round form above needs thousands of gathered loads per frame.)
 constexpr int GREEDY_MAX_WINDOW = 24;
 constexpr int GREEDY_LDS_BUDGET = 150 * 1024;
 constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
