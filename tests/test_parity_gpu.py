@@ -429,6 +429,39 @@ def test_batch_equals_single_frame(slamx, oracle):
     assert nm[0] == 0
 
 
+@pytest.mark.parametrize("window", [3, 12])
+def test_batch_of_identical_frames_is_timing_independent(slamx, oracle, window):
+    """The greedy NMS has waves that filter candidates against a grid another wave is writing, the sort has a
+    work queue: the result must not depend on how the waves interleave.  256 copies of two crowded frames run
+    side by side (different CUs, different neighbours, different timing), three times over; every copy must
+    give the oracle's keypoints, descriptors and matches."""
+    d = slamx.FeatureDetector(cfg_of(slamx, t=25, arc=9, window=window))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
+    rng = np.random.default_rng(window)
+    noise = rng.integers(0, 256, (150, 420), dtype=np.uint8)
+    rects = synth(slamx, 7, 150, 420, 900, rmin=3, rmax=14)
+    n = 256
+    frames = np.stack([noise if k % 2 == 0 else rects for k in range(n)])
+    refs = [oracle.detect_and_compute(frames[k], Pp) for k in range(2)]
+    ref_m = [oracle.match(refs[1][1], refs[0][1], refs[1][0], refs[0][0], oracle.match_params(m.cfg)),
+             oracle.match(refs[0][1], refs[1][1], refs[0][0], refs[1][0], oracle.match_params(m.cfg))]
+    b = slamx.Batch(d, 150, 420, n, max_candidates=16384, max_keypoints=8192)
+    b.upload(frames)
+    for rep in range(3):
+        b.detect_and_compute(n)
+        b.match_consecutive(m, n, use_keypoints=True)
+        for k in range(n):
+            kps, desc = b.download(k)
+            rk, rd = refs[k % 2]
+            assert_records_equal(kps, rk, "rep %d frame %d" % (rep, k))
+            assert np.array_equal(desc, rd), "descriptors rep %d frame %d" % (rep, k)
+            if k > 0:
+                # frame k (odd: rects vs noise; even: noise vs rects) against frame k - 1
+                assert_records_equal(b.download_matches(m, k), ref_m[0] if k % 2 == 1 else ref_m[1],
+                                     "matches rep %d frame %d" % (rep, k))
+
+
 def test_batch_upload_host_buffer_reusable_on_return(slamx):
     """slamx.h: the host buffer may be reused as soon as slamx_batch_upload returns."""
     d = slamx.FeatureDetector(cfg_of(slamx))
