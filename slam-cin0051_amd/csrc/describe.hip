@@ -67,6 +67,15 @@ __device__ __forceinline__ int select64d(unsigned long long m, int k) {
     return pos;
 }
 
+// Keypoint coordinates are caller data (slamx_compute).  The reference truncates them with
+// static_cast<int>(kp.x) (feature_detector.cpp:207-208, :235-236), undefined for values an int
+// cannot hold; here they are clamped to +-2^20 first (NaN -> -2^20), so that x +- radius cannot wrap
+// and such a keypoint is simply "outside the image": angle 0, zero descriptor.  Identical to the
+// reference for every coordinate an image (<= 65535 per side) can contain.
+__device__ __forceinline__ int kp_coord(float c) {
+    return static_cast<int>(__builtin_amdgcn_fmed3f(c, -1048576.0f, 1048576.0f));
+}
+
 __device__ __forceinline__ unsigned long long low_mask_d(int nbits) {  // bits [0, nbits)
     return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
 }
@@ -92,8 +101,8 @@ __global__ __launch_bounds__(256) void describe_kernel(BatchView v, DetectorPara
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {  // wave-uniform trip count
     slamx_keypoint* kp = v.kps + static_cast<size_t>(f) * v.maxK + i;
     uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + i) * v.width;
-    const int x = static_cast<int>(kp->x);
-    const int y = static_cast<int>(kp->y);
+    const int x = kp_coord(kp->x);
+    const int y = kp_coord(kp->y);
     const int radius = P.patch / 2;
     const bool inside = !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
 
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
         int kx = 0, ky = 0, kslot = 0;
         if (mine < n) {
             kslot = use_visit ? static_cast<int>(visit[mine]) : mine;
-            kx = static_cast<int>(kps[kslot].x);
-            ky = static_cast<int>(kps[kslot].y);
+            kx = kp_coord(kps[kslot].x);
+            ky = kp_coord(kps[kslot].y);
         }
         const int cnt = min(64, (n - 1 - (i0 + chunk * stride)) / stride + 1);
         int x = __builtin_amdgcn_readlane(kx, 0);
@@ -603,8 +612,8 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
         float kc = 0.0f, ks = 0.0f;
         if (mine < n) {
             kslot = use_visit ? static_cast<int>(visit[mine]) : mine;
-            kx = static_cast<int>(kps[kslot].x);
-            ky = static_cast<int>(kps[kslot].y);
+            kx = kp_coord(kps[kslot].x);
+            ky = kp_coord(kps[kslot].y);
             const float2 r = csf[kslot];
             kc = r.x;
             ks = r.y;
@@ -785,8 +794,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
         const int idx = g * FUSED_PER_WAVE + lane;
         if (lane < FUSED_PER_WAVE && idx < n) {
             kslot = use_visit ? static_cast<int>(visit[idx]) : idx;
-            kx = static_cast<int>(kps[kslot].x);
-            ky = static_cast<int>(kps[kslot].y);
+            kx = kp_coord(kps[kslot].x);
+            ky = kp_coord(kps[kslot].y);
         }
     };
     // Two wave-uniform bit masks of a group, evaluated once by the lanes that hold its keypoints: bit q =

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
         best_idx[u] = -1;
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) {
-            q[u][w] = i < n1 ? qd[static_cast<size_t>(i) * stride + w] : 0u;
+            // WORDS can exceed the descriptor's own word count (5 -> 6, 7 -> 8, 9..15 -> 16): the
+            // words past `stride` belong to the NEXT descriptor and are read as zero here
+            q[u][w] = (i < n1 && w < stride) ? qd[static_cast<size_t>(i) * stride + w] : 0u;
         }
         if (use_kp && i < n1) {
             const slamx_keypoint k = mv.kps[static_cast<size_t>(qf) * mv.maxK + i];
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
         for (int e = threadIdx.x; e < tn * WORDS; e += 256) {
             const int j = e / WORDS;
             const int w = e - j * WORDS;
-            tdesc[e] = td[static_cast<size_t>(t0 + j) * stride + w];
+            tdesc[e] = w < stride ? td[static_cast<size_t>(t0 + j) * stride + w] : 0u;
         }
         if (use_kp) {
             for (int e = threadIdx.x; e < tn; e += 256) {

@@ -117,6 +117,7 @@ struct slamx_batch {
                           // the second from ramping up while the first drains: ~9 % on the bench step)
     bool active = false;  // the current call records
     int last_frames = 0;
+    int last_status = 0;  // per-frame status bits seen by the most recent slamx_batch_download
 };
 
 namespace {
@@ -285,9 +286,27 @@ void enqueue_compute(slamx_batch* b, int nframes, bool after_nms) {
     record(b, 10);
 }
 
-int ensure_single(slamx_detector* det, int rows, int cols, int min_keypoints) {
+// Candidate capacity of the implicit one-frame batch behind the host-buffer API, which has no
+// capacity knob.  First sizing: a quarter of the pixels (natural images give 1-2 %); `every_pixel`
+// is the second sizing, taken when a frame overflowed the first: every pixel a candidate, up to
+// the hard limit of 2^20 (the sort key holds a 20-bit raster index, SCORE_SHIFT).
+long long single_capacity(int rows, int cols, bool every_pixel) {
+    const long long px = static_cast<long long>(rows) * cols;
+    long long cap = every_pixel ? px : px / 4;
+    if (cap < 1024) {
+        cap = 1024;
+    }
+    if (cap > MAX_CANDIDATES_HARD) {
+        cap = MAX_CANDIDATES_HARD;
+    }
+    return cap;
+}
+
+int ensure_single(slamx_detector* det, int rows, int cols, int min_keypoints, bool every_pixel = false) {
     slamx_batch* b = det->single;
-    if (b != nullptr && b->shape.rows == rows && b->shape.cols == cols && b->v.maxK >= min_keypoints) {
+    const long long cap = single_capacity(rows, cols, every_pixel);
+    if (b != nullptr && b->shape.rows == rows && b->shape.cols == cols && b->v.maxK >= min_keypoints &&
+        b->v.maxM >= cap) {
         return SLAMX_OK;
     }
     if (b != nullptr) {
@@ -298,18 +317,17 @@ int ensure_single(slamx_detector* det, int rows, int cols, int min_keypoints) {
     sh.rows = rows;
     sh.cols = cols;
     sh.max_frames = 1;
-    // the host-buffer API has no capacity knob: size for the worst case the image allows
-    const long long px = static_cast<long long>(rows) * cols;
-    long long cap = px / 4;
-    if (cap < 1024) {
-        cap = 1024;
-    }
-    if (cap > MAX_CANDIDATES_HARD) {
-        cap = MAX_CANDIDATES_HARD;
-    }
     sh.max_candidates = static_cast<int>(cap);
     sh.max_keypoints = std::max(static_cast<int>(cap), min_keypoints);
     return slamx_batch_create(det, &sh, &det->single);
+}
+
+// true when the one-frame batch overflowed its candidate capacity and a larger one can be had:
+// the caller re-runs the frame once with every_pixel sizing (the reference has no such limit)
+bool single_can_grow(const slamx_detector* det, int rc, int rows, int cols) {
+    const slamx_batch* b = det->single;
+    return rc == SLAMX_ERR_CAPACITY && b != nullptr && (b->last_status & STATUS_CAND_OVERFLOW) != 0 &&
+           b->v.maxM < single_capacity(rows, cols, true);
 }
 
 int check_image(const uint8_t* img, int rows, int cols, ptrdiff_t stride) {
@@ -390,8 +408,14 @@ int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
         }
         c->owns_stream = true;
     }
-    (void)hipEventCreate(&c->t0);
-    (void)hipEventCreate(&c->t1);
+    hipError_t ee = hipEventCreate(&c->t0);
+    if (ee == hipSuccess) {
+        ee = hipEventCreate(&c->t1);
+    }
+    if (ee != hipSuccess) {
+        slamx_ctx_destroy(c);
+        return fail(SLAMX_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(ee));
+    }
     *out = c;
     return SLAMX_OK;
 }
@@ -541,9 +565,11 @@ int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slam
         slamx_detector_destroy(d);
         return rc;
     }
-    HIP_TRY(hipMemcpy(d->pattern_dev, p8.data(), p8.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->weights_dev, w25, sizeof(w25), hipMemcpyHostToDevice));
-    if (cfg->patch_size / 2 <= 15) {
+    hipError_t e = hipMemcpy(d->pattern_dev, p8.data(), p8.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        e = hipMemcpy(d->weights_dev, w25, sizeof(w25), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && cfg->patch_size / 2 <= 15) {
         std::vector<uint32_t> mw(2 * MOMENT_TABLE_ENTRIES);
         moment_weight_table(cfg->patch_size / 2, mw.data());
         rc = dev_alloc(&d->moment_weights_dev, MOMENT_TABLE_ENTRIES);
@@ -551,7 +577,11 @@ int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slam
             slamx_detector_destroy(d);
             return rc;
         }
-        HIP_TRY(hipMemcpy(d->moment_weights_dev, mw.data(), mw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        e = hipMemcpy(d->moment_weights_dev, mw.data(), mw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        slamx_detector_destroy(d);  // the host object and its device buffers must not outlive a failed create
+        return fail(SLAMX_ERR_HIP, std::string("detector constants upload: ") + hipGetErrorString(e));
     }
     *out = d;
     return SLAMX_OK;
@@ -889,6 +919,7 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
     int cnt = 0;
     HIP_TRY(hipMemcpy(&st, b->v.status + frame, sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&cnt, b->v.n_kp + frame, sizeof(int), hipMemcpyDeviceToHost));
+    b->last_status = st;
     SLAMX_TRY(status_to_error(st, frame));
     if (n != nullptr) {
         *n = cnt;
@@ -999,13 +1030,20 @@ int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms) {
 int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
                  int cap, int* n) {
     SLAMX_TRY(check_image(img, rows, cols, stride));
-    SLAMX_TRY(ensure_single(det, rows, cols, 0));
-    slamx_batch* b = det->single;
-    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
-    begin_set(b);
-    enqueue_detect(b, 1);
-    HIP_TRY(hipGetLastError());
-    return slamx_batch_download(b, 0, kps, nullptr, cap, n);
+    for (int attempt = 0;; ++attempt) {
+        SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
+        slamx_batch* b = det->single;
+        SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+        HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), det->ctx->stream));
+        begin_set(b);
+        enqueue_detect(b, 1);
+        HIP_TRY(hipGetLastError());
+        const int rc = slamx_batch_download(b, 0, kps, nullptr, cap, n);
+        if (attempt == 0 && single_can_grow(det, rc, rows, cols)) {
+            continue;
+        }
+        return rc;
+    }
 }
 
 int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
@@ -1038,29 +1076,45 @@ int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, p
 int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
                              slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
     SLAMX_TRY(check_image(img, rows, cols, stride));
-    SLAMX_TRY(ensure_single(det, rows, cols, 0));
-    slamx_batch* b = det->single;
-    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
-    SLAMX_TRY(slamx_batch_detect_and_compute(b, 1));
-    return slamx_batch_download(b, 0, kps, desc, cap, n);
+    for (int attempt = 0;; ++attempt) {
+        SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
+        slamx_batch* b = det->single;
+        SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+        HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), det->ctx->stream));
+        SLAMX_TRY(slamx_batch_detect_and_compute(b, 1));
+        const int rc = slamx_batch_download(b, 0, kps, desc, cap, n);
+        if (attempt == 0 && single_can_grow(det, rc, rows, cols)) {
+            continue;
+        }
+        return rc;
+    }
 }
 
 int slamx_fast_candidates(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
                           slamx_keypoint* kps, int cap, int* n) {
     SLAMX_TRY(check_image(img, rows, cols, stride));
-    SLAMX_TRY(ensure_single(det, rows, cols, 0));
-    slamx_batch* b = det->single;
     hipStream_t s = det->ctx->stream;
     const DetectorParams p = params_of(det);
-    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
-    launch_fast_detect(b->v, p, 1, s);
-    launch_scan(b->v, 1, s);
-    launch_expand(b->v, p, 1, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    slamx_batch* b = nullptr;
     int st = 0, m = 0;
-    HIP_TRY(hipMemcpy(&st, b->v.status, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&m, b->v.n_cand, sizeof(int), hipMemcpyDeviceToHost));
+    for (int attempt = 0;; ++attempt) {
+        SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
+        b = det->single;
+        SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+        HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), s));
+        launch_fast_detect(b->v, p, 1, s);
+        launch_scan(b->v, 1, s);
+        launch_expand(b->v, p, 1, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(&st, b->v.status, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&m, b->v.n_cand, sizeof(int), hipMemcpyDeviceToHost));
+        b->last_status = st;
+        if (attempt == 0 && single_can_grow(det, status_to_error(st, 0), rows, cols)) {
+            continue;
+        }
+        break;
+    }
     SLAMX_TRY(status_to_error(st, 0));
     if (n != nullptr) {
         *n = m;

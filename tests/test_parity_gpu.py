@@ -86,6 +86,27 @@ def test_fast_candidates_dense_noise(slamx, oracle, arc, t):
     assert_records_equal(got, ref, "dense noise arc=%d t=%d" % (arc, t))
 
 
+@pytest.mark.parametrize("shape", [(64, 96), (200, 700)])
+def test_more_than_a_quarter_of_the_pixels_are_corners(slamx, oracle, shape):
+    """ContiguousPixelsThreshold 0 (accepted by the reference's validator) on noise: every pixel that
+    passes the cardinal pretest is a corner, well over the first sizing of the implicit one-frame
+    batch (a quarter of the pixels).  The host-buffer API then resizes for "every pixel" and runs
+    the frame again instead of failing -- the reference has no such limit."""
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    d = slamx.FeatureDetector(cfg_of(slamx, t=8, arc=0, window=4))
+    Pp = oracle.det_params(d.cfg)
+    ref = oracle.fast_candidates(img, Pp)
+    assert len(ref) > shape[0] * shape[1] // 4
+    assert_records_equal(d.fast_candidates(img), ref, "candidates beyond the first sizing")
+    if shape[0] * shape[1] < 10000:  # the oracle's greedy loop is O(M^2)
+        assert_records_equal(d.detect(img), oracle.detect(img, Pp), "detect beyond the first sizing")
+        k_ref, d_ref = oracle.detect_and_compute(img, Pp)
+        k_got, d_got = slamx.FeatureDetector(d.cfg).detectAndCompute(img)  # a fresh detector: first sizing again
+        assert_records_equal(k_got, k_ref, "detectAndCompute beyond the first sizing")
+        assert np.array_equal(d_got, d_ref)
+
+
 def test_fast_candidates_strided_input(det, oracle, P, slamx):
     big = synth(slamx, 3, 200, 300, 120, rmin=8, rmax=30)
     view = big[10:150, 17:260]  # non-contiguous rows
@@ -274,6 +295,36 @@ def test_compute_fractional_coordinates(det, oracle, P, slamx):
     assert np.array_equal(d_got, d_ref)
 
 
+@pytest.mark.parametrize("patch,pairs", [(31, 256), (7, 8), (101, 256), (31, 1024)])
+def test_compute_unrepresentable_coordinates(slamx, oracle, patch, pairs):
+    """Caller-supplied keypoints whose coordinates an int cannot hold (undefined in the reference's
+    static_cast<int>): they must behave as "outside the image" -- angle 0, zero descriptor -- and
+    never reach a tile load; the ordinary keypoints between them are unaffected."""
+    d = slamx.FeatureDetector(cfg_of(slamx, patch=patch, pairs=pairs, window=6))
+    Pp = oracle.det_params(d.cfg)
+    img = synth(slamx, 6, 240, 320, 1000, rmin=3, rmax=16)
+    good = oracle.detect(img, Pp)[:200]
+    wild = [3.0e9, -3.0e9, 2147483520.0, 2147483648.0, -2147483648.0, 4294967296.0, 1.0e30, -1.0e30, np.inf, -np.inf,
+            np.nan, 2147483648.0 - 15 * 128, 65536.0, 1048577.0, -1.0, -16.0]
+    kps = np.zeros(len(good) + 3 * len(wild), slamx.KEYPOINT_DTYPE)
+    kps["size"] = 6.0
+    kps["angle"] = 77.0
+    is_wild = np.zeros(len(kps), bool)
+    assert len(good) >= 150
+    for j, w in enumerate(wild):  # wild x, wild y, both -- spread between the ordinary keypoints
+        for k, (x, y) in enumerate(((w, 100.0), (100.0, w), (w, w))):
+            i = 4 * (3 * j + k) + 1
+            kps[i]["x"], kps[i]["y"] = x, y
+            is_wild[i] = True
+    kps[~is_wild] = good[: (~is_wild).sum()]
+    k_got, d_got = d.compute(img, kps)
+    assert (k_got["angle"][is_wild] == 0.0).all()
+    assert not d_got[is_wild].any()
+    k_ref, d_ref = oracle.compute(img, kps[~is_wild], Pp)
+    assert_records_equal(k_got[~is_wild], k_ref, "ordinary keypoints between wild ones")
+    assert np.array_equal(d_got[~is_wild], d_ref)
+
+
 @pytest.mark.parametrize("patch,pairs", [(31, 256), (15, 64), (7, 8), (51, 512), (31, 1024), (101, 256)])
 def test_compute_other_patterns(slamx, oracle, patch, pairs):
     d = slamx.FeatureDetector(cfg_of(slamx, patch=patch, pairs=pairs, window=6))
@@ -330,7 +381,9 @@ def test_match_shipped_config(slamx, oracle, kitti_pair, ref_data):
     assert len(got) <= 20
 
 
-@pytest.mark.parametrize("width", [1, 3, 8, 16, 32, 33, 64])
+# widths 20, 28, 36..60 bytes have 5, 7, 9..15 words: the kernel is instantiated for 6, 8 and 16
+# and must read the words past the descriptor's own as zero, not from the next descriptor
+@pytest.mark.parametrize("width", [1, 3, 4, 8, 12, 16, 20, 24, 28, 32, 33, 36, 44, 48, 60, 64])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (1, 300), (300, 1), (257, 255), (700, 513)])
 def test_match_random_descriptors(slamx, oracle, width, n1, n2):
     rng = np.random.default_rng(width * 100000 + n1 * 1000 + n2)
