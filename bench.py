@@ -2,7 +2,7 @@
 """bench.py -- throughput of the frontend hot path (detect + describe + match-to-previous) on
 N MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_2k|c2|c3] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_2k|c2|c3|c4] [--batch B]
 
 A "step" is one pass of the hot path over one batch of B synthetic frames that are already
 resident in HBM: FAST detect -> exact std::sort order -> greedy NMS -> blur -> orientation +
@@ -16,6 +16,11 @@ The reference has no feature-count knob, so counts are reached through the synth
 density and SuppressionWindowSize; the realised candidates M / keypoints N are in the JSON.
 Frames per step (512 / 1024 / 256): the sort and the NMS run one workgroup per frame, so a batch
 must be a multiple of the 256 CUs -- and of 2 x 256 where two of them fit a CU -- to keep the chip full.
+
+`c4` = configs[3]: the 500-frame sequence's sliding-window Gauss-Newton (one window of 10 poses x 2048 landmarks
+per frame, J^T J / J^T r and the landmark elimination on the FP64 matrix cores); a step there is one
+Gauss-Newton iteration (linearise + accumulate, solve, back-substitute, apply) over all windows of the
+rank; the cost after the last step is evaluated once at the end of the job, inside the timed region.
 
 Multi-GPU: frames shard embarrassingly (one independent stream per rank, seed + rank), no
 data-path collective; at the end of the timed job every rank triangulates its newest frame pair
@@ -43,6 +48,12 @@ WORKLOADS = {
     "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=256, max_cand=131072, max_kp=16384,
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
 }
+GN_WORKLOAD = dict(windows=500, cams=10, landmarks=2048, lam=1e-4, n_fixed=2,
+                   desc="500-frame sequence, one sliding window per frame: 10 poses x 2048 landmarks, one Gauss-Newton "
+                        "iteration per step (J^T J / J^T r + landmark elimination on FP64 MFMA, reduced solve, back-substitution)")
+# FP64 matrix peak of MI355X: 78.6 TFLOP/s (AMD spec; v_mfma_f64_16x16x4_f64 = 2048 flop in 64 cycles per
+# SIMD at 2.4 GHz on 1024 SIMDs = 78.6; tools/microbench/mfma_f64_peak.hip measures the sustained rate)
+MFMA_F64_PEAK_TFLOPS = 78.6
 SEED = 0x5EED0051
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Sustained rate of the Hamming inner loop's instruction mix (v_xor_b32 + v_bcnt_u32_b32 with fused
@@ -198,12 +209,118 @@ def cpu_baseline(mod, wl, frames, budget_s=15.0):
     }
 
 
+def main_gn(args, rank, local_rank, world, dist, torch):
+    """--workload c4: BASELINE.json configs[3].  Windows shard across ranks like frames do (independent
+    windows, no data-path collective); the gather at the end of the job exchanges the optimised poses."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gn_scene
+
+    mod = load_product()
+    g = GN_WORKLOAD
+    nw = args.batch or g["windows"]
+    W, L = g["cams"], g["landmarks"]
+    ctx = mod.Context(local_rank)
+    wins = [gn_scene.make_window(shard_seed(rank) * 1000 + k, W, L) for k in range(nw)]
+    poses0 = np.stack([w["poses0"] for w in wins])
+    for k, w in enumerate(wins):
+        poses0[k, : g["n_fixed"]] = w["poses_gt"][: g["n_fixed"]]  # the held cameras carry the gauge
+    X0 = np.stack([w["X0"] for w in wins])
+    obs = np.stack([w["obs"] for w in wins])
+    Kc = wins[0]["K"]
+    n_obs = int(np.isfinite(obs[..., 0]).sum())
+    gn = mod.GaussNewton(nw, W, L, ctx)
+    gn.upload(poses0, X0, obs)
+
+    def run_steps(n):  # slamx_gn_iterate takes at most 64 iterations per call
+        while n > 0:
+            gn.iterate(Kc, g["lam"], g["n_fixed"], min(n, 64))
+            n -= min(n, 64)
+
+    run_steps(max(args.warmup, 1))
+    ctx.synchronize()
+    _, _, cost_w, status = gn.download()
+    assert not status.any(), "a window's reduced system was not positive definite"
+    K = args.steps
+    gn.set_profiling(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    run_steps(K)  # K steps queued back to back + the cost evaluation after the last one
+    poses, _, cost, status = gn.download()  # end of the job: results leave the device
+    n_gathered = nw
+    if dist is not None:
+        n_gathered = sum(a.shape[0] for a in gather_map_points(dist, poses.reshape(-1, 3), "cuda")) // (W * 4)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms, launches = gn.stage_ms()
+    if rank == 0:
+        n_gpus = world
+        chunks = (L + 3) // 4
+        mfma_flops = 40 * 2048.0 * chunks * nw         # 10 F F^T tiles x 3 + 5 Gram tiles x 2 k-steps per 4 landmarks
+        survey_flops = 360.0 * n_obs                   # SURVEY.md 8d: 2x9 block, J^T J + J^T r per observation
+        acc_s = ms["accumulate"] * 1e-3
+        achieved = mfma_flops / acc_s / 1e12 if acc_s > 0 else 0.0
+        err = float(np.abs(poses - np.stack([w["poses_gt"] for w in wins])).max())
+        out = {
+            "metric": "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X",
+            "value": nw * K * n_gpus / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": g["desc"], "name": "c4", "windows_per_step_per_gpu": nw, "cameras": W, "landmarks": L,
+                       "observations_per_window": n_obs / nw, "lambda": g["lam"], "held_cameras": g["n_fixed"],
+                       "parallelism": "windows sharded across GPUs (dp%d), no data-path collective" % n_gpus},
+            "observations_per_s": float(n_obs) * K * n_gpus / elapsed,
+            "windows_gathered": n_gathered,
+            "stage_ms_per_launch": ms, "launches_timed": launches,
+            "roofline": {"kernel": "gn_accumulate_kernel", "bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F64_PEAK_TFLOPS, "algorithmic_per_launch": mfma_flops,
+                         "survey_flops_per_launch": survey_flops,
+                         "survey_achieved": survey_flops / acc_s / 1e12 if acc_s > 0 else 0.0,
+                         "avg_launch_ms": ms["accumulate"], "traffic": None,
+                         "note": "algorithmic = FP64 MFMA flops the formulation needs (15 accumulator tiles per 4 landmarks); "
+                                 "SURVEY.md 8d's per-observation figure (360 flop) is reported next to it"},
+            "cost_first_step": float(cost_w[:, 0].sum()) if cost_w is not None else None,
+            "cost_now": float(cost[:, -1].sum()), "max_pose_error_vs_generating": err,
+            "device": ctx.device_name,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            import oracle_binding
+
+            o = oracle_binding.load()
+            t1 = time.perf_counter()
+            done = 0
+            while done < nw and time.perf_counter() - t1 < 15.0:
+                w = wins[done]
+                o.gn_step_schur(poses0[done], w["X0"], w["obs"], Kc, g["lam"], g["n_fixed"])
+                done += 1
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d windows of the same workload, one Gauss-Newton step each (CPU restatement "
+                                             "oracle/gn_oracle.cpp:oracle_gn_step_schur, g++ -O3, 1 thread), %.1f s" % (done, dt),
+                                   "host_cpus": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p_2k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="1080p_2k", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-upload-inclusive leg (N == 1 only)")
@@ -223,6 +340,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
     n_gpus = world
+    if args.workload == "c4":
+        return main_gn(args, rank, local_rank, world, dist, torch)
 
     mod = load_product()
     import numpy as np

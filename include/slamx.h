@@ -271,6 +271,43 @@ int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const
 int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
                       float* x4, double* xyz);
 
+/* ---- sliding-window Gauss-Newton (BASELINE.json configs[3]; NO reference counterpart) ----
+ * The reference's backend is declaration-only (include/slam/backend/backend.hpp:10-18,
+ * include/slam/backend/map.hpp:9-21), so there is no interface to mirror: this is the entry point a
+ * Backend::run / Map implementation would call.  A batch of independent windows, each with n_cams
+ * (<= 10) poses (world -> camera, 12 doubles: R row-major, t), up to max_landmarks landmarks and a
+ * dense track table obs[landmark][cam] = (u, v) float pixel coordinates, NaN = not observed.
+ * One iteration = linearise the reprojection error, accumulate J^T J / J^T r and eliminate the
+ * landmarks on the FP64 matrix cores (gn.hip), solve the reduced camera system (6 n_cams unknowns,
+ * the first n_fixed cameras held, lambda added to every diagonal), back-substitute the landmarks,
+ * apply the step (R <- exp(phi^) R, t <- exp(phi^) t + rho, X <- X + dX).  Device-resident between
+ * calls; results are run-to-run identical (no atomics). */
+typedef struct slamx_gn slamx_gn;
+#define SLAMX_GN_MAX_CAMS 10
+#define SLAMX_GN_MAX_ITERATIONS 64
+int slamx_gn_create(slamx_ctx* ctx, int n_windows, int n_cams, int max_landmarks, slamx_gn** out);
+void slamx_gn_destroy(slamx_gn* gn);
+/* poses [n_windows][n_cams][12], landmarks [n_windows][max_landmarks][3],
+ * obs [n_windows][max_landmarks][n_cams][2], n_landmarks [n_windows] or NULL (= max_landmarks). */
+int slamx_gn_upload(slamx_gn* gn, const double* poses, const double* landmarks, const float* obs,
+                    const int32_t* n_landmarks);
+/* Enqueue `iterations` (0..64) steps plus a final cost evaluation; K = fx fy cx cy. */
+int slamx_gn_iterate(slamx_gn* gn, const double* K, double lambda, int n_fixed, int iterations);
+/* Any pointer may be NULL.  cost [n_windows][iterations + 1] of the last slamx_gn_iterate call
+ * (sum of squared residuals before every step and after the last); status [n_windows]: bit 0 =
+ * some step was skipped because the reduced system was not positive definite. */
+int slamx_gn_download(slamx_gn* gn, double* poses, double* landmarks, double* cost, int32_t* status);
+/* Per-kernel device time of the iterations enqueued since profiling was switched on: hipEvent pairs on the
+ * context stream around every launch.  avg_ms[3] = accumulate, solve, back-substitution; launches[3]
+ * (optional) = how many launches each average covers. */
+int slamx_gn_set_profiling(slamx_gn* gn, int on);
+int slamx_gn_stage_ms(slamx_gn* gn, float* avg_ms, int32_t* launches);
+/* Linearise at the current state WITHOUT stepping: S [n_windows][6 n_cams][6 n_cams], g and delta
+ * [n_windows][6 n_cams] (S delta = g), cost [n_windows].  For parity tests and callers that run
+ * their own step control. */
+int slamx_gn_normal_equations(slamx_gn* gn, const double* K, double lambda, int n_fixed, double* S, double* g,
+                              double* delta, double* cost);
+
 /* ---- slam::Camera (include/slam/common/common.hpp:67-190) ---- */
 typedef struct slamx_camera {
     double fx, fy, cx, cy;     /* K(0,0), K(1,1), K(0,2), K(1,2)                           */

@@ -98,6 +98,8 @@ EXPORTS = [
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
+    "slamx_gn_create", "slamx_gn_destroy", "slamx_gn_upload", "slamx_gn_iterate", "slamx_gn_download",
+    "slamx_gn_normal_equations", "slamx_gn_set_profiling", "slamx_gn_stage_ms",
 ]
 
 _lib = None
@@ -170,6 +172,15 @@ def load_library():
     lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.slamx_camera_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(Camera)]
     lib.slamx_undistort.argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_ssize_t, vp]
+    lib.slamx_gn_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.slamx_gn_destroy.argtypes = [vp]
+    lib.slamx_gn_destroy.restype = None
+    lib.slamx_gn_upload.argtypes = [vp, vp, vp, vp, vp]
+    lib.slamx_gn_iterate.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int]
+    lib.slamx_gn_download.argtypes = [vp, vp, vp, vp, vp]
+    lib.slamx_gn_set_profiling.argtypes = [vp, C.c_int]
+    lib.slamx_gn_stage_ms.argtypes = [vp, vp, vp]
+    lib.slamx_gn_normal_equations.argtypes = [vp, vp, C.c_double, C.c_int, vp, vp, vp, vp]
     lib.slamx_synth_frame.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     _lib = lib
     return lib
@@ -666,3 +677,72 @@ class Batch:
         ms = (C.c_float * len(STAGES))()
         _check(self.lib.slamx_batch_stage_ms(self.h, set_index, ms))
         return dict(zip(STAGES, [float(x) for x in ms]))
+
+
+class GaussNewton:
+    """A batch of sliding windows for slamx_gn_* (include/slamx.h): n_cams poses (world -> camera, R
+    row-major + t), up to max_landmarks landmarks and a dense track table per window.  Build-defined
+    (BASELINE.json configs[3]); the reference's backend is declaration-only."""
+
+    def __init__(self, n_windows, n_cams, max_landmarks, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.n_windows, self.n_cams, self.max_landmarks = n_windows, n_cams, max_landmarks
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_gn_create(self.ctx.h, n_windows, n_cams, max_landmarks, C.byref(self.h)))
+        self.iterations = -1
+        self.ctx._children.add(self)  # destroyed before the context (its stream is synchronised on destroy)
+
+    def close(self):
+        if self.h:
+            self.lib.slamx_gn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, poses, landmarks, obs, n_landmarks=None):
+        W, L, n = self.n_cams, self.max_landmarks, self.n_windows
+        poses = np.ascontiguousarray(poses, np.float64).reshape(n, W, 12)
+        landmarks = np.ascontiguousarray(landmarks, np.float64).reshape(n, L, 3)
+        obs = np.ascontiguousarray(obs, np.float32).reshape(n, L, W, 2)
+        nl = None if n_landmarks is None else np.ascontiguousarray(n_landmarks, np.int32).reshape(n)
+        _check(self.lib.slamx_gn_upload(self.h, _ptr(poses), _ptr(landmarks), _ptr(obs), _ptr(nl)))
+        self.iterations = -1
+
+    def iterate(self, K, lam, n_fixed, iterations):
+        k4 = np.ascontiguousarray(K, np.float64).reshape(4)
+        _check(self.lib.slamx_gn_iterate(self.h, _ptr(k4), float(lam), n_fixed, iterations))
+        self.iterations = iterations
+
+    def download(self):
+        """-> poses [n][W][12], landmarks [n][L][3], cost [n][iterations + 1] (or None), status [n]"""
+        n = self.n_windows
+        poses = np.empty((n, self.n_cams, 12))
+        lm = np.empty((n, self.max_landmarks, 3))
+        cost = np.empty((n, self.iterations + 1)) if self.iterations >= 0 else None
+        status = np.empty(n, np.int32)
+        _check(self.lib.slamx_gn_download(self.h, _ptr(poses), _ptr(lm), _ptr(cost), _ptr(status)))
+        return poses, lm, cost, status
+
+    def set_profiling(self, on=True):
+        _check(self.lib.slamx_gn_set_profiling(self.h, 1 if on else 0))
+
+    def stage_ms(self):
+        """-> ({"accumulate": ms, "solve": ms, "backsub": ms}, launches per stage)"""
+        ms = np.zeros(3, np.float32)
+        n = np.zeros(3, np.int32)
+        _check(self.lib.slamx_gn_stage_ms(self.h, _ptr(ms), _ptr(n)))
+        names = ("accumulate", "solve", "backsub")
+        return dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n]))
+
+    def normal_equations(self, K, lam, n_fixed):
+        """Linearise at the current state without stepping -> S [n][6W][6W], g, delta [n][6W], cost [n]"""
+        n, m = self.n_windows, 6 * self.n_cams
+        k4 = np.ascontiguousarray(K, np.float64).reshape(4)
+        S, g, d, c = np.empty((n, m, m)), np.empty((n, m)), np.empty((n, m)), np.empty(n)
+        _check(self.lib.slamx_gn_normal_equations(self.h, _ptr(k4), float(lam), n_fixed, _ptr(S), _ptr(g), _ptr(d), _ptr(c)))
+        return S, g, d, c

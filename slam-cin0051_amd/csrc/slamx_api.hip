@@ -1745,6 +1745,306 @@ int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const 
     return SLAMX_OK;
 }
 
+// ------------------------------------------------------------------ sliding-window Gauss-Newton (gn.hip)
+}  // extern "C"
+
+struct slamx_gn {
+    slamx_ctx* ctx = nullptr;
+    int n_windows = 0, n_cams = 0, max_landmarks = 0, nslices = 1;
+    double* poses[2] = {nullptr, nullptr};  // [cur] = linearisation point, the other receives the step
+    int cur = 0;
+    double* landmarks = nullptr;
+    float* obs = nullptr;
+    int* n_landmarks = nullptr;
+    double* partial = nullptr;
+    double* delta = nullptr;
+    double* cost = nullptr;  // [SLAMX_GN_MAX_ITERATIONS + 1][n_windows]
+    int* status = nullptr;
+    int last_iterations = -1;
+    // profiling: event pairs around every kernel of the iterations since it was switched on
+    // (stage 0 accumulate, 1 solve, 2 back-substitution), on the context stream
+    bool profiling = false;
+    std::vector<hipEvent_t> ev[3];
+    size_t ev_used[3] = {0, 0, 0};
+};
+
+namespace {
+
+// record the next unused event of a stage (grown on demand); pairs are (2k, 2k + 1)
+void gn_mark(slamx_gn* g, int stage) {
+    if (!g->profiling) {
+        return;
+    }
+    if (g->ev_used[stage] == g->ev[stage].size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) {
+            return;
+        }
+        g->ev[stage].push_back(e);
+    }
+    (void)hipEventRecord(g->ev[stage][g->ev_used[stage]++], g->ctx->stream);
+}
+
+GnLaunch gn_launch_of(const slamx_gn* g, const double* K, double lambda, int n_fixed, int cost_slot) {
+    GnLaunch a{};
+    a.poses = g->poses[g->cur];
+    a.landmarks = g->landmarks;
+    a.obs = g->obs;
+    a.n_landmarks = g->n_landmarks;
+    a.partial = g->partial;
+    a.delta = g->delta;
+    a.cost = g->cost + static_cast<size_t>(cost_slot) * g->n_windows;
+    a.status = g->status;
+    a.n_windows = g->n_windows;
+    a.n_cams = g->n_cams;
+    a.max_landmarks = g->max_landmarks;
+    a.nslices = g->nslices;
+    a.n_fixed = n_fixed;
+    for (int k = 0; k < 4; ++k) {
+        a.K[k] = K[k];
+    }
+    a.lambda = lambda;
+    return a;
+}
+
+int gn_check_step_args(const slamx_gn* g, const double* K, double lambda, int n_fixed) {
+    if (g == nullptr || K == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    if (!(lambda >= 0.0) || n_fixed < 0 || n_fixed > g->n_cams) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: lambda must be >= 0 and 0 <= n_fixed <= n_cams");
+    }
+    if (!(K[0] > 0.0) || !(K[1] > 0.0)) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: focal lengths must be positive");
+    }
+    return SLAMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slamx_gn_create(slamx_ctx* ctx, int n_windows, int n_cams, int max_landmarks, slamx_gn** out) {
+    if (ctx == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    *out = nullptr;
+    if (n_windows <= 0 || n_cams < 1 || n_cams > SLAMX_GN_MAX_CAMS || max_landmarks <= 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: need n_windows > 0, 1 <= n_cams <= 10, max_landmarks > 0");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto* g = new slamx_gn();
+    g->ctx = ctx;
+    g->n_windows = n_windows;
+    g->n_cams = n_cams;
+    g->max_landmarks = max_landmarks;
+    // waves per window: all of them resident at once (1024 SIMDs x 2 waves of 250 registers) or a whole
+    // number of such rounds; never more than there are chunks
+    const int chunks = (max_landmarks + 3) / 4;
+    int slices = 4096 / n_windows;
+    slices = std::max(1, std::min(std::min(slices, 32), chunks));
+    g->nslices = slices;
+    const size_t nw = static_cast<size_t>(n_windows);
+    int rc = dev_alloc(&g->poses[0], nw * n_cams * 12);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->poses[1], nw * n_cams * 12);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->landmarks, nw * max_landmarks * 3);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->obs, nw * max_landmarks * n_cams * 2);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->n_landmarks, nw);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->partial, nw * slices * 15 * 256);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->delta, nw * 64);
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->cost, nw * (SLAMX_GN_MAX_ITERATIONS + 1));
+    if (rc == SLAMX_OK) rc = dev_alloc(&g->status, nw);
+    if (rc != SLAMX_OK) {
+        slamx_gn_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return SLAMX_OK;
+}
+
+void slamx_gn_destroy(slamx_gn* g) {
+    if (g == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    dev_free(g->poses[0]);
+    dev_free(g->poses[1]);
+    dev_free(g->landmarks);
+    dev_free(g->obs);
+    dev_free(g->n_landmarks);
+    dev_free(g->partial);
+    dev_free(g->delta);
+    dev_free(g->cost);
+    dev_free(g->status);
+    for (auto& v : g->ev) {
+        for (hipEvent_t e : v) {
+            (void)hipEventDestroy(e);
+        }
+    }
+    delete g;
+}
+
+int slamx_gn_set_profiling(slamx_gn* g, int on) {
+    if (g == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    g->profiling = on != 0;
+    for (auto& u : g->ev_used) {
+        u = 0;
+    }
+    return SLAMX_OK;
+}
+
+int slamx_gn_stage_ms(slamx_gn* g, float* avg_ms, int32_t* launches) {
+    if (g == nullptr || avg_ms == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    for (int st = 0; st < 3; ++st) {
+        double sum = 0.0;
+        int n = 0;
+        for (size_t k = 0; k + 1 < g->ev_used[st]; k += 2) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, g->ev[st][k], g->ev[st][k + 1]) == hipSuccess) {
+                sum += t;
+                ++n;
+            }
+        }
+        avg_ms[st] = n > 0 ? static_cast<float>(sum / n) : 0.0f;
+        if (launches != nullptr) {
+            launches[st] = n;
+        }
+    }
+    return SLAMX_OK;
+}
+
+int slamx_gn_upload(slamx_gn* g, const double* poses, const double* landmarks, const float* obs,
+                    const int32_t* n_landmarks) {
+    if (g == nullptr || poses == nullptr || landmarks == nullptr || obs == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    const size_t nw = static_cast<size_t>(g->n_windows);
+    std::vector<int> nl(nw, g->max_landmarks);
+    if (n_landmarks != nullptr) {
+        for (size_t w = 0; w < nw; ++w) {
+            if (n_landmarks[w] < 0 || n_landmarks[w] > g->max_landmarks) {
+                return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: n_landmarks out of range");
+            }
+            nl[w] = n_landmarks[w];
+        }
+    }
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    g->cur = 0;
+    HIP_TRY(hipMemcpyAsync(g->poses[0], poses, nw * g->n_cams * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->landmarks, landmarks, nw * g->max_landmarks * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->obs, obs, nw * g->max_landmarks * g->n_cams * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->n_landmarks, nl.data(), nw * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(g->status, 0, nw * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));  // pageable sources: the caller may reuse them on return
+    g->last_iterations = -1;
+    return SLAMX_OK;
+}
+
+int slamx_gn_iterate(slamx_gn* g, const double* K, double lambda, int n_fixed, int iterations) {
+    SLAMX_TRY(gn_check_step_args(g, K, lambda, n_fixed));
+    if (iterations < 0 || iterations > SLAMX_GN_MAX_ITERATIONS) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: iterations must be in [0, 64]");
+    }
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    for (int it = 0; it <= iterations; ++it) {
+        const GnLaunch a = gn_launch_of(g, K, lambda, n_fixed, it);
+        gn_mark(g, 0);
+        launch_gn_accumulate(a, s);
+        gn_mark(g, 0);
+        const bool last = it == iterations;  // the final pass only evaluates the cost
+        gn_mark(g, 1);
+        launch_gn_solve(a, g->poses[g->cur ^ 1], last ? 1 : 0, nullptr, nullptr, s);
+        gn_mark(g, 1);
+        if (!last) {
+            gn_mark(g, 2);
+            launch_gn_backsub(a, s);
+            gn_mark(g, 2);
+            g->cur ^= 1;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    g->last_iterations = iterations;
+    return SLAMX_OK;
+}
+
+int slamx_gn_download(slamx_gn* g, double* poses, double* landmarks, double* cost, int32_t* status) {
+    if (g == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
+    }
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    const size_t nw = static_cast<size_t>(g->n_windows);
+    HIP_TRY(hipStreamSynchronize(s));
+    if (poses != nullptr) {
+        HIP_TRY(hipMemcpy(poses, g->poses[g->cur], nw * g->n_cams * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (landmarks != nullptr) {
+        HIP_TRY(hipMemcpy(landmarks, g->landmarks, nw * g->max_landmarks * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (cost != nullptr) {
+        if (g->last_iterations < 0) {
+            return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: no slamx_gn_iterate call to report costs of");
+        }
+        // device layout [iteration][window] -> caller layout [window][iteration]
+        const int ni = g->last_iterations + 1;
+        std::vector<double> tmp(nw * ni);
+        HIP_TRY(hipMemcpy(tmp.data(), g->cost, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < nw; ++w) {
+            for (int i = 0; i < ni; ++i) {
+                cost[w * ni + i] = tmp[static_cast<size_t>(i) * nw + w];
+            }
+        }
+    }
+    if (status != nullptr) {
+        HIP_TRY(hipMemcpy(status, g->status, nw * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return SLAMX_OK;
+}
+
+int slamx_gn_normal_equations(slamx_gn* g, const double* K, double lambda, int n_fixed, double* S, double* gvec,
+                              double* delta, double* cost) {
+    SLAMX_TRY(gn_check_step_args(g, K, lambda, n_fixed));
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    const size_t nw = static_cast<size_t>(g->n_windows);
+    const size_t n = static_cast<size_t>(6) * g->n_cams;
+    DevBuf dS, dg;
+    HIP_TRY(dS.alloc(nw * n * n * sizeof(double)));
+    HIP_TRY(dg.alloc(nw * n * sizeof(double)));
+    // slot SLAMX_GN_MAX_ITERATIONS of the cost array is scratch here; the stepped poses go to the spare buffer
+    const GnLaunch a = gn_launch_of(g, K, lambda, n_fixed, SLAMX_GN_MAX_ITERATIONS);
+    launch_gn_accumulate(a, s);
+    launch_gn_solve(a, g->poses[g->cur ^ 1], 0, dS.as<double>(), dg.as<double>(), s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    if (S != nullptr) {
+        HIP_TRY(hipMemcpy(S, dS.p, nw * n * n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (gvec != nullptr) {
+        HIP_TRY(hipMemcpy(gvec, dg.p, nw * n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (delta != nullptr) {
+        std::vector<double> d64(nw * 64);
+        HIP_TRY(hipMemcpy(d64.data(), g->delta, d64.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < nw; ++w) {
+            std::memcpy(delta + w * n, d64.data() + w * 64, n * sizeof(double));
+        }
+    }
+    if (cost != nullptr) {
+        HIP_TRY(hipMemcpy(cost, a.cost, nw * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SLAMX_OK;
+}
+
 // ------------------------------------------------------------------ camera
 int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out) {
     YamlFile y;

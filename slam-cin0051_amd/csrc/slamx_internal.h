@@ -219,6 +219,25 @@ void launch_sampson(const double* x1, const double* x2, int n, const double* E, 
 void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
                         double* xyz, hipStream_t stream);
 
+// sliding-window Gauss-Newton (gn.hip): device pointers of a batch of windows
+struct GnLaunch {
+    const double* poses;     // [n_windows][n_cams][12]  linearisation point
+    double* landmarks;       // [n_windows][max_landmarks][3]  updated in place by the back-substitution
+    const float* obs;        // [n_windows][max_landmarks][n_cams][2]
+    const int* n_landmarks;  // [n_windows]
+    double* partial;         // [n_windows][nslices][15][256]  per-wave accumulator tiles
+    double* delta;           // [n_windows][64]  camera step
+    double* cost;            // [n_windows]
+    int* status;             // [n_windows]
+    int n_windows, n_cams, max_landmarks, nslices, n_fixed;
+    double K[4];             // fx fy cx cy
+    double lambda;
+};
+void launch_gn_accumulate(const GnLaunch& a, hipStream_t stream);
+// writes delta, cost, status and (unless cost_only) the stepped poses into poses_next
+void launch_gn_solve(const GnLaunch& a, double* poses_next, int cost_only, double* S_out, double* g_out, hipStream_t stream);
+void launch_gn_backsub(const GnLaunch& a, hipStream_t stream);
+
 void launch_undistort(const uint8_t* img, int rows, int cols, int pitch, const slamx_camera& cam, double* out,
                       hipStream_t stream);
 

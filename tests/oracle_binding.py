@@ -203,6 +203,57 @@ class Oracle:
         self.lib.oracle_sort_desc(_p(s), s.shape[0], _p(perm))
         return perm
 
+    # ---- sliding-window Gauss-Newton (oracle/gn_oracle.cpp; build-defined problem, no reference counterpart)
+    def gn_step_dense(self, poses, X, obs, K, lam, n_fixed):
+        """One window, full dense normal equations -> dict(delta_c [W,6], delta_x [L,3], cost, S, g, active, rc)"""
+        poses = np.ascontiguousarray(poses, np.float64)
+        X = np.ascontiguousarray(X, np.float64)
+        obs = np.ascontiguousarray(obs, np.float32)
+        W, L = poses.shape[0], X.shape[0]
+        assert obs.shape == (L, W, 2)
+        k4 = np.ascontiguousarray(K, np.float64)
+        dc, dx = np.zeros((W, 6)), np.zeros((L, 3))
+        S, g = np.zeros((6 * W, 6 * W)), np.zeros(6 * W)
+        act = np.zeros(L, np.uint8)
+        cost = C.c_double()
+        fn = self.lib.oracle_gn_step_dense
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
+                       C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = fn(_p(poses), _p(X), _p(obs), W, L, _p(k4), float(lam), n_fixed, _p(dc), _p(dx), C.byref(cost), _p(S), _p(g), _p(act))
+        return dict(delta_c=dc, delta_x=dx, cost=cost.value, S=S, g=g, active=act, rc=rc)
+
+    def gn_apply(self, poses, X, delta_c, delta_x):
+        poses = np.array(poses, np.float64, order="C")
+        X = np.array(X, np.float64, order="C")
+        dc = np.ascontiguousarray(delta_c, np.float64)
+        dx = np.ascontiguousarray(delta_x, np.float64)
+        self.lib.oracle_gn_apply.restype = None
+        self.lib.oracle_gn_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.oracle_gn_apply(_p(poses), _p(X), poses.shape[0], X.shape[0], _p(dc), _p(dx))
+        return poses, X
+
+    def gn_cost(self, poses, X, obs, K, lam=0.0):
+        poses = np.ascontiguousarray(poses, np.float64)
+        X = np.ascontiguousarray(X, np.float64)
+        obs = np.ascontiguousarray(obs, np.float32)
+        k4 = np.ascontiguousarray(K, np.float64)
+        self.lib.oracle_gn_cost.restype = C.c_double
+        self.lib.oracle_gn_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]
+        return self.lib.oracle_gn_cost(_p(poses), _p(X), _p(obs), poses.shape[0], X.shape[0], _p(k4), float(lam))
+
+    def gn_step_schur(self, poses, X, obs, K, lam, n_fixed):
+        """One window, eliminated the way a CPU bundle adjuster does; returns (cost before, poses, X)."""
+        poses = np.array(poses, np.float64, order="C")
+        X = np.array(X, np.float64, order="C")
+        obs = np.ascontiguousarray(obs, np.float32)
+        k4 = np.ascontiguousarray(K, np.float64)
+        fn = self.lib.oracle_gn_step_schur
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int]
+        c = fn(_p(poses), _p(X), _p(obs), poses.shape[0], X.shape[0], _p(k4), float(lam), n_fixed)
+        return c, poses, X
+
 
 _cached = None
 
