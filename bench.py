@@ -47,6 +47,12 @@ WORKLOADS = {
                desc="640x480, ~2k keypoints/frame (SuppressionWindowSize 6), detect+describe+match-to-previous"),
     "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=256, max_cand=131072, max_kp=16384,
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
+    # configs[2] as BASELINE.json words it: "1920x1080 8-level pyramid, 10k feats/frame" -- the pyramid is a build-side
+    # extension (the reference has none), levels >= 1 are parity-unpinned; reported separately from c3
+    "c3p": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=256, max_cand=32768, max_kp=16384,
+                levels=8, scale=1.2,
+                desc="1920x1080, 8-level pyramid (scale 1.2), ~12k keypoints/frame over all levels (the default workload's frames, "
+                     "shipped YAML), detect+describe on every level + match-to-previous on the merged sets"),
 }
 GN_WORKLOAD = dict(windows=500, cams=10, landmarks=2048, lam=1e-4, n_fixed=2,
                    desc="500-frame sequence, one sliding window per frame: 10 poses x 2048 landmarks, one Gauss-Newton "
@@ -188,14 +194,20 @@ def cpu_baseline(mod, wl, frames, budget_s=15.0):
     o = oracle_binding.load()
     P = oracle_binding.DetectorParams(20, 12, 1, wl["window"], 31, 256)
     M = oracle_binding.MatcherParams(0, 20, 1, 0.5)
+    def dac(img):
+        if "levels" in wl:
+            return o.pyramid_detect_and_compute(img, P, wl["levels"], wl["scale"])
+        return o.detect_and_compute(img, P)
+
     t0 = time.perf_counter()
-    prev = o.detect_and_compute(frames[-1], P)  # predecessor of frame 0, not counted
+    prev = dac(frames[-1])  # predecessor of frame 0, not counted
+    o.match(prev[1], prev[1], prev[0], prev[0], M)  # (sizes the sample: matching is O(N^2) and dominates at 10k keypoints)
     t_first = time.perf_counter() - t0
     n = int(max(2, min(len(frames), budget_s / max(t_first, 1e-3))))
     t0 = time.perf_counter()
     kps_total = 0
     for k in range(n):
-        cur = o.detect_and_compute(frames[k], P)
+        cur = dac(frames[k])
         o.match(cur[1], prev[1], cur[0], prev[0], M)
         kps_total += len(cur[0])
         prev = cur
@@ -353,12 +365,20 @@ def main():
     matcher = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx)  # FilterMatches 0
     seed = shard_seed(rank)
     frames = np.stack([mod.synth_frame(seed, k, wl["rows"], wl["cols"], wl["n_rect"], wl["rmin"], wl["rmax"]) for k in range(B)])
-    batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
+    pyr = None
+    if "levels" in wl:
+        pyr = mod.Pyramid(det, wl["rows"], wl["cols"], B, wl["levels"], wl["scale"], wl["max_cand"], wl["max_kp"])
+        batch = pyr.level(0)  # frames in, merged results out
+    else:
+        batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
     batch.upload(frames)
     ctx.synchronize()
 
     def step():
-        batch.detect_and_compute(B)
+        if pyr is not None:
+            pyr.detect_and_compute(B)
+        else:
+            batch.detect_and_compute(B)
         batch.match_consecutive(matcher, B, use_keypoints=not args.no_keypoints, first_train_frame=B - 1)
 
     for _ in range(args.warmup):
@@ -486,7 +506,11 @@ def main():
                              "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
             "device": ctx.device_name,
         }
-        if n_gpus == 1 and not args.no_pcie:
+        if pyr is not None:
+            out["config"]["pyramid"] = {"levels": wl["levels"], "scale_factor": wl["scale"], "level_shapes": pyr.shapes,
+                                        "note": "stage_ms_per_step / roofline are level 0's kernels only (candidates_per_frame too); "
+                                                "keypoints_per_frame and the matcher cover all levels"}
+        if n_gpus == 1 and not args.no_pcie and pyr is None:
             batch.set_profiling(0, 1)
             out["pcie_inclusive"] = pcie_inclusive(mod, wl, B, frames, (ctx, batch, matcher), local_rank,
                                                    not args.no_keypoints)

@@ -271,6 +271,27 @@ int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const
 int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
                       float* x4, double* xyz);
 
+/* ---- image pyramid (BASELINE.json north_star / configs[2]; NO reference counterpart) ----
+ * The reference detects on the full-resolution image only (feature_detector.cpp:8-18, Keypoint::size
+ * is the constant 6.0, feature_detector.hpp:18,35).  A pyramid is a stack of batches: level 0 has the
+ * caller's shape, level l is cvRound(size / scale_factor^l) (sizes computed in double as ORB-style
+ * pyramids do) and is an integer bilinear downscale of level l-1 (pyramid.hip).
+ * slamx_pyramid_detect_and_compute builds the levels from the frames in level 0, runs the unchanged
+ * detector on every level and appends the results of levels >= 1 to level 0's arrays, level after
+ * level: x, y and size multiplied by float(scale_factor^l), angle / response / descriptor as they
+ * are.  Frames go in and merged results come out through the level-0 batch (slamx_pyramid_batch(p, 0)
+ * with slamx_batch_upload / _match_consecutive / _counts / _download); shape.max_keypoints is the
+ * merged capacity; shape.max_candidates applies to every level (downscaled levels hold about as many raw
+ * corners as level 0). */
+typedef struct slamx_pyramid slamx_pyramid;
+#define SLAMX_PYRAMID_MAX_LEVELS 16
+int slamx_pyramid_create(slamx_detector* det, const slamx_batch_shape* shape, int n_levels, double scale_factor,
+                         slamx_pyramid** out);
+void slamx_pyramid_destroy(slamx_pyramid* p);
+slamx_batch* slamx_pyramid_batch(slamx_pyramid* p, int level);
+int slamx_pyramid_level_shape(const slamx_pyramid* p, int level, int* rows, int* cols, double* scale);
+int slamx_pyramid_detect_and_compute(slamx_pyramid* p, int nframes);
+
 /* ---- sliding-window Gauss-Newton (BASELINE.json configs[3]; NO reference counterpart) ----
  * The reference's backend is declaration-only (include/slam/backend/backend.hpp:10-18,
  * include/slam/backend/map.hpp:9-21), so there is no interface to mirror: this is the entry point a

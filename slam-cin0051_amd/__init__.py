@@ -98,6 +98,8 @@ EXPORTS = [
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
+    "slamx_pyramid_create", "slamx_pyramid_destroy", "slamx_pyramid_batch", "slamx_pyramid_level_shape",
+    "slamx_pyramid_detect_and_compute",
     "slamx_gn_create", "slamx_gn_destroy", "slamx_gn_upload", "slamx_gn_iterate", "slamx_gn_download",
     "slamx_gn_normal_equations", "slamx_gn_set_profiling", "slamx_gn_stage_ms",
 ]
@@ -172,6 +174,13 @@ def load_library():
     lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.slamx_camera_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(Camera)]
     lib.slamx_undistort.argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_ssize_t, vp]
+    lib.slamx_pyramid_create.argtypes = [vp, C.POINTER(BatchShape), C.c_int, C.c_double, C.POINTER(vp)]
+    lib.slamx_pyramid_destroy.argtypes = [vp]
+    lib.slamx_pyramid_destroy.restype = None
+    lib.slamx_pyramid_batch.argtypes = [vp, C.c_int]
+    lib.slamx_pyramid_batch.restype = vp
+    lib.slamx_pyramid_level_shape.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    lib.slamx_pyramid_detect_and_compute.argtypes = [vp, C.c_int]
     lib.slamx_gn_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.slamx_gn_destroy.argtypes = [vp]
     lib.slamx_gn_destroy.restype = None
@@ -677,6 +686,59 @@ class Batch:
         ms = (C.c_float * len(STAGES))()
         _check(self.lib.slamx_batch_stage_ms(self.h, set_index, ms))
         return dict(zip(STAGES, [float(x) for x in ms]))
+
+
+class _BorrowedBatch(Batch):
+    """A level of a Pyramid: the handle belongs to the pyramid, so close() only forgets it."""
+
+    def __init__(self, detector, handle, rows, cols, max_frames):
+        self.det = detector
+        self.lib = detector.lib
+        self.h = C.c_void_p(handle)
+        self.rows, self.cols, self.max_frames = rows, cols, max_frames
+
+    def close(self):
+        self.h = C.c_void_p()
+
+
+class Pyramid:
+    """slamx_pyramid_* (include/slamx.h): n_levels batches, level l = cvRound(size / scale_factor ** l).
+    Frames go into level(0) (upload), merged results come out of it (counts / download /
+    match_consecutive / download_matches).  Build-side extension: the reference has no pyramid."""
+
+    def __init__(self, detector, rows, cols, max_frames, n_levels=8, scale_factor=1.2, max_candidates=0, max_keypoints=0):
+        self.det = detector
+        self.lib = detector.lib
+        shape = BatchShape(rows, cols, max_frames, max_candidates, max_keypoints)
+        self.h = C.c_void_p()
+        _check(self.lib.slamx_pyramid_create(detector.h, C.byref(shape), n_levels, float(scale_factor), C.byref(self.h)))
+        self.n_levels, self.max_frames = n_levels, max_frames
+        self._levels = []
+        for l in range(n_levels):
+            r, c, s = C.c_int(), C.c_int(), C.c_double()
+            _check(self.lib.slamx_pyramid_level_shape(self.h, l, C.byref(r), C.byref(c), C.byref(s)))
+            self._levels.append(_BorrowedBatch(detector, self.lib.slamx_pyramid_batch(self.h, l), r.value, c.value, max_frames))
+        self.shapes = [(b.rows, b.cols) for b in self._levels]
+        detector._children.add(self)
+
+    def close(self):
+        if self.h:
+            for b in self._levels:
+                b.close()
+            self.lib.slamx_pyramid_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level(self, l):
+        return self._levels[l]
+
+    def detect_and_compute(self, nframes):
+        _check(self.lib.slamx_pyramid_detect_and_compute(self.h, nframes))
 
 
 class GaussNewton:

@@ -1745,6 +1745,176 @@ int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const 
     return SLAMX_OK;
 }
 
+// ------------------------------------------------------------------ image pyramid (pyramid.hip)
+}  // extern "C"
+
+struct slamx_pyramid {
+    slamx_detector* det = nullptr;
+    std::vector<slamx_batch*> levels;
+    std::vector<double> scale;         // scale_factor^l
+    std::vector<uint32_t*> xtab, ytab;  // per level >= 1: source index | weight << 16 per destination column / row
+};
+
+namespace {
+
+// centre-aligned source position of destination index d: ((2d + 1) Ws - Wd) / (2 Wd), as index + 11-bit weight
+std::vector<uint32_t> scale_table(int dst, int src) {
+    std::vector<uint32_t> t(static_cast<size_t>(dst));
+    for (int d = 0; d < dst; ++d) {
+        const long long num = (2LL * d + 1) * src - dst;
+        const long long den = 2LL * dst;
+        long long i0 = 0, f = 0;
+        if (num > 0) {
+            i0 = num / den;
+            f = ((num % den) * 2048) / den;
+        }
+        if (i0 >= src - 1) {
+            i0 = src - 1;
+            f = 0;
+        }
+        t[static_cast<size_t>(d)] = static_cast<uint32_t>(i0) | (static_cast<uint32_t>(f) << 16);
+    }
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slamx_pyramid_create(slamx_detector* det, const slamx_batch_shape* shape, int n_levels, double scale_factor,
+                         slamx_pyramid** out) {
+    if (det == nullptr || shape == nullptr || out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    *out = nullptr;
+    if (n_levels < 1 || n_levels > SLAMX_PYRAMID_MAX_LEVELS || !(scale_factor > 1.0) || !(scale_factor <= 4.0)) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: 1 <= n_levels <= 16 and 1 < scale_factor <= 4");
+    }
+    auto* p = new slamx_pyramid();
+    p->det = det;
+    const double px0 = static_cast<double>(shape->rows) * shape->cols;
+    for (int l = 0; l < n_levels; ++l) {
+        const double sc = std::pow(scale_factor, l);
+        slamx_batch_shape sh = *shape;
+        sh.rows = static_cast<int>(std::lrint(shape->rows / sc));
+        sh.cols = static_cast<int>(std::lrint(shape->cols / sc));
+        if (sh.rows < 8 || sh.cols < 8) {
+            slamx_pyramid_destroy(p);
+            return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: level " + std::to_string(l) + " is smaller than 8 pixels");
+        }
+        if (l > 0) {
+            // Downscaling moves structures closer together and averages the noise away: raw corners per
+            // PIXEL go up level by level, their number per level hardly falls (measured on the bench
+            // frames: 14k, 20k, 23k, 24k, 24k, 24k, 22k, 19k).  The candidate capacity is therefore the
+            // caller's on every level (bounded by the level's pixels); kept keypoints are bounded by the
+            // suppression radius, i.e. by the area: they get the linear scale, with a floor.
+            const double r = std::sqrt((static_cast<double>(sh.rows) * sh.cols) / px0);
+            if (shape->max_candidates > 0) {
+                sh.max_candidates = static_cast<int>(std::min<long long>(shape->max_candidates, static_cast<long long>(sh.rows) * sh.cols));
+                sh.max_candidates = std::max(sh.max_candidates, 1024);
+            }
+            if (shape->max_keypoints > 0) {
+                sh.max_keypoints = std::max(256, static_cast<int>(shape->max_keypoints * r) + 64);
+            }
+        }
+        slamx_batch* b = nullptr;
+        const int rc = slamx_batch_create(det, &sh, &b);
+        if (rc != SLAMX_OK) {
+            slamx_pyramid_destroy(p);
+            return rc;
+        }
+        p->levels.push_back(b);
+        p->scale.push_back(sc);
+        p->xtab.push_back(nullptr);
+        p->ytab.push_back(nullptr);
+        if (l > 0) {
+            const slamx_batch* prev = p->levels[static_cast<size_t>(l) - 1];
+            const std::vector<uint32_t> xt = scale_table(sh.cols, prev->shape.cols);
+            const std::vector<uint32_t> yt = scale_table(sh.rows, prev->shape.rows);
+            int rc2 = dev_alloc(&p->xtab[static_cast<size_t>(l)], xt.size());
+            if (rc2 == SLAMX_OK) {
+                rc2 = dev_alloc(&p->ytab[static_cast<size_t>(l)], yt.size());
+            }
+            hipError_t e = hipSuccess;
+            if (rc2 == SLAMX_OK) {
+                e = hipMemcpy(p->xtab[static_cast<size_t>(l)], xt.data(), xt.size() * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) {
+                    e = hipMemcpy(p->ytab[static_cast<size_t>(l)], yt.data(), yt.size() * 4, hipMemcpyHostToDevice);
+                }
+            }
+            if (rc2 != SLAMX_OK || e != hipSuccess) {
+                slamx_pyramid_destroy(p);
+                return rc2 != SLAMX_OK ? rc2 : fail(SLAMX_ERR_HIP, std::string("pyramid tables: ") + hipGetErrorString(e));
+            }
+        }
+    }
+    *out = p;
+    return SLAMX_OK;
+}
+
+void slamx_pyramid_destroy(slamx_pyramid* p) {
+    if (p == nullptr) {
+        return;
+    }
+    for (slamx_batch* b : p->levels) {
+        slamx_batch_destroy(b);
+    }
+    for (auto& t : p->xtab) {
+        dev_free(t);
+    }
+    for (auto& t : p->ytab) {
+        dev_free(t);
+    }
+    delete p;
+}
+
+slamx_batch* slamx_pyramid_batch(slamx_pyramid* p, int level) {
+    if (p == nullptr || level < 0 || level >= static_cast<int>(p->levels.size())) {
+        return nullptr;
+    }
+    return p->levels[static_cast<size_t>(level)];
+}
+
+int slamx_pyramid_level_shape(const slamx_pyramid* p, int level, int* rows, int* cols, double* scale) {
+    if (p == nullptr || level < 0 || level >= static_cast<int>(p->levels.size())) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: level out of range");
+    }
+    const slamx_batch* b = p->levels[static_cast<size_t>(level)];
+    if (rows != nullptr) {
+        *rows = b->shape.rows;
+    }
+    if (cols != nullptr) {
+        *cols = b->shape.cols;
+    }
+    if (scale != nullptr) {
+        *scale = p->scale[static_cast<size_t>(level)];
+    }
+    return SLAMX_OK;
+}
+
+int slamx_pyramid_detect_and_compute(slamx_pyramid* p, int nframes) {
+    if (p == nullptr || nframes < 0 || nframes > p->levels[0]->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: nframes out of range");
+    }
+    if (nframes == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(p->det->ctx->device));
+    hipStream_t s = p->det->ctx->stream;
+    const size_t nl = p->levels.size();
+    for (size_t l = 1; l < nl; ++l) {
+        launch_downscale(p->levels[l - 1]->v, p->levels[l]->v, p->xtab[l], p->ytab[l], nframes, s);
+    }
+    for (size_t l = 0; l < nl; ++l) {
+        SLAMX_TRY(slamx_batch_detect_and_compute(p->levels[l], nframes));
+    }
+    for (size_t l = 1; l < nl; ++l) {
+        launch_merge_level(p->levels[l]->v, p->levels[0]->v, static_cast<float>(p->scale[l]), nframes, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return SLAMX_OK;
+}
+
 // ------------------------------------------------------------------ sliding-window Gauss-Newton (gn.hip)
 }  // extern "C"
 

@@ -219,6 +219,12 @@ void launch_sampson(const double* x1, const double* x2, int n, const double* E, 
 void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
                         double* xyz, hipStream_t stream);
 
+// image pyramid (pyramid.hip): dst level frames from src level frames (tables built by the host), and the
+// append of a level's results, scaled to level-0 coordinates, to level 0's keypoint / descriptor arrays
+void launch_downscale(const BatchView& src, const BatchView& dst, const uint32_t* xtab, const uint32_t* ytab, int nframes,
+                      hipStream_t stream);
+void launch_merge_level(const BatchView& src, const BatchView& dst, float scale, int nframes, hipStream_t stream);
+
 // sliding-window Gauss-Newton (gn.hip): device pointers of a batch of windows
 struct GnLaunch {
     const double* poses;     // [n_windows][n_cams][12]  linearisation point

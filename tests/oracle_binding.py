@@ -203,6 +203,46 @@ class Oracle:
         self.lib.oracle_sort_desc(_p(s), s.shape[0], _p(perm))
         return perm
 
+    # ---- image pyramid (oracle/pyramid_oracle.cpp; build-defined, no reference counterpart)
+    def downscale(self, img, drows, dcols):
+        src = np.ascontiguousarray(img, np.uint8)
+        dst = np.empty((drows, dcols), np.uint8)
+        self.lib.oracle_downscale.restype = None
+        self.lib.oracle_downscale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        self.lib.oracle_downscale(_p(src), src.shape[0], src.shape[1], _p(dst), drows, dcols)
+        return dst
+
+    def pyramid_sizes(self, rows, cols, n_levels, scale_factor):
+        fn = self.lib.oracle_pyramid_level_size
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int, C.c_double, C.c_int]
+        return [(fn(rows, scale_factor, l), fn(cols, scale_factor, l)) for l in range(n_levels)]
+
+    def pyramid_images(self, img, n_levels, scale_factor):
+        sizes = self.pyramid_sizes(img.shape[0], img.shape[1], n_levels, scale_factor)
+        out = [np.ascontiguousarray(img, np.uint8)]
+        for r, c in sizes[1:]:
+            out.append(self.downscale(out[-1], r, c))  # every level from the one above it
+        return out
+
+    def pyramid_detect_and_compute(self, img, P, n_levels, scale_factor):
+        """The unchanged detector on every level, results concatenated level after level with x, y, size
+        multiplied by float32(scale_factor ** level) -- what slamx_pyramid_detect_and_compute returns."""
+        kps, descs = [], []
+        for l, im in enumerate(self.pyramid_images(img, n_levels, scale_factor)):
+            k, d = self.detect_and_compute(im, P)
+            k = k.copy()
+            sc = np.float32(float(scale_factor) ** l)
+            for name in ("x", "y", "size"):
+                k[name] = k[name] * sc
+            kps.append(k)
+            if d.size:
+                descs.append(d)
+        kp = np.concatenate(kps)
+        width = P.numBRIEFPairs // 8
+        de = np.concatenate(descs) if descs else np.zeros((0, width), np.uint8)
+        return kp, de
+
     # ---- sliding-window Gauss-Newton (oracle/gn_oracle.cpp; build-defined problem, no reference counterpart)
     def gn_step_dense(self, poses, X, obs, K, lam, n_fixed):
         """One window, full dense normal equations -> dict(delta_c [W,6], delta_x [L,3], cost, S, g, active, rc)"""

@@ -220,3 +220,21 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"oracle_|libslam_oracle|/oracle/", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_oracle_pyramid_downscale_properties(oracle):
+    """The build-defined downscale (no reference counterpart): level sizes as ORB-style pyramids compute
+    them, constants stay constant, same-size is the identity, a 2:1 reduction of an aligned image is the
+    2x2 box mean rounded half up."""
+    assert oracle.pyramid_sizes(1080, 1920, 8, 1.2) == [(1080, 1920), (900, 1600), (750, 1333), (625, 1111), (521, 926),
+                                                        (434, 772), (362, 643), (301, 536)]
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (60, 90), dtype=np.uint8)
+    assert np.array_equal(oracle.downscale(img, 60, 90), img)
+    assert (oracle.downscale(np.full((50, 70), 137, np.uint8), 31, 43) == 137).all()
+    half = oracle.downscale(img, 30, 45)
+    box = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) // 4
+    assert np.array_equal(half, box.astype(np.uint8))
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (40, 1))
+    small = oracle.downscale(ramp, 33, 83).astype(int)
+    assert (np.diff(small, axis=1) >= 0).all() and (small == small[0]).all()
