@@ -249,6 +249,320 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Hamming distances on the int8 matrix cores (descriptors with at most 62 live bits, i.e. the shipped
+// configuration's 46 surviving BRIEF pairs).
+//
+// For bit vectors a, b:  hamming(a, b) = |a| + |b| - 2 a.b  -- an exact integer identity.  With every
+// descriptor expanded to 64 int8 values
+//     train form  t' = [ bit 0 .. bit 61 |  |t| |  1  ]        (xdesc_kernel writes this form)
+//     query form  q' = [ -2 bit 0 .. -2 bit 61 |  1  | |q| ]   (derived from the train form at load)
+// the dot product q'.t' IS the Hamming distance, and one v_mfma_i32_16x16x64_i8 (K = 64) gives the
+// 256 distances of 16 train x 16 query descriptors in 16 cycles: 16 pairs per cycle and SIMD against 4
+// for xor + popcount at its peak.  Integer arithmetic, so the values are the reference's
+// (calculateHammingDistance, common.hpp:40-50) bit for bit; both operands use the same byte -> k
+// assignment, so the k order inside the instruction does not matter.
+//
+// What stays on the vector ALU is the per-query bookkeeping, and the matrix cores leave it 4
+// instructions per MFMA before it becomes the bound (counters: the first versions of this kernel
+// spent 16 and ran no faster than the popcount kernel).  C/D layout: lane (c = lane & 15, g = lane >> 4)
+// receives rows 4g..4g+3 of column c: four consecutive TRAIN descriptors against ONE query.  So:
+//   * the accumulator input of the MFMA is -bound(query), the stale upper bound of the query's `second`
+//     that match_kernel filters with: the product comes out as distance - bound, a pair passes iff it
+//     is negative, and a lane knows whether ANY of its 16 pairs of a train tile (4 query tiles x 4
+//     rows) passes from the sign of their OR: 8 v_or3 + 1 compare per 4 MFMAs;
+//   * a passing (lane, tile) -- a few per cent of them -- is appended to a per-WAVE FIFO in LDS, and
+//     whenever 64 entries wait the whole wave works them off, one entry per lane whoever pushed it:
+//     xor + popcount of the 16 pairs from the compact bits; the one or two of them that still reach the
+//     query's current `second` go to a second FIFO of PAIRS, which is settled 64 at a time as well:
+//     the reference's penalty arithmetic (with every pair slot of the first level taking it, at one
+//     active lane in 64, it was two thirds of the kernel's instructions) and the update of the
+//     query's state, which lives in LDS as two 64-bit keys (distance << 32 | train index):
+//         old = atomicMin(best_key, key);  atomicMin(second_key, max(old, key))
+//     Every key but the final minimum is offered to second_key exactly once (when it loses), so the two
+//     keys end as the two lexicographically smallest of all pairs, whatever the order of the updates:
+//     the smallest distance with the LOWEST train index -- the reference's strict '<' in an ascending
+//     scan (feature_matcher.cpp:132-141) -- and the second smallest distance of the multiset.
+// The slow path thus runs on full waves, needs no per-lane state and leaves no merge for the end.
+// Filtering with strict '<' is exact: when the filter of a train tile runs, the keys hold only pairs of
+// EARLIER tiles (lower indices), so a pair that merely ties with `second` cannot be one of the two
+// smallest keys; inside a batch of 64, where two lanes may update one query at the same time, the
+// pre-test is '<=' and the index part of the keys decides.
+constexpr int MM_STAGE = 256;    // train descriptors staged in LDS at a time
+constexpr int MM_XSTRIDE = 80;   // bytes between staged expanded descriptors: 16 lanes x 16 B then cover all 64 banks
+constexpr int MM_QT = 4;         // query tiles (of 16) per wave: 64 queries per wave, 256 per workgroup
+constexpr int MM_FIFO = 256;     // ring capacity per wave: < 64 waiting + the 64 pushes of one train tile
+constexpr int MM_TRASH = MM_FIFO;  // one more slot: where the lanes that do not pass write
+constexpr int MM_PAIRS = 128;    // pair ring per wave: < 64 waiting + the 64 pushes of one pair slot
+constexpr int MM_MAX_BITS = 62;
+constexpr unsigned long long MM_KEY_NONE = 0x7fffffffffffffffull;  // distance INT_MAX, index -1
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// desc (compact bits) -> train-form expanded descriptors, 64 bytes each; 4 lanes per keypoint
+__global__ __launch_bounds__(256) void xdesc_kernel(const uint8_t* __restrict__ desc, const int* __restrict__ n_kp, int maxK,
+                                                    int width, uint8_t* __restrict__ xdesc, int first_frame) {
+    const int f = first_frame + blockIdx.y;
+    const int n = n_kp[f];
+    const int stride = width / 4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * 4; e += gridDim.x * 256) {
+        const int i = e >> 2;
+        const int quarter = e & 3;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(desc + (static_cast<size_t>(f) * maxK + i) * width);
+        const uint32_t w0 = row[0];
+        const uint32_t w1 = stride > 1 ? row[1] : 0u;
+        const unsigned long long bits = static_cast<unsigned long long>(w0) | (static_cast<unsigned long long>(w1) << 32);
+        const uint32_t b16 = static_cast<uint32_t>(bits >> (16 * quarter)) & 0xffffu;
+        uint4 o;
+        // four bits -> four bytes: the shifted copies of the nibble (by 0, 7, 14, 21) do not overlap
+        o.x = ((b16 & 0xfu) * 0x00204081u) & 0x01010101u;
+        o.y = (((b16 >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+        o.z = (((b16 >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+        o.w = (((b16 >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+        if (quarter == 3) {  // bits 62, 63 are never set (MM_MAX_BITS): bytes 62, 63 carry |t| and 1
+            o.w = (o.w & 0x0000ffffu) | (static_cast<uint32_t>(__popcll(bits)) << 16) | 0x01000000u;
+        }
+        *reinterpret_cast<uint4*>(xdesc + (static_cast<size_t>(f) * maxK + i) * 64 + 16 * quarter) = o;
+    }
+}
+
+// (amdgpu_waves_per_eu >= 2 caps the kernel at 256 registers, which lets the compiler give the MFMAs plain
+// VGPR destinations; with the default cap of 512 it allocates accumulator registers and copies every result)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void match_mfma_kernel(MatchView mv,
+                                                                                                  int first_query_frame,
+                                                                                                  int first_train_frame,
+                                                                                                  int stride, int npairs,
+                                                                                                  int qblocks) {
+    __shared__ __attribute__((aligned(16))) uint8_t xt[MM_STAGE * MM_XSTRIDE];
+    __shared__ uint2 tbits[MM_STAGE];
+    __shared__ float2 txy[MM_STAGE];
+    __shared__ uint4 qtab[4][16 * MM_QT];                  // per wave and query: compact bits (x, y), position (z, w as float bits)
+    __shared__ unsigned long long keys[4][16 * MM_QT][2];  // per wave and query: best_key, second_key
+    __shared__ uint16_t fifo[4][MM_FIFO + 64];             // per wave: lane | train tile << 6
+    __shared__ uint32_t pairq[4][MM_PAIRS + 64];           // per wave: query | train << 8 | raw distance << 16
+    constexpr int QW = 16 * MM_QT;                         // queries per wave
+    const int pair = static_cast<int>(blockIdx.x) % npairs;
+    const int rest = static_cast<int>(blockIdx.x) / npairs;
+    const int qblock = rest % qblocks;
+    const int split = rest / qblocks;
+    const int qf = first_query_frame + pair;
+    const int tf = qf == 0 ? first_train_frame : qf - 1;
+    const int n1 = mv.n_kp[qf];
+    const int n2 = mv.n_kp[tf];
+    const int block_first = qblock * (QW * 4);
+    if (block_first >= n1) {
+        return;
+    }
+    const bool use_kp = mv.kps != nullptr;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(qf) * mv.maxK * mv.width);
+    const uint32_t* td = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(tf) * mv.maxK * mv.width);
+    const uint8_t* xq = mv.xdesc + static_cast<size_t>(qf) * mv.maxK * 64;
+    const uint8_t* xtr = mv.xdesc + static_cast<size_t>(tf) * mv.maxK * 64;
+    const int wave_first = block_first + wave * QW;
+    const bool wave_has_queries = wave_first < n1;
+    for (int k = lane; k < QW; k += 64) {
+        // query wave_first + k of the wave
+        const int i = wave_first + k;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n1) {
+            q.x = qd[static_cast<size_t>(i) * stride];
+            q.y = stride > 1 ? qd[static_cast<size_t>(i) * stride + 1] : 0u;
+            if (use_kp) {
+                const slamx_keypoint kp = mv.kps[static_cast<size_t>(qf) * mv.maxK + i];
+                q.z = __float_as_uint(kp.x);
+                q.w = __float_as_uint(kp.y);
+            }
+        }
+        qtab[wave][k] = q;
+        keys[wave][k][0] = MM_KEY_NONE;
+        keys[wave][k][1] = MM_KEY_NONE;
+    }
+    constexpr int NEVER = 0x3fffffff;  // accumulator input of an absent query: distance + NEVER is never negative
+    v4i B[MM_QT];
+    v4i C[MM_QT];  // -bound of the lane's query of each tile, in all four rows
+#pragma unroll
+    for (int u = 0; u < MM_QT; ++u) {
+        const int i = wave_first + u * 16 + c;
+        const bool ok = i < n1;
+        B[u] = v4i{0, 0, 0, 0};
+        const int nb = ok ? -0x7fffffff : NEVER;
+        C[u] = v4i{nb, nb, nb, nb};
+        if (ok) {
+            const uint4 t = *reinterpret_cast<const uint4*>(xq + static_cast<size_t>(i) * 64 + 16 * g);
+            // train form -> query form: bits * -2 (= * 254 per byte, no carries), and |q| / 1 swapped
+            uint32_t w3 = t.w * 254u;
+            if (g == 3) {
+                w3 = ((t.w & 0x0101u) * 254u) | 0x00010000u | ((t.w >> 16 & 0xffu) << 24);
+            }
+            B[u] = v4i{static_cast<int>(t.x * 254u), static_cast<int>(t.y * 254u), static_cast<int>(t.z * 254u),
+                       static_cast<int>(w3)};
+        }
+    }
+    uint16_t* const myfifo = fifo[wave];
+    uint32_t* const mypairs = pairq[wave];
+    int head = 0, tail = 0;    // tile FIFO: ring positions (wave-uniform, kept in SGPRs); entries [head, tail)
+    int phead = 0, ptail = 0;  // pair FIFO
+    // level 2: `count` (<= 64) pairs from the head of the pair FIFO, one per lane: the reference's penalty
+    // arithmetic (feature_matcher.cpp:161-170) and the update of the query's two keys
+    auto settle = [&](int count, int t0) {
+        if (lane < count) {
+            const uint32_t e = mypairs[(phead + lane) & (MM_PAIRS - 1)];
+            const int q = static_cast<int>(e & 0xffu);
+            const int t = static_cast<int>(e >> 8 & 0xffu);
+            int dist = static_cast<int>(e >> 16);
+            unsigned long long* key = keys[wave][q];
+            const int sec = static_cast<int>(key[1] >> 32);  // may have shrunk since the pair was queued
+            if (dist <= sec) {
+                if (use_kp) {
+                    const uint4 qv = qtab[wave][q];
+                    const float2 p = txy[t];
+                    dist = penalised_distance(dist, __uint_as_float(qv.z), __uint_as_float(qv.w), p.x, p.y);
+                }
+                if (dist <= sec) {
+                    const unsigned long long k = (static_cast<unsigned long long>(static_cast<uint32_t>(dist)) << 32) |
+                                                 static_cast<uint32_t>(t0 + t);
+                    const unsigned long long old = atomicMin(&key[0], k);
+                    atomicMin(&key[1], old > k ? old : k);
+                }
+            }
+        }
+        phead += count;
+    };
+    // level 1: `count` (<= 64) entries from the head of the tile FIFO, one per lane: entry = (lane L, tile) stands
+    // for the 16 pairs {query u * 16 + (L & 15)} x {train 16 tile + 4 (L >> 4) + r}; their distances are
+    // recomputed with xor + popcount and the ones that still reach the query's `second` go to the pair FIFO
+    auto work = [&](int count, int t0, int tn) {
+        const bool valid = lane < count;
+        const uint32_t e = myfifo[(head + lane) & (MM_FIFO - 1)];
+        const int ec = static_cast<int>(e & 15u);
+        const int trow = static_cast<int>(e >> 6) * 16 + 4 * static_cast<int>(e >> 4 & 3u);
+        // a loop, not unrolled: `settle` (with the penalty arithmetic inside) is then instantiated once
+#pragma unroll 1
+        for (int slot16 = 0; slot16 < 4 * MM_QT; ++slot16) {
+            const int q = (slot16 >> 2) * 16 + ec;
+            const int t = trow + (slot16 & 3);
+            const uint2 qb = *reinterpret_cast<const uint2*>(&qtab[wave][q]);
+            const uint2 tb = tbits[t & (MM_STAGE - 1)];
+            int sec = static_cast<int>(keys[wave][q][1] >> 32);
+            sec = valid ? sec : -1;  // lanes without an entry queue nothing
+            const int dist = __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y);
+            const bool pass = dist <= sec && t < tn;
+            const unsigned long long pm = __ballot(pass);
+            if (pm != 0) {  // wave-uniform
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+                const uint32_t slot = pass ? ((static_cast<uint32_t>(ptail) + rank) & (MM_PAIRS - 1)) : static_cast<uint32_t>(MM_PAIRS);
+                mypairs[slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(t) << 8) | (static_cast<uint32_t>(dist) << 16);
+                ptail += __popcll(pm);
+                if (ptail - phead >= 64) {
+                    settle(64, t0);
+                }
+            }
+        }
+        head += count;
+    };
+    auto refresh_bounds = [&]() {
+#pragma unroll
+        for (int u = 0; u < MM_QT; ++u) {
+            const int sec = static_cast<int>(keys[wave][u * 16 + c][1] >> 32);
+            const int nb = C[u][0] == NEVER ? NEVER : -sec;
+            C[u] = v4i{nb, nb, nb, nb};
+        }
+    };
+    const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
+    const int t_begin = split * chunk;
+    const int t_end = min(n2, t_begin + chunk);
+    for (int t0 = t_begin; t0 < t_end; t0 += MM_STAGE) {
+        const int tn = min(MM_STAGE, t_end - t0);
+        __syncthreads();
+        {
+            // thread t stages train descriptor t0 + t: 64 expanded bytes, its compact bits, its position
+            const int t = threadIdx.x;
+            uint4 x0, x1, x2, x3;
+            if (t < tn) {
+                const uint4* src = reinterpret_cast<const uint4*>(xtr + static_cast<size_t>(t0 + t) * 64);
+                x0 = src[0];
+                x1 = src[1];
+                x2 = src[2];
+                x3 = src[3];
+                tbits[t] = make_uint2(td[static_cast<size_t>(t0 + t) * stride],
+                                      stride > 1 ? td[static_cast<size_t>(t0 + t) * stride + 1] : 0u);
+                if (use_kp) {
+                    const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + t0 + t];
+                    txy[t] = make_float2(k.x, k.y);
+                }
+            } else {
+                // past the end of the train set: distance 127 + |q|, which no bound below 127 lets through
+                // (and the slow path checks the index anyway)
+                x0 = x1 = x2 = make_uint4(0u, 0u, 0u, 0u);
+                x3 = make_uint4(0u, 0u, 0u, 0x017f0000u);
+                tbits[t] = make_uint2(0u, 0u);
+            }
+            uint4* dst = reinterpret_cast<uint4*>(xt + t * MM_XSTRIDE);
+            dst[0] = x0;
+            dst[1] = x1;
+            dst[2] = x2;
+            dst[3] = x3;
+        }
+        __syncthreads();
+        if (!wave_has_queries) {
+            continue;  // wave-uniform: this wave only helps staging
+        }
+        const int ntiles = (tn + 15) >> 4;
+        const uint8_t* arow = xt + c * MM_XSTRIDE + 16 * g;
+        v4i A = *reinterpret_cast<const v4i*>(arow);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            // distance - bound of the 4 x 4 pairs this lane sees of the tile; the next tile's operand behind the products
+            v4i D[MM_QT];
+#pragma unroll
+            for (int u = 0; u < MM_QT; ++u) {
+                D[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[u], C[u], 0, 0, 0);
+            }
+            A = *reinterpret_cast<const v4i*>(arow + min(tile + 1, ntiles - 1) * 16 * MM_XSTRIDE);
+            int any = 0;
+#pragma unroll
+            for (int u = 0; u < MM_QT; ++u) {
+                any |= D[u][0] | D[u][1] | D[u][2] | D[u][3];
+            }
+            const bool pass = any < 0;  // some pair is below its (stale) bound
+            const unsigned long long pm = __ballot(pass);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+            // branch-free: every lane stores, the ones that do not pass into the trash slot
+            const uint32_t slot = pass ? ((static_cast<uint32_t>(tail) + rank) & (MM_FIFO - 1)) : static_cast<uint32_t>(MM_TRASH);
+            myfifo[slot] = static_cast<uint16_t>(lane | (tile << 6));
+            tail += __popcll(pm);
+            if (tail - head >= 64) {  // wave-uniform
+                do {
+                    work(64, t0, tn);
+                } while (tail - head >= 64);
+                refresh_bounds();
+            }
+        }
+        // entries are stage-relative and the stage is about to be replaced
+        while (tail - head > 0) {
+            work(min(64, tail - head), t0, tn);
+        }
+        while (ptail - phead > 0) {
+            settle(min(64, ptail - phead), t0);
+        }
+        refresh_bounds();
+    }
+    for (int k = lane; k < QW; k += 64) {
+        const int i = wave_first + k;
+        if (i < n1) {
+            const unsigned long long kb = keys[wave][k][0], ks = keys[wave][k][1];
+            const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + split) * mv.maxK + i;
+            mv.best[slot] = make_int2(static_cast<int>(kb >> 32), static_cast<int>(static_cast<uint32_t>(kb)));
+            mv.second[slot] = static_cast<int>(ks >> 32);
+        }
+    }
+}
+
 // Any descriptor width (bytes): byte-wise popcount straight from global memory.  Correctness
 // path for widths that are not 8/16/32/64 bytes.
 __global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
@@ -388,7 +702,23 @@ void launch_match_consecutive(const MatchView& mv, int first_query_frame, int np
         return;
     }
     const int stride = mv.width / 4;
-    if (mv.width % 4 == 0 && stride <= 16) {
+    if (mv.xdesc != nullptr && mv.width % 4 == 0 && mv.live_bits > 0 && mv.live_bits <= MM_MAX_BITS) {
+        // expanded descriptors of every frame that is a query or a train set of this call, then the matrix-core scan
+        const int qblocks = (mv.maxK + 64 * MM_QT - 1) / (64 * MM_QT);
+        // frames in use: the queries, their predecessors, and first_train_frame when frame 0 is a query
+        const int lo_frame = first_query_frame > 0 ? first_query_frame - 1 : 0;
+        const int hi_frame = first_query_frame + npairs - 1;
+        dim3 gx(grid_x(mv.maxK * 4, 256, hi_frame - lo_frame + 1), hi_frame - lo_frame + 1);
+        hipLaunchKernelGGL(xdesc_kernel, gx, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc, lo_frame);
+        if (first_query_frame == 0 && first_train_frame >= 0 && (first_train_frame < lo_frame || first_train_frame > hi_frame)) {
+            dim3 g1(grid_x(mv.maxK * 4, 256, 1), 1);
+            hipLaunchKernelGGL(xdesc_kernel, g1, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc,
+                               first_train_frame);
+        }
+        dim3 grid(static_cast<unsigned>(qblocks) * npairs * mv.nsplit);
+        hipLaunchKernelGGL(match_mfma_kernel, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame, stride,
+                           npairs, qblocks);
+    } else if (mv.width % 4 == 0 && stride <= 16) {
         int live = mv.live_words > 0 && mv.live_words < stride ? mv.live_words : stride;
         switch (live) {
             case 1: launch_words<1>(mv, first_query_frame, npairs, first_train_frame, stream); break;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -93,6 +94,7 @@ struct slamx_matcher {
     int* n_matches = nullptr;
     int2* best = nullptr;
     int* second = nullptr;
+    uint8_t* xdesc = nullptr;  // [2][cap][64]
 };
 
 struct slamx_batch {
@@ -105,6 +107,7 @@ struct slamx_batch {
     int* n_matches = nullptr;
     int2* best = nullptr;
     int* second = nullptr;
+    uint8_t* xdesc = nullptr;  // [F][maxK][64] expanded descriptors of the matrix-core matcher
     // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
     // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS_BUILD|5|NMS_ROUNDS|6|BLUR|7|MOMENTS|8|TRIG|9|BRIEF|10|MATCH|11|EMIT|12
     static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
@@ -364,6 +367,16 @@ int match_split_for(int npairs, int maxK) {
         s = MATCH_MAX_SPLIT;
     }
     return static_cast<int>(s);
+}
+
+// Train-set size from which the matrix-core scan is taken; SLAMX_MATCH_MFMA_MIN_KEYPOINTS overrides the
+// built-in threshold (the parity tests run small sets through both scans that way).
+int match_mfma_min_keypoints() {
+    const char* e = std::getenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS");
+    if (e != nullptr && *e != '\0') {
+        return std::atoi(e);
+    }
+    return MATCH_MFMA_MIN_KEYPOINTS;
 }
 
 uint64_t splitmix64(uint64_t& s) {
@@ -741,6 +754,7 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(b->n_matches);
     dev_free(b->best);
     dev_free(b->second);
+    dev_free(b->xdesc);
     for (auto& e : b->ev) {
         if (e != nullptr) {
             (void)hipEventDestroy(e);
@@ -853,6 +867,14 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
         SLAMX_TRY(dev_alloc(&b->second, F * MATCH_MAX_SPLIT * b->v.maxK));
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
     }
+    const int pattern_len = static_cast<int>(b->det->pattern.size() / 4);
+    // The matrix-core scan (match.hip) wins for large sets (measured: 4.0 vs 4.9 ms per 256 frames of 10.4k
+    // keypoints) and loses for small ones (0.67 vs 0.59 ms per 512 frames of 2.1k): its slow path handles
+    // ~2 ln(n) filter passes per query, a cost per QUERY, while the scan it replaces is a cost per PAIR.
+    // The keypoint count of a frame is only known on the device; the batch's capacity stands in for it.
+    if (b->xdesc == nullptr && pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints()) {
+        SLAMX_TRY(dev_alloc(&b->xdesc, F * b->v.maxK * 64));
+    }
     MatchView mv{};
     mv.desc = b->v.desc;
     mv.kps = use_keypoints != 0 ? b->v.kps : nullptr;
@@ -864,8 +886,11 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     mv.maxK = b->v.maxK;
     mv.width = b->v.width;
     // descriptors of a batch come from describe_kernel: bits >= pattern_len are never set
-    mv.live_words = std::max(1, (static_cast<int>(b->det->pattern.size() / 4) + 31) / 32);
-    mv.nsplit = match_split_for(nframes, b->v.maxK);
+    mv.live_words = std::max(1, (pattern_len + 31) / 32);
+    mv.live_bits = std::max(1, pattern_len);
+    mv.xdesc = b->xdesc;
+    // (the matrix-core path takes 256 queries per workgroup, the popcount path 512)
+    mv.nsplit = match_split_for(nframes, b->xdesc != nullptr ? b->v.maxK * 2 : b->v.maxK);
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
     if (!recorded(b, 10)) {
@@ -1318,6 +1343,7 @@ void slamx_matcher_destroy(slamx_matcher* m) {
     dev_free(m->n_matches);
     dev_free(m->best);
     dev_free(m->second);
+    dev_free(m->xdesc);
     delete m;
 }
 
@@ -1356,6 +1382,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
         dev_free(m->n_matches);
         dev_free(m->best);
         dev_free(m->second);
+        dev_free(m->xdesc);
         m->cap = 0;
         const size_t c = static_cast<size_t>(need);
         SLAMX_TRY(dev_alloc(&m->desc, 2 * c * width1 + 64));
@@ -1365,6 +1392,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
         SLAMX_TRY(dev_alloc(&m->n_matches, 2));
         SLAMX_TRY(dev_alloc(&m->best, 2 * MATCH_MAX_SPLIT * c));
         SLAMX_TRY(dev_alloc(&m->second, 2 * MATCH_MAX_SPLIT * c));
+        SLAMX_TRY(dev_alloc(&m->xdesc, 2 * c * 64));
         m->cap = need;
         m->width = width1;
     }
@@ -1390,6 +1418,8 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     mv.width = width1;
     mv.nsplit = match_split_for(1, m->cap);
     mv.live_words = 0;
+    mv.live_bits = 0;
+    mv.xdesc = nullptr;
     if (width1 % 4 == 0) {
         // highest 32-bit word that is non-zero in any descriptor of either set
         int live = 1;
@@ -1410,6 +1440,30 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
             }
         }
         mv.live_words = live;
+        if (live <= 2) {
+            // at most 64 bits in use: the exact position of the highest one decides whether the
+            // matrix-core path (<= 62 live bits) applies
+            uint32_t top = 0;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint8_t* d = s2 == 0 ? d1 : d2;
+                const int cnt = s2 == 0 ? n1 : n2;
+                for (int i = 0; i < cnt; ++i) {
+                    uint32_t val;
+                    std::memcpy(&val, d + static_cast<size_t>(i) * width1 + 4 * (live - 1), 4);
+                    top |= val;
+                }
+            }
+            int hb = 0;
+            while (top != 0) {
+                ++hb;
+                top >>= 1;
+            }
+            mv.live_bits = std::max(1, 32 * (live - 1) + hb);
+            if (n2 >= match_mfma_min_keypoints()) {  // see slamx_batch_match_consecutive
+                mv.xdesc = m->xdesc;
+                mv.nsplit = match_split_for(1, m->cap * 2);
+            }
+        }
     }
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;

@@ -403,6 +403,94 @@ def test_match_random_descriptors(slamx, oracle, width, n1, n2):
                                  "random match w=%d kp=%s" % (width, kp))
 
 
+@pytest.fixture
+def mfma_scan_for_all_sizes(monkeypatch):
+    """The matrix-core scan is only taken for train sets of >= 6144 keypoints (smaller ones are faster on
+    the popcount scan); the override sends every size through it."""
+    monkeypatch.setenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", "0")
+
+
+@pytest.mark.parametrize("bits", [1, 7, 31, 32, 33, 46, 61, 62, 63, 64])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 1), (1, 700), (15, 17), (16, 16), (250, 270), (257, 255), (700, 513), (2100, 2300)])
+def test_match_live_bit_prefix(slamx, oracle, bits, n1, n2, mfma_scan_for_all_sizes):
+    """Descriptors whose bits >= `bits` are zero (what the detector produces: 46 live bits): up to 62 live bits
+    the all-pairs distances come from the int8 matrix cores (match_mfma_kernel), above that from xor + popcount.
+    Few distinct values on purpose -- ties in best AND second, duplicates, all-zero rows -- with and without the
+    jump penalty, with and without the ratio test."""
+    rng = np.random.default_rng(bits * 7919 + n1 * 31 + n2)
+    width = 32
+
+    def make(n):
+        d = np.zeros((n, width), np.uint8)
+        raw = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+        if bits < 64:
+            mask = np.frombuffer(np.uint64((1 << bits) - 1).tobytes(), np.uint8)
+            raw &= mask
+        d[:, :8] = raw
+        return d
+
+    d1, d2 = make(n1), make(n2)
+    d2[rng.integers(0, n2, n2 // 3 + 1)] = d1[rng.integers(0, n1, n2 // 3 + 1)]  # exact duplicates -> ties
+    d2[rng.integers(0, n2, n2 // 10 + 1)] = 0
+    if bits >= 7:  # near-duplicates: many equal small distances
+        k = rng.integers(0, n2, n2 // 4 + 1)
+        d2[k] = d1[rng.integers(0, n1, len(k))]
+        d2[k, 0] ^= np.uint8(1) << rng.integers(0, min(bits, 8), len(k)).astype(np.uint8)
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.integers(0, 1920, len(k))
+        k["y"] = rng.integers(0, 1080, len(k))
+    for kp in (True, False):
+        for ratio_on, ratio in ((1, 0.8), (0, 0.5)):
+            m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, ratio_on, ratio))
+            a1, a2 = (k1, k2) if kp else (None, None)
+            assert_records_equal(m.match(d1, d2, a1, a2), oracle.match(d1, d2, a1, a2, oracle.match_params(m.cfg)),
+                                 "live bits %d kp=%s ratio=%s" % (bits, kp, ratio_on))
+
+
+def test_match_large_train_set_takes_the_matrix_core_scan(slamx, oracle):
+    """7000 train descriptors with 46 live bits: above the built-in threshold, no override."""
+    rng = np.random.default_rng(77)
+    n1, n2 = 900, 7000
+    d1 = np.zeros((n1, 32), np.uint8)
+    d2 = np.zeros((n2, 32), np.uint8)
+    mask = np.frombuffer(np.uint64((1 << 46) - 1).tobytes(), np.uint8)
+    d1[:, :8] = rng.integers(0, 256, (n1, 8), dtype=np.uint8) & mask
+    d2[:, :8] = rng.integers(0, 256, (n2, 8), dtype=np.uint8) & mask
+    d2[rng.integers(0, n2, 3000)] = d1[rng.integers(0, n1, 3000)]
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.integers(0, 1920, len(k))
+        k["y"] = rng.integers(0, 1080, len(k))
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.8))
+    assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, oracle.match_params(m.cfg)), "large train set")
+
+
+def test_batch_matching_through_the_matrix_core_scan(slamx, oracle, mfma_scan_for_all_sizes):
+    """A device-resident batch (46 live bits by construction) with the override: frames matched to their
+    predecessors, ragged keypoint counts, train sets of several LDS stages."""
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
+    mp = oracle.match_params(m.cfg)
+    frames = [synth(slamx, k, 360, 500, 300 + 400 * k, rmin=3, rmax=20) for k in range(4)]
+    b = slamx.Batch(d, 360, 500, 4, 32768, 8192)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(4)
+    b.match_consecutive(m, 4, use_keypoints=True, first_train_frame=3)
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    for k in range(4):
+        t = (k - 1) % 4
+        want = oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], mp)
+        assert_records_equal(b.download_matches(m, k), want, "frame %d vs %d" % (k, t))
+    b.match_consecutive(m, 4, use_keypoints=False, first_train_frame=-1)
+    for k in range(1, 4):
+        want = oracle.match(ref[k][1], ref[k - 1][1], None, None, mp)
+        assert_records_equal(b.download_matches(m, k), want, "no keypoints, frame %d" % k)
+
+
 def test_match_penalty_fractional_keypoints(slamx, oracle):
     rng = np.random.default_rng(9)
     d1 = rng.integers(0, 256, (400, 32), dtype=np.uint8)
