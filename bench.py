@@ -152,10 +152,13 @@ def pmc_traffic_bytes(kernel, batch):
 
 
 def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=6):
-    """The same step with every frame coming from the host: the batch is copied from page-locked host
-    memory (slamx_batch_upload_async) before it is processed.  Two contexts (two streams, two batches)
-    alternate, so the copy of one batch overlaps the kernels of the other.  Reported next to `value`,
-    never as it (the timed region of `value` starts with the frames resident in HBM)."""
+    """The same step with every frame coming from the host AND every result going back to it: the batch is
+    copied from page-locked host memory (slamx_batch_upload_async) before it is processed, and counts,
+    keypoints, descriptors and matches of all its frames are copied back to page-locked memory
+    (slamx_batch_download_results_async) after it.  Two contexts (two streams, two batches) alternate, so
+    the copies of one batch overlap the kernels of the other.  Reported next to `value`, never as it (the
+    timed region of `value` starts with the frames resident in HBM, as the task's measurement rule says;
+    SURVEY.md 8d's end-to-end definition is this leg)."""
     pin = mod.pinned_array(frames.shape)
     pin[...] = frames
     ctx2 = mod.Context(local_rank)
@@ -163,12 +166,14 @@ def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=6)
     matcher2 = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx2)
     batch2 = mod.Batch(det2, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
     lanes = [main, (ctx2, batch2, matcher2)]
+    outs = [lanes[k][1].result_buffers(B, wl["max_kp"]) for k in range(2)]
 
     def step(i):
         _, b, m = lanes[i % 2]
         b.upload_async(pin)
         b.detect_and_compute(B)
         b.match_consecutive(m, B, use_keypoints=use_keypoints, first_train_frame=B - 1)
+        b.download_results_async(B, outs[i % 2])
 
     for i in range(2):
         step(i)
@@ -181,8 +186,12 @@ def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=6)
         c.synchronize()
     dt = time.perf_counter() - t0
     gb = steps * frames.nbytes / 1e9
+    gb_out = steps * sum(a.nbytes for a in outs[0]) / 1e9
+    assert int(outs[0][3].sum()) > 0 and int(outs[0][4].sum()) > 0  # the results did arrive
     return {"value": steps * B / dt, "unit": "frames/s", "steps": steps, "host_to_hbm_GBps": gb / dt,
-            "note": "every batch uploaded from pinned host memory before it is processed; two contexts alternate"}
+            "hbm_to_host_GBps": gb_out / dt,
+            "note": "every batch uploaded from pinned host memory before it is processed and all its results (counts, "
+                    "keypoints, descriptors, matches: capacity-padded arrays) downloaded after; two contexts alternate"}
 
 
 def cpu_baseline(mod, wl, frames, budget_s=15.0):

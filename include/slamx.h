@@ -204,6 +204,14 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
 int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride);
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
                                  int cap, int* n);
+/* The streaming form of the downloads: queues the copy of the results of frames [0, nframes) into
+ * PAGE-LOCKED host memory (slamx_host_alloc) on the context stream and returns; any pointer may be
+ * NULL.  Layout = the device's capacity-padded arrays: kps [nframes][max_keypoints],
+ * desc [nframes][max_keypoints][width], matches [nframes][max_keypoints]; n_keypoints / n_matches
+ * [nframes] say how much of each frame's slice is valid.  Synchronise the context before reading. */
+int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoint* kps, uint8_t* desc,
+                                       slamx_match* matches, int32_t* n_keypoints, int32_t* n_matches);
+
 /* Per-stage device time from hipEvents recorded on the context stream between the kernels (no
  * synchronization is added).  slamx_batch_set_profiling(b, n_sets) keeps n_sets event sets
  * (0 = off); the i-th detect_and_compute call after it records into set i % n_sets, and the

@@ -95,7 +95,7 @@ EXPORTS = [
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
+    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
     "slamx_pyramid_create", "slamx_pyramid_destroy", "slamx_pyramid_batch", "slamx_pyramid_level_shape",
@@ -163,6 +163,7 @@ def load_library():
     lib.slamx_batch_download.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_batch_download_results_async.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.slamx_batch_set_profiling_every.argtypes = [vp, C.c_int, C.c_int]
     lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -678,6 +679,18 @@ class Batch:
         _check(self.lib.slamx_batch_download_matches(self.h, matcher.h, frame, 1 if apply_filter else 0, _ptr(out),
                                                      out.shape[0], C.byref(n)))
         return out[: n.value].copy()
+
+    def result_buffers(self, nframes, max_keypoints):
+        """Page-locked host arrays for download_results_async: (kps, desc, matches, n_keypoints, n_matches)."""
+        return (pinned_array((nframes, max_keypoints), KEYPOINT_DTYPE), pinned_array((nframes, max_keypoints, self.det.width)),
+                pinned_array((nframes, max_keypoints), MATCH_DTYPE), pinned_array((nframes,), np.int32),
+                pinned_array((nframes,), np.int32))
+
+    def download_results_async(self, nframes, bufs):
+        """Queue the copy of all results of frames [0, nframes) into result_buffers(); synchronise before reading."""
+        kps, desc, matches, nk, nm = bufs
+        _check(self.lib.slamx_batch_download_results_async(self.h, nframes, kps.ctypes.data, desc.ctypes.data,
+                                                           matches.ctypes.data, nk.ctypes.data, nm.ctypes.data))
 
     def set_profiling(self, n_sets=1, every=1):
         _check(self.lib.slamx_batch_set_profiling_every(self.h, n_sets, every))

@@ -963,6 +963,50 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
     return SLAMX_OK;
 }
 
+int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoint* kps, uint8_t* desc, slamx_match* matches,
+                                       int32_t* n_keypoints, int32_t* n_matches) {
+    if (b == nullptr || nframes < 0 || nframes > b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
+    }
+    if (nframes == 0) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    hipStream_t s = b->det->ctx->stream;
+    const size_t n = static_cast<size_t>(nframes);
+    const void* dsts[5] = {kps, desc, matches, n_keypoints, n_matches};
+    for (const void* p : dsts) {
+        if (p == nullptr) {
+            continue;
+        }
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_results_async needs page-locked host memory (slamx_host_alloc)");
+        }
+    }
+    if ((matches != nullptr || n_matches != nullptr) && b->matches == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "no matches computed on this batch");
+    }
+    // whole capacity-padded arrays, one copy each: the counts say how much of every frame's slice is valid
+    if (kps != nullptr) {
+        HIP_TRY(hipMemcpyAsync(kps, b->v.kps, n * b->v.maxK * sizeof(slamx_keypoint), hipMemcpyDeviceToHost, s));
+    }
+    if (desc != nullptr) {
+        HIP_TRY(hipMemcpyAsync(desc, b->v.desc, n * b->v.maxK * b->v.width, hipMemcpyDeviceToHost, s));
+    }
+    if (matches != nullptr) {
+        HIP_TRY(hipMemcpyAsync(matches, b->matches, n * b->v.maxK * sizeof(slamx_match), hipMemcpyDeviceToHost, s));
+    }
+    if (n_keypoints != nullptr) {
+        HIP_TRY(hipMemcpyAsync(n_keypoints, b->v.n_kp, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    if (n_matches != nullptr) {
+        HIP_TRY(hipMemcpyAsync(n_matches, b->n_matches, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    return SLAMX_OK;
+}
+
 int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride) {
     if (frame < 0 || frame >= b->shape.max_frames || out == nullptr || stride < b->v.cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or output buffer invalid");

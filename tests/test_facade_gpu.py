@@ -205,3 +205,10 @@ def test_loop_closure_config_checks(slamx, ref_data, tmp_path):
     ok = slamx.load_loop_closure_config(os.path.join(ref_data, "loop_closure.yml"))
     assert (ok.min_db_size, ok.min_frames_difference, ok.min_matches_for_pnp, ok.min_inliers_for_pnp, ok.ransac_max_iterations) == (2, 2, 20, 5, 100)
     assert ok.min_absolute_score == 0.005 and ok.relative_score_factor == 1.5 and ok.ransac_reprojection_threshold == 2.0
+
+
+def test_backend_program():
+    """slam::Map / slam::Backend (declared, never implemented, by the reference): Backend::run() optimises the newest
+    window of keyframes on its thread with the GPU Gauss-Newton and writes poses and points back into the map."""
+    text = _run([os.path.join(BIN, "test_backend")])
+    assert text.startswith("cost ")

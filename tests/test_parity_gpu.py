@@ -642,6 +642,32 @@ def test_batch_upload_async_from_pinned_memory(slamx, oracle):
         batch.upload_async(frames)  # pageable
 
 
+def test_batch_download_results_async(slamx, oracle):
+    """The streaming download: all results of a batch into page-locked memory with five queued copies."""
+    d = slamx.FeatureDetector(cfg_of(slamx, window=8))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.8))
+    frames = [synth(slamx, k, 200, 300, 250, rmin=4, rmax=24) for k in range(3)]
+    b = slamx.Batch(d, 200, 300, 3, 8192, 1024)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(3)
+    b.match_consecutive(m, 3, use_keypoints=True, first_train_frame=2)
+    bufs = b.result_buffers(3, 1024)
+    b.download_results_async(3, bufs)
+    d.ctx.synchronize()
+    kps, desc, matches, nk, nm = bufs
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    for k in range(3):
+        assert nk[k] == len(ref[k][0])
+        assert_records_equal(kps[k, : nk[k]], ref[k][0], "keypoints of frame %d" % k)
+        assert np.array_equal(desc[k, : nk[k]], ref[k][1])
+        t = (k - 1) % 3
+        want = oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], oracle.match_params(m.cfg))
+        assert_records_equal(matches[k, : nm[k]], want, "matches of frame %d" % k)
+    with pytest.raises(ValueError):  # pageable memory is refused, as for the uploads
+        b.download_results_async(3, (np.empty((3, 1024), slamx.KEYPOINT_DTYPE),) + bufs[1:])
+
+
 def test_batch_capacity_overflow_is_loud(slamx):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     frame = synth(slamx, 0, 240, 320, 1200, rmin=3, rmax=16)

@@ -1,0 +1,50 @@
+// test_backend -- exercises slam::Map / slam::Backend (the reference declares both and implements neither:
+// include/slam/backend/backend.hpp:10-18, map.hpp:9-21).  A simulated trajectory of 10 keyframes over 400 map
+// points, perturbed, is handed to Backend::run(); exit code 0 iff the optimisation reduced the
+// reprojection cost by more than 10x and the newest pose moved towards the truth.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include <slam/backend/backend.hpp>
+
+int main() {
+    std::mt19937 rng(7);
+    std::normal_distribution<double> n01(0.0, 1.0);
+    std::uniform_real_distribution<double> ux(-4, 6), uy(-2.5, 2.5), uz(4, 12);
+    const double fx = 1700, fy = 1700, cx = 960, cy = 540;
+    slam::Map map;
+    std::vector<std::array<double, 3>> centres;
+    for (int c = 0; c < 10; ++c) {
+        const std::array<double, 3> centre = {0.25 * c, 0.0, 0.05 * c};
+        centres.push_back(centre);
+        // identity rotation; held keyframes (the first two) exact, the others off by ~2 cm
+        const double s = c < 2 ? 0.0 : 0.02;
+        map.insertKeyframe({1, 0, 0, 0, 1, 0, 0, 0, 1}, {-centre[0] + s * n01(rng), -centre[1] + s * n01(rng), -centre[2] + s * n01(rng)});
+    }
+    for (int l = 0; l < 400; ++l) {
+        const std::array<double, 3> X = {ux(rng), uy(rng), uz(rng)};
+        const int id = map.insertMapPoint({X[0] + 0.05 * n01(rng), X[1] + 0.05 * n01(rng), X[2] + 0.05 * n01(rng)});
+        for (int c = 0; c < 10; ++c) {
+            const double px = X[0] - centres[c][0], py = X[1] - centres[c][1], pz = X[2] - centres[c][2];
+            const double u = fx * px / pz + cx + 0.3 * n01(rng), v = fy * py / pz + cy + 0.3 * n01(rng);
+            if (u >= 0 && u < 1920 && v >= 0 && v < 1080) {
+                map.addObservation(c, id, static_cast<float>(u), static_cast<float>(v));
+            }
+        }
+    }
+    slam::Backend::Options o;
+    o.fx = fx;
+    o.fy = fy;
+    o.cx = cx;
+    o.cy = cy;
+    slam::Backend backend(map, o);
+    const auto before = map.keyframe(9);
+    backend.run();
+    backend.join();
+    const auto after = map.keyframe(9);
+    const double e0 = std::fabs(before.t[0] + centres[9][0]) + std::fabs(before.t[1] + centres[9][1]) + std::fabs(before.t[2] + centres[9][2]);
+    const double e1 = std::fabs(after.t[0] + centres[9][0]) + std::fabs(after.t[1] + centres[9][1]) + std::fabs(after.t[2] + centres[9][2]);
+    std::printf("cost %.1f -> %.1f, newest keyframe off by %.4f -> %.4f\n", backend.initialCost(), backend.finalCost(), e0, e1);
+    return backend.finalCost() < 0.1 * backend.initialCost() && e1 < 0.5 * e0 ? 0 : 1;
+}
