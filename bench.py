@@ -66,6 +66,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # accumulate) measured on MI355X with tools/microbench/valu_peak.hip: 42.1 Tera lane-ops/s
 # (v_bcnt is half rate; full-rate int32 pairs reach 65.8).  SURVEY.md 8d's nominal 3.9e13 agrees.
 VALU_HAMMING_PEAK_GOPS = 42100.0
+# int8 matrix-core peak (dense): ~5 POP/s (MI355X_MICROARCH.md; v_mfma_i32_16x16x64_i8 = 32768 ops in 16 cycles per SIMD)
+MFMA_I8_PEAK_TOPS = 5000.0
 
 
 def load_product():
@@ -137,7 +139,7 @@ def pmc_traffic_bytes(kernel, batch):
     """2 x FETCH_SIZE + WRITE_SIZE of one launch of `kernel`: measured offline at 256 frames per launch
     (tools/collect_profiles.sh) and scaled to `batch` frames -- the per-frame traffic of these kernels
     does not depend on the batch."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_b256.csv")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_b256.csv")
     if not os.path.exists(path):
         return None
     scale = batch / 256.0
@@ -463,7 +465,22 @@ def main():
         kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
                      "brief": "brief_kernel", "nms_build": "nms_greedy_kernel", "sort": "sort_kernel",
                      "moments": "describe_fused_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
-        if dom == "match":
+        mfma_match = wl["max_kp"] >= mod.load_library().slamx_matcher_mfma_threshold()
+        if mfma_match:
+            kernel_of["match"] = "match_mfma_kernel"
+        if dom == "match" and mfma_match:
+            # large train sets: Hamming distances as int8 dot products on the matrix cores (match.hip): one
+            # v_mfma_i32_16x16x64_i8 per 16 x 16 pairs, K = 64 of which 48 carry data (46 bits + 2 augmenting terms)
+            ops = 2.0 * 64.0 * N * N * B
+            achieved = ops / (stage[dom] * 1e-3) / 1e12
+            roof = {"kernel": kernel_of[dom], "bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS,
+                    "unit": "TOP/s", "frac": achieved / MFMA_I8_PEAK_TOPS, "algorithmic_per_launch": ops,
+                    "pairs_per_s": N * N * B / (stage[dom] * 1e-3),
+                    "popcount_equivalent_Gops": 2.0 * live_words * N * N * B / (stage[dom] * 1e-3) / 1e9,
+                    "survey_ops_per_launch_256bit": 16.0 * N * N * B, "traffic": None,
+                    "note": "int8 MFMA ops issued (K padded to 64); the kernel is bound by the vector ALU's per-query "
+                            "bookkeeping beside the MFMAs, not by the matrix cores (DESIGN.md 4.12)"}
+        elif dom == "match":
             # executed algorithmic work: xor + popcount-accumulate per live 32-bit word per pair;
             # SURVEY.md 8d's figure (16 ops per 256-bit pair) is reported next to it
             ops = 2.0 * live_words * N * N * B
@@ -480,7 +497,7 @@ def main():
         roof["avg_launch_ms"] = stage[dom]
         # HBM traffic per launch from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
         # separate runs of this same command by tools/collect_profiles.sh ->
-        # profiles/r01_pmc_hbm_traffic_b256.csv), FETCH_SIZE doubled as the guide prescribes for
+        # profiles/r02_pmc_hbm_traffic_b256.csv), FETCH_SIZE doubled as the guide prescribes for
         # gfx950.  Check on fast_detect_kernel, whose compulsory traffic is known (every frame byte
         # once): 2 x 259 MB = 519 MB against 531 MB of frames.
         roof["traffic"] = pmc_traffic_bytes(roof["kernel"], B)

@@ -93,6 +93,11 @@ typedef struct slamx_batch slamx_batch;
 
 const char* slamx_last_error(void);
 const char* slamx_version(void);
+/* Train-set size (keypoint capacity of a batch / n2 of slamx_matcher_match) from which the matcher
+ * computes its all-pairs Hamming distances on the int8 matrix cores instead of with xor + popcount
+ * (descriptors with <= 62 live bits only; results are identical either way).  Built-in 6144,
+ * overridden by the environment variable SLAMX_MATCH_MFMA_MIN_KEYPOINTS. */
+int slamx_matcher_mfma_threshold(void);
 
 /* ---- context: one per GPU; owns (or borrows) the HIP stream all work is enqueued on. ---- */
 /* hip_stream == NULL: the context creates its own non-blocking stream. */

@@ -86,7 +86,7 @@ class BatchShape(C.Structure):
 
 # every symbol include/slamx.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "slamx_last_error", "slamx_version", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
+    "slamx_last_error", "slamx_version", "slamx_matcher_mfma_threshold", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
     "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
     "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",

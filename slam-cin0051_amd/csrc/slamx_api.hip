@@ -391,7 +391,8 @@ uint64_t splitmix64(uint64_t& s) {
 extern "C" {
 
 const char* slamx_last_error(void) { return g_last_error.c_str(); }
-const char* slamx_version(void) { return "slamx 0.1 (gfx950)"; }
+const char* slamx_version(void) { return "slamx 0.2 (gfx950)"; }
+int slamx_matcher_mfma_threshold(void) { return match_mfma_min_keypoints(); }
 
 int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
     if (out == nullptr) {

@@ -1,26 +1,52 @@
 #!/bin/bash
 # Collects the measurements that profiles/ holds for a round (run on the GPU box through gpurun):
-#   1. bench.py JSON lines for the three workloads (with the CPU baseline for the default one)
-#   2. rocprofv3 --kernel-trace --stats of the default bench command
-#   3. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command (HBM traffic)
+#   1. bench.py JSON lines for every workload (with the CPU baseline for the default one, c3p and c4)
+#   2. rocprofv3 --kernel-trace --stats of the default bench command, of c3 and of c4
+#   3. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the default command (HBM traffic)
 #   4. separate --pmc passes for the instruction mix (SQ_INSTS_*) and the busy counters (TA, VALU)
+#   5. matrix-core counters: FP64 MFMA of gn_accumulate_kernel (c4), int8 MFMA of match_mfma_kernel (c3)
+#   6. tools/microbench: sustained FP64 MFMA rate
 # usage: tools/collect_profiles.sh <tag>      (writes under gpurun_out/<tag>/)
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python bench.py --steps 10 --warmup 2 > "$out/bench_1080p_2k.json"
+echo "default done"
 python bench.py --batch 256 --steps 20 --warmup 3 --no-cpu-baseline --no-pcie > "$out/bench_1080p_2k_b256.json"
 python bench.py --workload c2 --steps 20 --warmup 3 --no-pcie > "$out/bench_c2.json"
 python bench.py --workload c3 --steps 10 --warmup 2 --no-pcie > "$out/bench_c3.json"
-rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pcie > "$out/bench_under_rocprof.json"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > /dev/null
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o write --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > /dev/null
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d "$out/pmc_insts" -o insts --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > /dev/null
-rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU -d "$out/pmc_busy" -o busy --output-format csv -- python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > /dev/null
-python tools/pmc_summary.py "$out/pmc_insts/insts_counter_collection.csv" > "$out/pmc_insts.csv"
-python tools/pmc_summary.py "$out/pmc_busy/busy_counter_collection.csv" > "$out/pmc_busy.csv"
-python tools/pmc_summary.py "$out/pmc_fetch/fetch_counter_collection.csv" > "$out/pmc_fetch.csv"
-python tools/pmc_summary.py "$out/pmc_write/write_counter_collection.csv" > "$out/pmc_write.csv"
+echo "c3 done"
+python bench.py --workload c3p --steps 5 --warmup 2 > "$out/bench_c3p.json"
+echo "c3p done"
+python bench.py --workload c4 --steps 20 --warmup 3 > "$out/bench_c4.json"
+echo "c4 done"
+./tools/microbench/mfma_f64_peak > "$out/mfma_f64_peak.txt"
+P="--no-cpu-baseline --no-pcie"
+rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 $P > "$out/bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats -d "$out/stats_c3" -o stats --output-format csv -- python bench.py --workload c3 --steps 5 --warmup 2 $P > "$out/bench_c3_under_rocprof.json"
+rocprofv3 --kernel-trace --stats -d "$out/stats_c4" -o stats --output-format csv -- python bench.py --workload c4 --steps 20 --warmup 3 $P > "$out/bench_c4_under_rocprof.json"
+echo "stats done"
+B="python bench.py --batch 256 --steps 3 --warmup 1 $P"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch --output-format csv -- $B > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o write --output-format csv -- $B > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d "$out/pmc_insts" -o insts --output-format csv -- $B > /dev/null
+rocprofv3 --kernel-trace --pmc TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU -d "$out/pmc_busy" -o busy --output-format csv -- $B > /dev/null
+echo "pmc default done"
+G="python bench.py --workload c4 --steps 4 --warmup 1 $P"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$out/pmc_gn" -o gn --output-format csv -- $G > /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_gn_fetch" -o gnf --output-format csv -- $G > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_gn_write" -o gnw --output-format csv -- $G > /dev/null
+M="python bench.py --workload c3 --batch 128 --steps 2 --warmup 1 $P"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$out/pmc_match" -o mm --output-format csv -- $M > /dev/null
+echo "pmc mfma done"
+for n in insts busy fetch write gn gn_fetch gn_write match; do
+    f=$(find "$out/pmc_$n" -name "*counter_collection.csv" | head -1)
+    python tools/pmc_summary.py "$f" > "$out/pmc_$n.csv"
+done
+for n in stats stats_c3 stats_c4; do
+    f=$(find "$out/$n" -name "*kernel_stats.csv" | head -1)
+    cp "$f" "$out/${n}_kernel_stats.csv"
+done
 ls -la "$out"
