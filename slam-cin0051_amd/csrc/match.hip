@@ -273,8 +273,10 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
 //     rows) passes from the sign of their OR: 8 v_or3 + 1 compare per 4 MFMAs;
 //   * a passing (lane, tile) -- a few per cent of them -- is appended to a per-WAVE FIFO in LDS, and
 //     whenever 64 entries wait the whole wave works them off, one entry per lane whoever pushed it:
-//     xor + popcount of the 16 pairs from the compact bits; the one or two of them that still reach the
-//     query's current `second` go to a second FIFO of PAIRS, which is settled 64 at a time as well:
+//     xor + popcount of the 16 pairs from the compact bits (read from global memory: entries carry train
+//     indices, not positions in the LDS stage, so nothing is flushed half-full when a stage is replaced);
+//     the one or two of them that can still change the query's keys go to a second FIFO of PAIRS, which
+//     is settled 64 at a time as well:
 //     the reference's penalty arithmetic (with every pair slot of the first level taking it, at one
 //     active lane in 64, it was two thirds of the kernel's instructions) and the update of the
 //     query's state, which lives in LDS as two 64-bit keys (distance << 32 | train index):
@@ -293,7 +295,7 @@ constexpr int MM_XSTRIDE = 80;   // bytes between staged expanded descriptors: 1
 constexpr int MM_QT = 4;         // query tiles (of 16) per wave: 64 queries per wave, 256 per workgroup
 constexpr int MM_FIFO = 256;     // ring capacity per wave: < 64 waiting + the 64 pushes of one train tile
 constexpr int MM_TRASH = MM_FIFO;  // one more slot: where the lanes that do not pass write
-constexpr int MM_PAIRS = 128;    // pair ring per wave: < 64 waiting + the 64 pushes of one pair slot
+constexpr int MM_PAIRS = 512;    // pair ring per wave: < 64 waiting + the 4 x 64 pushes of one query tile
 constexpr int MM_MAX_BITS = 62;
 constexpr unsigned long long MM_KEY_NONE = 0x7fffffffffffffffull;  // distance INT_MAX, index -1
 
@@ -334,17 +336,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                                                                   int stride, int npairs,
                                                                                                   int qblocks) {
     __shared__ __attribute__((aligned(16))) uint8_t xt[MM_STAGE * MM_XSTRIDE];
-    __shared__ uint2 tbits[MM_STAGE];
-    __shared__ float2 txy[MM_STAGE];
     __shared__ uint4 qtab[4][16 * MM_QT];                  // per wave and query: compact bits (x, y), position (z, w as float bits)
     __shared__ unsigned long long keys[4][16 * MM_QT][2];  // per wave and query: best_key, second_key
-    __shared__ uint16_t fifo[4][MM_FIFO + 64];             // per wave: lane | train tile << 6
-    __shared__ uint32_t pairq[4][MM_PAIRS + 64];           // per wave: query | train << 8 | raw distance << 16
+    __shared__ uint32_t fifo[4][MM_FIFO + 64];             // per wave: lane | first train index of the tile << 6
+    __shared__ uint32_t pairq[4][MM_PAIRS + 64];           // per wave: query | raw distance << 8 | train index << 16
     constexpr int QW = 16 * MM_QT;                         // queries per wave
-    const int pair = static_cast<int>(blockIdx.x) % npairs;
-    const int rest = static_cast<int>(blockIdx.x) / npairs;
-    const int qblock = rest % qblocks;
-    const int split = rest / qblocks;
+    // Workgroups are dealt to the 8 XCDs round-robin.  An XCD takes its pairs ONE AFTER THE OTHER (all query
+    // blocks and train chunks of a pair on consecutive ids of that XCD): the workgroups resident on an XCD then
+    // belong to ~3 pairs and their train descriptors (64 expanded bytes each, 0.7 MB per 10k-keypoint frame,
+    // re-read by every query block) stay in its 4 MB L2.  With the pair index fastest -- the popcount kernel's
+    // order, fine for its 8-byte descriptors -- 32 pairs were in flight per XCD and the staging loads went to
+    // the Infinity Cache / HBM (7 GB per step at 10k keypoints).
+    int pair, qblock, split;
+    {
+        const int id = static_cast<int>(blockIdx.x);
+        const int per_pair = qblocks * mv.nsplit;
+        if (npairs >= 8) {
+            const int k = id >> 3;
+            pair = (id & 7) + 8 * (k / per_pair);
+            const int in_pair = k - (k / per_pair) * per_pair;
+            qblock = in_pair % qblocks;
+            split = in_pair / qblocks;
+            if (pair >= npairs) {
+                return;
+            }
+        } else {
+            pair = id % npairs;
+            const int rest = id / npairs;
+            qblock = rest % qblocks;
+            split = rest / qblocks;
+        }
+    }
     const int qf = first_query_frame + pair;
     const int tf = qf == 0 ? first_train_frame : qf - 1;
     const int n1 = mv.n_kp[qf];
@@ -402,29 +424,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                        static_cast<int>(w3)};
         }
     }
-    uint16_t* const myfifo = fifo[wave];
+    uint32_t* const myfifo = fifo[wave];
     uint32_t* const mypairs = pairq[wave];
     int head = 0, tail = 0;    // tile FIFO: ring positions (wave-uniform, kept in SGPRs); entries [head, tail)
     int phead = 0, ptail = 0;  // pair FIFO
     // level 2: `count` (<= 64) pairs from the head of the pair FIFO, one per lane: the reference's penalty
     // arithmetic (feature_matcher.cpp:161-170) and the update of the query's two keys
-    auto settle = [&](int count, int t0) {
+    const slamx_keypoint* tkps = use_kp ? mv.kps + static_cast<size_t>(tf) * mv.maxK : nullptr;
+    auto settle = [&](int count) {
         if (lane < count) {
             const uint32_t e = mypairs[(phead + lane) & (MM_PAIRS - 1)];
             const int q = static_cast<int>(e & 0xffu);
-            const int t = static_cast<int>(e >> 8 & 0xffu);
-            int dist = static_cast<int>(e >> 16);
+            int dist = static_cast<int>(e >> 8 & 0xffu);
+            const int t = static_cast<int>(e >> 16);
             unsigned long long* key = keys[wave][q];
             const int sec = static_cast<int>(key[1] >> 32);  // may have shrunk since the pair was queued
             if (dist <= sec) {
                 if (use_kp) {
                     const uint4 qv = qtab[wave][q];
-                    const float2 p = txy[t];
+                    const float2 p = *reinterpret_cast<const float2*>(&tkps[t]);  // x, y lead the keypoint record
                     dist = penalised_distance(dist, __uint_as_float(qv.z), __uint_as_float(qv.w), p.x, p.y);
                 }
                 if (dist <= sec) {
                     const unsigned long long k = (static_cast<unsigned long long>(static_cast<uint32_t>(dist)) << 32) |
-                                                 static_cast<uint32_t>(t0 + t);
+                                                 static_cast<uint32_t>(t);
                     const unsigned long long old = atomicMin(&key[0], k);
                     atomicMin(&key[1], old > k ? old : k);
                 }
@@ -435,32 +458,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     // level 1: `count` (<= 64) entries from the head of the tile FIFO, one per lane: entry = (lane L, tile) stands
     // for the 16 pairs {query u * 16 + (L & 15)} x {train 16 tile + 4 (L >> 4) + r}; their distances are
     // recomputed with xor + popcount and the ones that still reach the query's `second` go to the pair FIFO
-    auto work = [&](int count, int t0, int tn) {
+    auto work = [&](int count, int t_end) {
         const bool valid = lane < count;
         const uint32_t e = myfifo[(head + lane) & (MM_FIFO - 1)];
         const int ec = static_cast<int>(e & 15u);
-        const int trow = static_cast<int>(e >> 6) * 16 + 4 * static_cast<int>(e >> 4 & 3u);
-        // a loop, not unrolled: `settle` (with the penalty arithmetic inside) is then instantiated once
+        const int trow = static_cast<int>(e >> 6) + 4 * static_cast<int>(e >> 4 & 3u);
+        // the compact bits of the four trains come from global memory (L2): entries outlive the LDS stage they
+        // were found in, so nothing has to be flushed when the stage is replaced
+        uint2 tb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = valid ? min(trow + r, t_end - 1) : 0;
+            tb[r] = make_uint2(td[static_cast<size_t>(t) * stride], stride > 1 ? td[static_cast<size_t>(t) * stride + 1] : 0u);
+        }
+        // a loop over the query tiles, not unrolled: `settle` (with the penalty arithmetic inside) is instantiated once
 #pragma unroll 1
-        for (int slot16 = 0; slot16 < 4 * MM_QT; ++slot16) {
-            const int q = (slot16 >> 2) * 16 + ec;
-            const int t = trow + (slot16 & 3);
+        for (int u = 0; u < MM_QT; ++u) {
+            const int q = u * 16 + ec;
             const uint2 qb = *reinterpret_cast<const uint2*>(&qtab[wave][q]);
-            const uint2 tb = tbits[t & (MM_STAGE - 1)];
+            const int bestd = static_cast<int>(keys[wave][q][0] >> 32);
             int sec = static_cast<int>(keys[wave][q][1] >> 32);
-            sec = valid ? sec : -1;  // lanes without an entry queue nothing
-            const int dist = __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y);
-            const bool pass = dist <= sec && t < tn;
-            const unsigned long long pm = __ballot(pass);
-            if (pm != 0) {  // wave-uniform
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
-                const uint32_t slot = pass ? ((static_cast<uint32_t>(ptail) + rank) & (MM_PAIRS - 1)) : static_cast<uint32_t>(MM_PAIRS);
-                mypairs[slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(t) << 8) | (static_cast<uint32_t>(dist) << 16);
-                ptail += __popcll(pm);
-                if (ptail - phead >= 64) {
-                    settle(64, t0);
+            // A pair that merely TIES with `second` changes an output only if it also ties with `best` and has
+            // the lower index; with best < second it could at most replace the second key by an equal distance.
+            const int limit = valid ? (bestd == sec ? sec : sec - 1) : -1;  // lanes without an entry queue nothing
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = trow + r;
+                const int dist = __popc(qb.x ^ tb[r].x) + __popc(qb.y ^ tb[r].y);
+                const bool pass = dist <= limit && t < t_end;
+                const unsigned long long pm = __ballot(pass);
+                if (pm != 0) {  // wave-uniform
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+                    const uint32_t slot = pass ? ((static_cast<uint32_t>(ptail) + rank) & (MM_PAIRS - 1)) : static_cast<uint32_t>(MM_PAIRS);
+                    mypairs[slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(dist) << 8) | (static_cast<uint32_t>(t) << 16);
+                    ptail += __popcll(pm);
                 }
+            }
+            while (ptail - phead >= 64) {
+                settle(64);
             }
         }
         head += count;
@@ -480,7 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         const int tn = min(MM_STAGE, t_end - t0);
         __syncthreads();
         {
-            // thread t stages train descriptor t0 + t: 64 expanded bytes, its compact bits, its position
+            // thread t stages train descriptor t0 + t: its 64 expanded bytes
             const int t = threadIdx.x;
             uint4 x0, x1, x2, x3;
             if (t < tn) {
@@ -489,18 +525,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 x1 = src[1];
                 x2 = src[2];
                 x3 = src[3];
-                tbits[t] = make_uint2(td[static_cast<size_t>(t0 + t) * stride],
-                                      stride > 1 ? td[static_cast<size_t>(t0 + t) * stride + 1] : 0u);
-                if (use_kp) {
-                    const slamx_keypoint k = mv.kps[static_cast<size_t>(tf) * mv.maxK + t0 + t];
-                    txy[t] = make_float2(k.x, k.y);
-                }
             } else {
                 // past the end of the train set: distance 127 + |q|, which no bound below 127 lets through
                 // (and the slow path checks the index anyway)
                 x0 = x1 = x2 = make_uint4(0u, 0u, 0u, 0u);
                 x3 = make_uint4(0u, 0u, 0u, 0x017f0000u);
-                tbits[t] = make_uint2(0u, 0u);
             }
             uint4* dst = reinterpret_cast<uint4*>(xt + t * MM_XSTRIDE);
             dst[0] = x0;
@@ -534,23 +563,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
             // branch-free: every lane stores, the ones that do not pass into the trash slot
             const uint32_t slot = pass ? ((static_cast<uint32_t>(tail) + rank) & (MM_FIFO - 1)) : static_cast<uint32_t>(MM_TRASH);
-            myfifo[slot] = static_cast<uint16_t>(lane | (tile << 6));
+            myfifo[slot] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t0 + tile * 16) << 6);
             tail += __popcll(pm);
             if (tail - head >= 64) {  // wave-uniform
                 do {
-                    work(64, t0, tn);
+                    work(64, t_end);
                 } while (tail - head >= 64);
                 refresh_bounds();
             }
         }
-        // entries are stage-relative and the stage is about to be replaced
+    }
+    if (wave_has_queries) {  // end of the scan: what is still waiting
         while (tail - head > 0) {
-            work(min(64, tail - head), t0, tn);
+            work(min(64, tail - head), t_end);
         }
         while (ptail - phead > 0) {
-            settle(min(64, ptail - phead), t0);
+            settle(min(64, ptail - phead));
         }
-        refresh_bounds();
     }
     for (int k = lane; k < QW; k += 64) {
         const int i = wave_first + k;
@@ -702,7 +731,7 @@ void launch_match_consecutive(const MatchView& mv, int first_query_frame, int np
         return;
     }
     const int stride = mv.width / 4;
-    if (mv.xdesc != nullptr && mv.width % 4 == 0 && mv.live_bits > 0 && mv.live_bits <= MM_MAX_BITS) {
+    if (mv.xdesc != nullptr && mv.width % 4 == 0 && mv.live_bits > 0 && mv.live_bits <= MM_MAX_BITS && mv.maxK <= 65536) {  // (pair entries hold the train index in 16 bits)
         // expanded descriptors of every frame that is a query or a train set of this call, then the matrix-core scan
         const int qblocks = (mv.maxK + 64 * MM_QT - 1) / (64 * MM_QT);
         // frames in use: the queries, their predecessors, and first_train_frame when frame 0 is a query
@@ -715,7 +744,8 @@ void launch_match_consecutive(const MatchView& mv, int first_query_frame, int np
             hipLaunchKernelGGL(xdesc_kernel, g1, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc,
                                first_train_frame);
         }
-        dim3 grid(static_cast<unsigned>(qblocks) * npairs * mv.nsplit);
+        const int pair_slots = npairs >= 8 ? 8 * ((npairs + 7) / 8) : npairs;
+        dim3 grid(static_cast<unsigned>(qblocks) * pair_slots * mv.nsplit);
         hipLaunchKernelGGL(match_mfma_kernel, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame, stride,
                            npairs, qblocks);
     } else if (mv.width % 4 == 0 && stride <= 16) {
