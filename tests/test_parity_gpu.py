@@ -449,6 +449,31 @@ def test_match_live_bit_prefix(slamx, oracle, bits, n1, n2, mfma_scan_for_all_si
                                  "live bits %d kp=%s ratio=%s" % (bits, kp, ratio_on))
 
 
+@pytest.mark.parametrize("width,bits", [(4, 20), (4, 32), (8, 50), (8, 62), (16, 46), (64, 46)])
+def test_match_matrix_core_scan_descriptor_widths(slamx, oracle, width, bits, mfma_scan_for_all_sizes):
+    """One-word and two-word descriptors and long ones whose tail is zero through the matrix-core scan."""
+    rng = np.random.default_rng(width * 100 + bits)
+    n1, n2 = 300, 1000
+    mask = np.frombuffer(np.uint64((1 << bits) - 1).tobytes(), np.uint8)[: min(width, 8)]
+
+    def make(n):
+        d = np.zeros((n, width), np.uint8)
+        d[:, : min(width, 8)] = rng.integers(0, 256, (n, min(width, 8)), dtype=np.uint8) & mask
+        return d
+
+    d1, d2 = make(n1), make(n2)
+    d2[rng.integers(0, n2, 300)] = d1[rng.integers(0, n1, 300)]
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.integers(0, 1920, len(k))
+        k["y"] = rng.integers(0, 1080, len(k))
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.9))
+    for a1, a2 in ((k1, k2), (None, None)):
+        assert_records_equal(m.match(d1, d2, a1, a2), oracle.match(d1, d2, a1, a2, oracle.match_params(m.cfg)),
+                             "width %d, %d live bits" % (width, bits))
+
+
 def test_match_large_train_set_takes_the_matrix_core_scan(slamx, oracle):
     """7000 train descriptors with 46 live bits: above the built-in threshold, no override."""
     rng = np.random.default_rng(77)

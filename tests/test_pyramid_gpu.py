@@ -83,6 +83,20 @@ def test_pyramid_batch_with_matching(slamx, oracle, window, n_levels, scale):
     assert np.array_equal(b.counts(len(frames))[1], nkp)
 
 
+@pytest.mark.parametrize("pairs", [8, 24, 64])
+def test_pyramid_narrow_descriptors(slamx, oracle, pairs):
+    """Descriptor widths that are not a multiple of 4 bytes (1, 3 bytes) take the byte-wise merge kernel."""
+    det = slamx.FeatureDetector(cfg_of(slamx, window=8, patch=15, pairs=pairs))
+    P = oracle.det_params(det.cfg)
+    img = synth(slamx, 2, 240, 360, 500, rmin=3, rmax=20)
+    pyr = run_pyramid(slamx, det, [img], 4, 1.3, max_cand=16384)
+    k_got, d_got = pyr.level(0).download(0)
+    k_ref, d_ref = oracle.pyramid_detect_and_compute(img, P, 4, 1.3)
+    assert d_ref.shape[1] == pairs // 8
+    assert_records_equal(k_got, k_ref, "keypoints, %d pairs" % pairs)
+    assert np.array_equal(d_got, d_ref)
+
+
 def test_pyramid_merged_capacity_overflow_is_loud(slamx):
     det = slamx.FeatureDetector(cfg_of(slamx, window=6))
     img = synth(slamx, 0, 300, 420, 700, rmin=3, rmax=24)
