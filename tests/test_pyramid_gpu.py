@@ -117,3 +117,26 @@ def test_pyramid_argument_errors(slamx):
         slamx.Pyramid(det, 100, 100, 1, 4, 1.0)
     with pytest.raises(ValueError):
         slamx.Pyramid(det, 20, 20, 1, 8, 1.5)  # the last levels would be smaller than 8 pixels
+
+
+def test_full_size_pyramid_workload_bit_exact(slamx, oracle):
+    """bench.py's c3p workload itself (1080p, 8 levels, shipped YAML, ~12.5k keypoints per frame over all
+    levels), two consecutive frames: merged keypoints, descriptors and the matches of both directions (1.6e8
+    pairs each, through the matrix-core scan) against the oracle."""
+    det = slamx.FeatureDetector(cfg_of(slamx, window=12))
+    P = oracle.det_params(det.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 20, 1, 0.5))
+    mp = oracle.match_params(m.cfg)
+    frames = [synth(slamx, k, 1080, 1920, 6800, rmin=3, rmax=24) for k in range(2)]
+    pyr = run_pyramid(slamx, det, frames, 8, 1.2, max_cand=32768, max_kp=16384)
+    b = pyr.level(0)
+    b.match_consecutive(m, 2, use_keypoints=True, first_train_frame=1)
+    ref = [oracle.pyramid_detect_and_compute(f, P, 8, 1.2) for f in frames]
+    for k in range(2):
+        k_got, d_got = b.download(k)
+        assert_records_equal(k_got, ref[k][0], "c3p frame %d keypoints" % k)
+        assert np.array_equal(d_got, ref[k][1])
+    assert len(ref[0][0]) > 11000
+    for q, t_ in ((1, 0), (0, 1)):
+        want = oracle.match(ref[q][1], ref[t_][1], ref[q][0], ref[t_][0], mp)
+        assert_records_equal(b.download_matches(m, q), want, "c3p matches %d->%d" % (q, t_))
