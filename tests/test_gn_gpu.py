@@ -191,3 +191,24 @@ def test_argument_errors(slamx):
         gn.iterate(w["K"], 0.0, 1, 65)
     with pytest.raises(ValueError):
         gn.upload(w["poses0"][None], np.zeros((1, 10, 3)), np.zeros((1, 10, 4, 2), np.float32), np.array([11], np.int32))
+
+
+def test_full_size_windows_of_the_c4_workload(slamx, oracle):
+    """bench.py's c4 windows themselves (10 poses x 2048 landmarks, ~13.4k observations): one step against the CPU
+    statement with per-landmark elimination (the dense one would need a 6204 x 6204 Cholesky per window; the two
+    CPU formulations are compared with each other at small sizes in tests/test_gn_cpu.py)."""
+    W, L, lam, n_fixed = 10, 2048, 1e-4, 2
+    windows = [gn_scene.make_window(0x5EED0051 * 1000 + k, W, L) for k in range(3)]
+    for w in windows:
+        w["poses0"][:n_fixed] = w["poses_gt"][:n_fixed]
+    gn = upload(slamx, windows)
+    gn.iterate(windows[0]["K"], lam, n_fixed, 1)
+    poses, X, cost, status = gn.download()
+    assert not status.any()
+    for i, w in enumerate(windows):
+        c0, p_ref, X_ref = oracle.gn_step_schur(w["poses0"], w["X0"], w["obs"], w["K"], lam, n_fixed)
+        assert cost[i, 0] == pytest.approx(c0, rel=COST_RTOL)
+        np.testing.assert_allclose(poses[i], p_ref, rtol=0, atol=STEP_ATOL)
+        np.testing.assert_allclose(X[i], X_ref, rtol=0, atol=X_ATOL)
+        assert cost[i, 1] == pytest.approx(oracle.gn_cost(p_ref, X_ref, w["obs"], w["K"], lam), rel=1e-7)
+        assert cost[i, 1] < 0.05 * cost[i, 0]
