@@ -27,7 +27,9 @@ data-path collective; at the end of the timed job every rank triangulates its ne
 and the map points are exchanged with one RCCL all_gather (counts + padded points).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-dominant kernel and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N == 1 only).
+dominant kernel and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N == 1 only).  The default
+run on one GPU also carries `other_workloads`: short runs of c3 / c3p / c4 (child processes, after the timed
+region), so that BASELINE.json's other single-GPU configs are measured by whoever runs the default command.
 """
 import argparse
 import ctypes
@@ -348,6 +350,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-upload-inclusive leg (N == 1 only)")
     ap.add_argument("--no-keypoints", action="store_true", help="diagnostic: match without the jump-radius penalty")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default workload only: skip the short runs of c3 / c3p / c4 reported under other_workloads")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -542,10 +546,37 @@ def main():
                                                    not args.no_keypoints)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mod, wl, frames)
+        if n_gpus == 1 and args.workload == "1080p_2k" and not args.no_extras:
+            out["other_workloads"] = other_workloads()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_workloads():
+    """Short runs of BASELINE.json's other single-GPU configs (configs[2] with and without the pyramid, configs[3]),
+    each in a child process after this run's timed region: their headline numbers travel with the default line.
+    Full lines with the CPU baselines: profiles/r02_bench_c3.json, _c3p.json, _c4.json."""
+    import subprocess
+
+    res = {}
+    for name, extra in (("c3", ["--steps", "5", "--warmup", "2"]), ("c3p", ["--steps", "3", "--warmup", "1"]),
+                        ("c4", ["--steps", "20", "--warmup", "3"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-pcie", "--no-extras"] + extra
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            res[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                         "workload": d["config"]["workload"], "dtype": d["dtype"],
+                         "roofline": {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
+            for k in ("keypoints_per_frame", "candidates_per_frame", "observations_per_window"):
+                if k in d["config"]:
+                    res[name][k] = d["config"][k]
+        except Exception as e:  # a failed extra must not take the headline line down
+            res[name] = {"error": repr(e)[:200]}
+    return res
 
 
 if __name__ == "__main__":
