@@ -1,5 +1,6 @@
 // match.hip -- brute-force Hamming 1-NN with second-best tracking, jump-radius penalty and
-// Lowe ratio test.
+// Lowe ratio test.  Two all-pairs scans with identical results: match_kernel (xor + popcount, below) and
+// match_mfma_kernel (int8 matrix cores, further down; taken for train sets of >= 6144 keypoints).
 //
 // Reference (paths relative to the reference root):
 //   calculateHammingDistance   include/slam/common/common.hpp:40-50   (byte LUT popcount)
@@ -288,8 +289,10 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
 // The slow path thus runs on full waves, needs no per-lane state and leaves no merge for the end.
 // Filtering with strict '<' is exact: when the filter of a train tile runs, the keys hold only pairs of
 // EARLIER tiles (lower indices), so a pair that merely ties with `second` cannot be one of the two
-// smallest keys; inside a batch of 64, where two lanes may update one query at the same time, the
-// pre-test is '<=' and the index part of the keys decides.
+// smallest keys.  Behind the filter, where entries of different tiles are worked off together and two
+// lanes may update one query at the same time, the index part of the keys decides: a tie with
+// `second` is let through when it also ties with `best` (it may carry the lower index), and dropped
+// otherwise (it could only replace the second key by one of the same distance).
 constexpr int MM_STAGE = 256;    // train descriptors staged in LDS at a time
 constexpr int MM_XSTRIDE = 80;   // bytes between staged expanded descriptors: 16 lanes x 16 B then cover all 64 banks
 constexpr int MM_QT = 4;         // query tiles (of 16) per wave: 64 queries per wave, 256 per workgroup
