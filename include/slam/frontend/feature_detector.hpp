@@ -42,7 +42,10 @@ public:
         detail::check(slamx_detector_config_load(configPath.string().c_str(), &cfg));
         detail::check(slamx_detector_create(detail::default_context(), &cfg, &m_handle));
     }
-    ~FeatureDetector() { slamx_detector_destroy(m_handle); }
+    ~FeatureDetector() {
+        slamx_pyramid_destroy(m_pyramid);
+        slamx_detector_destroy(m_handle);
+    }
     FeatureDetector(const FeatureDetector&) = delete;
     FeatureDetector& operator=(const FeatureDetector&) = delete;
 
@@ -71,6 +74,47 @@ public:
                           DescriptorMatrix& descriptors) {
         keypoints.clear();
         run_sized(image, keypoints, &descriptors);
+    }
+
+    // EXTENSION, no reference counterpart (the reference detects at full resolution only, feature_detector.cpp:8-18;
+    // BASELINE.json configs[2] asks for an 8-level pyramid): the same detector on every level of an image pyramid
+    // (level l = cvRound(size / scaleFactor^l), integer bilinear downscale), results of all levels in one list with
+    // x, y and size scaled to the full-resolution frame (Keypoint::size = 6 * scaleFactor^l tells the level).
+    void detectAndComputePyramid(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints, DescriptorMatrix& descriptors,
+                                 int nLevels = 8, double scaleFactor = 1.2) {
+        const int rows = static_cast<int>(image.rows());
+        const int cols = static_cast<int>(image.cols());
+        if (m_pyramid == nullptr || rows != m_pyrRows || cols != m_pyrCols || nLevels != m_pyrLevels || scaleFactor != m_pyrScale) {
+            slamx_pyramid_destroy(m_pyramid);
+            m_pyramid = nullptr;
+            slamx_batch_shape shape{};
+            shape.rows = rows;
+            shape.cols = cols;
+            shape.max_frames = 1;
+            shape.max_candidates = std::max(1024, rows * cols / 4);
+            shape.max_keypoints = std::max(1024, rows * cols / 8);
+            detail::check(slamx_pyramid_create(m_handle, &shape, nLevels, scaleFactor, &m_pyramid));
+            m_pyrRows = rows;
+            m_pyrCols = cols;
+            m_pyrLevels = nLevels;
+            m_pyrScale = scaleFactor;
+        }
+        slamx_batch* level0 = slamx_pyramid_batch(m_pyramid, 0);
+        detail::check(slamx_batch_upload(level0, 0, 1, image.data(), cols, 0));
+        detail::check(slamx_pyramid_detect_and_compute(m_pyramid, 1));
+        const int width = slamx_detector_descriptor_width(m_handle);
+        int n = 0;
+        int rc = slamx_batch_download(level0, 0, nullptr, nullptr, 0, &n);  // the count first
+        if (rc != SLAMX_OK && rc != SLAMX_ERR_CAPACITY) {
+            detail::check(rc);
+        }
+        keypoints.resize(static_cast<size_t>(n));
+        if (n == 0) {
+            descriptors = DescriptorMatrix(0, 0);
+            return;
+        }
+        descriptors.resize(n, width);
+        detail::check(slamx_batch_download(level0, 0, reinterpret_cast<slamx_keypoint*>(keypoints.data()), descriptors.data(), n, &n));
     }
 
 private:
@@ -113,6 +157,9 @@ private:
     }
 
     slamx_detector* m_handle{};
+    slamx_pyramid* m_pyramid{};  // lazily created by detectAndComputePyramid, one frame deep
+    int m_pyrRows{}, m_pyrCols{}, m_pyrLevels{};
+    double m_pyrScale{};
 };
 
 }  // namespace slam

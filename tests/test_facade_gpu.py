@@ -79,6 +79,16 @@ def test_cli_runs_the_pipeline(ref_data):
     assert _run([os.path.join(BIN, "cli"), "-h"]).startswith("cli -c")
 
 
+def test_cli_pyramid_option(ref_data, oracle, slamx):
+    """-p 4: the facade's detectAndComputePyramid; the keypoint count of the first frame is the oracle's."""
+    text = _run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images_test_loop"), "-p", "4"])
+    lines = [l for l in text.splitlines() if l.startswith("frame ")]
+    img = load_gray(os.path.join(ref_data, "images_test_loop", "0.png"))
+    P = oracle.det_params(slamx.load_detector_config(os.path.join(ref_data, "feature_detector.yml")))
+    k_ref, _ = oracle.pyramid_detect_and_compute(img, P, 4, 1.2)
+    assert len(lines) == 4 and ("%d keypoints" % len(k_ref)) in lines[0] and len(k_ref) > 59
+
+
 def test_cli_estimates_the_pose_between_kitti_frames(ref_data):
     """camera.yml present -> PoseEstimator::estimate + triangulatePoints on the matches (the two KITTI
     frames are 0.1 s apart on a forward-driving car: small rotation, translation mostly along z)."""

@@ -2,12 +2,14 @@
 // reference's stub SLAMModel (src/model/model.cpp:5-7 is empty, run() is never defined), actually
 // drives the hot path: frame directory -> detectAndCompute -> match(frame k, frame k-1) and, when the
 // config directory also holds a camera.yml, PoseEstimator::estimate + triangulatePoints on the matches.
-//   cli -c <config dir with feature_detector.yml + feature_matcher.yml [+ camera.yml]> -v <directory of PNG frames>
+//   cli -c <config dir with feature_detector.yml + feature_matcher.yml [+ camera.yml]> -v <directory of PNG frames> [-p <levels>]
+// -p (an extension: the reference has no pyramid) runs the detector on an image pyramid of that many levels.
 #include <getopt.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <filesystem>
 #include <string>
 #include <vector>
@@ -19,9 +21,10 @@
 #include <slam/preprocessing/png_gray.hpp>
 
 static void printHelp() {
-    std::printf("cli -c <config_dir> -v <stream_path>\n"
+    std::printf("cli -c <config_dir> -v <stream_path> [-p <levels>]\n"
                 "  -c  directory holding feature_detector.yml and feature_matcher.yml\n"
                 "  -v  directory of 8-bit PNG frames (processed in lexical order)\n"
+                "  -p  detect on an image pyramid of this many levels (scale 1.2); default: full resolution only\n"
                 "  -h  this help\n");
 }
 
@@ -29,7 +32,8 @@ int main(int argc, char** argv) {
     int c{};
     std::string streamPath{};
     std::string configPath{};
-    while ((c = getopt(argc, argv, "hv:c:")) != -1) {
+    int pyramidLevels = 0;
+    while ((c = getopt(argc, argv, "hv:c:p:")) != -1) {
         switch (c) {
             case 'h':
                 printHelp();
@@ -39,6 +43,9 @@ int main(int argc, char** argv) {
                 break;
             case 'c':
                 configPath = optarg;
+                break;
+            case 'p':
+                pyramidLevels = std::atoi(optarg);
                 break;
             default:
                 printHelp();
@@ -72,7 +79,11 @@ int main(int argc, char** argv) {
             slam::EigenGrayMatrix image = slamx_tools::read_png_gray(files[i].string());
             std::vector<slam::Keypoint> kps;
             slam::DescriptorMatrix desc;
-            detector.detectAndCompute(image, kps, desc);
+            if (pyramidLevels > 1) {
+                detector.detectAndComputePyramid(image, kps, desc, pyramidLevels, 1.2);
+            } else {
+                detector.detectAndCompute(image, kps, desc);
+            }
             std::vector<slam::Match> matches;
             if (i > 0 && !kps.empty() && !prevKps.empty()) {
                 matcher.match(desc, prevDesc, matches, kps, prevKps);
