@@ -34,7 +34,10 @@
 //   * gn_backsub_kernel re-linearises (same device function, same values) and updates the landmarks.
 #include "slamx_internal.h"
 
-#pragma clang fp contract(off)
+// Nothing in this file is pinned to a reference that computes without FMA (the Makefile's -ffp-contract=off is
+// for the parity-pinned front end): contraction is allowed here, results are compared with the CPU statement
+// at 1e-9 relative.
+#pragma clang fp contract(fast)
 
 namespace slamx {
 
@@ -74,6 +77,21 @@ __device__ __forceinline__ double sum16(double v) {
     return v;
 }
 
+// 1 / x and 1 / sqrt(x) from the hardware estimates plus two Newton steps (full f64 accuracy to a few ulps);
+// the IEEE-exact division / square root sequences cost ~25 instructions each, and the kernel has 4 per lane and chunk.
+__device__ __forceinline__ double gn_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ double gn_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+
 struct GnObs {
     bool valid;
     double r[2];
@@ -93,7 +111,7 @@ __device__ __forceinline__ GnObs gn_linearize(const double* pose, double X0, dou
     }
     // finite(u), finite(v): x - x == 0 fails for NaN and +-inf
     o.valid = (u - u == 0.0) && (v - v == 0.0) && p[2] > 1e-9;
-    const double iz = 1.0 / (o.valid ? p[2] : 1.0);
+    const double iz = gn_rcp(o.valid ? p[2] : 1.0);
     o.r[0] = fx * p[0] * iz + cx - u;
     o.r[1] = fy * p[1] * iz + cy - v;
     const double Jp[2][3] = {{fx * iz, 0.0, -fx * p[0] * iz * iz}, {0.0, fy * iz, -fy * p[1] * iz * iz}};
@@ -136,22 +154,24 @@ __device__ __forceinline__ GnObs gn_linearize(const double* pose, double X0, dou
 __device__ __forceinline__ bool gn_factor3(const double* a, double* lo) {
     const double p1 = a[0];
     bool ok = p1 > 0.0;
-    const double i00 = 1.0 / sqrt(ok ? p1 : 1.0);
+    const double i00 = gn_rsqrt(ok ? p1 : 1.0);
     const double l10 = a[1] * i00;
     const double l20 = a[3] * i00;
     const double p2 = a[2] - l10 * l10;
     ok = ok && p2 > 1e-9 * a[2];
-    const double i11 = 1.0 / sqrt(ok ? p2 : 1.0);
+    const double i11 = gn_rsqrt(ok ? p2 : 1.0);
     const double l21 = (a[4] - l20 * l10) * i11;
     const double p3 = a[5] - l20 * l20 - l21 * l21;
     ok = ok && p3 > 1e-9 * a[5];
-    const double i22 = 1.0 / sqrt(ok ? p3 : 1.0);
-    lo[0] = i00;
+    const double i22 = gn_rsqrt(ok ? p3 : 1.0);
+    // a landmark that takes no part gets zero reciprocals: every forward substitution with them yields exact
+    // zeros (finite operands), so no select is needed on the 21 values derived from them
+    lo[0] = ok ? i00 : 0.0;
     lo[1] = l10;
-    lo[2] = i11;
+    lo[2] = ok ? i11 : 0.0;
     lo[3] = l20;
     lo[4] = l21;
-    lo[5] = i22;
+    lo[5] = ok ? i22 : 0.0;
     return ok;
 }
 
@@ -249,12 +269,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double lo[6];
         const bool active = gn_factor3(a, lo);
         // y = L^-1 b_l
-        double y0 = bl[0] * lo[0];
-        double y1 = (bl[1] - lo[1] * y0) * lo[2];
-        double y2 = (bl[2] - lo[3] * y0 - lo[4] * y1) * lo[5];
-        if (!active) {
-            y0 = y1 = y2 = 0.0;
-        }
+        const double y0 = bl[0] * lo[0];
+        const double y1 = (bl[1] - lo[1] * y0) * lo[2];
+        const double y2 = (bl[2] - lo[3] * y0 - lo[4] * y1) * lo[5];
+        const double part = active ? 1.0 : 0.0;
         double* pf = panelF + (L.ll * 3) * GN_PSTRIDE;
         if (c == 0) {
             pf[GN_Y_ROW] = y0;
@@ -269,21 +287,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const double e0 = o.Jc[0][i] * o.Jl[0][0] + o.Jc[1][i] * o.Jl[1][0];
                 const double e1 = o.Jc[0][i] * o.Jl[0][1] + o.Jc[1][i] * o.Jl[1][1];
                 const double e2 = o.Jc[0][i] * o.Jl[0][2] + o.Jc[1][i] * o.Jl[1][2];
-                double f0 = e0 * lo[0];
-                double f1 = (e1 - lo[1] * f0) * lo[2];
-                double f2 = (e2 - lo[3] * f0 - lo[4] * f1) * lo[5];
-                if (!active) {
-                    f0 = f1 = f2 = 0.0;
-                }
+                const double f0 = e0 * lo[0];
+                const double f1 = (e1 - lo[1] * f0) * lo[2];
+                const double f2 = (e2 - lo[3] * f0 - lo[4] * f1) * lo[5];
                 pf[6 * c + i] = f0;
                 pf[GN_PSTRIDE + 6 * c + i] = f1;
                 pf[2 * GN_PSTRIDE + 6 * c + i] = f2;
                 // a landmark that takes no part leaves its observations out of H_cc, b_c and the cost too
-                gp[i] = active ? o.Jc[0][i] : 0.0;
-                gp[16 + i] = active ? o.Jc[1][i] : 0.0;
+                gp[i] = part * o.Jc[0][i];
+                gp[16 + i] = part * o.Jc[1][i];
             }
-            gp[6] = active ? o.r[0] : 0.0;
-            gp[16 + 6] = active ? o.r[1] : 0.0;
+            gp[6] = part * o.r[0];
+            gp[16 + 6] = part * o.r[1];
         }
         gn_wave_sync();
         // F F^T: operand element (row 16 t + col, k = 4 ks + kk) serves as A of tile row t and B of tile column t
