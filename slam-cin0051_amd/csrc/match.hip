@@ -272,11 +272,11 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
 //     that match_kernel filters with: the product comes out as distance - bound, a pair passes iff it
 //     is negative, and a lane knows whether ANY of its 16 pairs of a train tile (4 query tiles x 4
 //     rows) passes from the sign of their OR: 8 v_or3 + 1 compare per 4 MFMAs;
-//   * a passing (lane, tile) -- a few per cent of them -- is appended to a per-WAVE FIFO in LDS, and
+//   * a passing (lane, tile) -- a few per cent of them -- is appended to a per-WAVE work list in LDS, and
 //     whenever 64 entries wait the whole wave works them off, one entry per lane whoever pushed it:
 //     xor + popcount of the 16 pairs from the compact bits (read from global memory: entries carry train
 //     indices, not positions in the LDS stage, so nothing is flushed half-full when a stage is replaced);
-//     the one or two of them that can still change the query's keys go to a second FIFO of PAIRS, which
+//     the one or two of them that can still change the query's keys go to a second list of PAIRS, which
 //     is settled 64 at a time as well:
 //     the reference's penalty arithmetic (with every pair slot of the first level taking it, at one
 //     active lane in 64, it was two thirds of the kernel's instructions) and the update of the
@@ -296,9 +296,12 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
 constexpr int MM_STAGE = 256;    // train descriptors staged in LDS at a time
 constexpr int MM_XSTRIDE = 80;   // bytes between staged expanded descriptors: 16 lanes x 16 B then cover all 64 banks
 constexpr int MM_QT = 4;         // query tiles (of 16) per wave: 64 queries per wave, 256 per workgroup
-constexpr int MM_FIFO = 256;     // ring capacity per wave: < 64 waiting + the 64 pushes of one train tile
+// The two work lists are plain arrays filled from the front: the OLDEST 64 entries are taken (an entry that
+// waits keeps its query's bound loose) and the few that remain are moved down -- on the slow path, so that the
+// always-executed push needs no ring arithmetic.
+constexpr int MM_FIFO = 128;     // tile entries per wave: < 64 waiting + the 64 pushes of one train tile
 constexpr int MM_TRASH = MM_FIFO;  // one more slot: where the lanes that do not pass write
-constexpr int MM_PAIRS = 512;    // pair ring per wave: < 64 waiting + the 4 x 64 pushes of one query tile
+constexpr int MM_PAIRS = 320;    // pair entries per wave: < 64 waiting + the 4 x 64 pushes of one query tile
 constexpr int MM_MAX_BITS = 62;
 constexpr unsigned long long MM_KEY_NONE = 0x7fffffffffffffffull;  // distance INT_MAX, index -1
 
@@ -429,14 +432,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
     uint32_t* const myfifo = fifo[wave];
     uint32_t* const mypairs = pairq[wave];
-    int head = 0, tail = 0;    // tile FIFO: ring positions (wave-uniform, kept in SGPRs); entries [head, tail)
-    int phead = 0, ptail = 0;  // pair FIFO
+    int tail = 0;   // tile entries waiting (wave-uniform, kept in an SGPR)
+    int ptail = 0;  // pair entries waiting
     // level 2: `count` (<= 64) pairs from the head of the pair FIFO, one per lane: the reference's penalty
     // arithmetic (feature_matcher.cpp:161-170) and the update of the query's two keys
     const slamx_keypoint* tkps = use_kp ? mv.kps + static_cast<size_t>(tf) * mv.maxK : nullptr;
     auto settle = [&](int count) {
         if (lane < count) {
-            const uint32_t e = mypairs[(phead + lane) & (MM_PAIRS - 1)];
+            const uint32_t e = mypairs[lane];
             const int q = static_cast<int>(e & 0xffu);
             int dist = static_cast<int>(e >> 8 & 0xffu);
             const int t = static_cast<int>(e >> 16);
@@ -456,14 +459,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 }
             }
         }
-        phead += count;
+        // move what is left to the front (reads of a step before its writes: one wave, LDS in program order)
+        for (int base = count; base < ptail; base += 64) {
+            const uint32_t v = mypairs[base + lane];
+            if (base + lane < ptail) {
+                mypairs[base - count + lane] = v;
+            }
+        }
+        ptail -= count;
     };
     // level 1: `count` (<= 64) entries from the head of the tile FIFO, one per lane: entry = (lane L, tile) stands
     // for the 16 pairs {query u * 16 + (L & 15)} x {train 16 tile + 4 (L >> 4) + r}; their distances are
     // recomputed with xor + popcount and the ones that still reach the query's `second` go to the pair FIFO
     auto work = [&](int count, int t_end) {
         const bool valid = lane < count;
-        const uint32_t e = myfifo[(head + lane) & (MM_FIFO - 1)];
+        const uint32_t e = myfifo[lane];
+        {
+            const uint32_t v = myfifo[count + lane];  // at most 63 entries remain: moved to the front
+            if (count + lane < tail) {
+                myfifo[lane] = v;
+            }
+        }
+        tail -= count;
         const int ec = static_cast<int>(e & 15u);
         const int trow = static_cast<int>(e >> 6) + 4 * static_cast<int>(e >> 4 & 3u);
         // the compact bits of the four trains come from global memory (L2): entries outlive the LDS stage they
@@ -493,16 +510,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 if (pm != 0) {  // wave-uniform
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
-                    const uint32_t slot = pass ? ((static_cast<uint32_t>(ptail) + rank) & (MM_PAIRS - 1)) : static_cast<uint32_t>(MM_PAIRS);
+                    const uint32_t slot = pass ? static_cast<uint32_t>(ptail) + rank : static_cast<uint32_t>(MM_PAIRS);
                     mypairs[slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(dist) << 8) | (static_cast<uint32_t>(t) << 16);
                     ptail += __popcll(pm);
                 }
             }
-            while (ptail - phead >= 64) {
+            while (ptail >= 64) {
                 settle(64);
             }
         }
-        head += count;
     };
     auto refresh_bounds = [&]() {
 #pragma unroll
@@ -565,23 +581,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
             // branch-free: every lane stores, the ones that do not pass into the trash slot
-            const uint32_t slot = pass ? ((static_cast<uint32_t>(tail) + rank) & (MM_FIFO - 1)) : static_cast<uint32_t>(MM_TRASH);
+            const uint32_t slot = pass ? static_cast<uint32_t>(tail) + rank : static_cast<uint32_t>(MM_TRASH);
             myfifo[slot] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t0 + tile * 16) << 6);
             tail += __popcll(pm);
-            if (tail - head >= 64) {  // wave-uniform
+            if (tail >= 64) {  // wave-uniform
                 do {
                     work(64, t_end);
-                } while (tail - head >= 64);
+                } while (tail >= 64);
                 refresh_bounds();
             }
         }
     }
     if (wave_has_queries) {  // end of the scan: what is still waiting
-        while (tail - head > 0) {
-            work(min(64, tail - head), t_end);
+        while (tail > 0) {
+            work(min(64, tail), t_end);
         }
-        while (ptail - phead > 0) {
-            settle(min(64, ptail - phead));
+        while (ptail > 0) {
+            settle(min(64, ptail));
         }
     }
     for (int k = lane; k < QW; k += 64) {
