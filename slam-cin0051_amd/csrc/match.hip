@@ -580,9 +580,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const unsigned long long pm = __ballot(pass);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
-            // branch-free: every lane stores, the ones that do not pass into the trash slot
-            const uint32_t slot = pass ? static_cast<uint32_t>(tail) + rank : static_cast<uint32_t>(MM_TRASH);
-            myfifo[slot] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t0 + tile * 16) << 6);
+            // branch-free: every lane stores, the ones that do not pass into the trash slot; the list's write position
+            // is a scalar, so the address is one shift-add and one select
+            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+            lds_u32* const wr = (lds_u32*)myfifo + tail;
+            lds_u32* const dst = pass ? wr + rank : (lds_u32*)myfifo + MM_TRASH;
+            *dst = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t0 + tile * 16) << 6);
             tail += __popcll(pm);
             if (tail >= 64) {  // wave-uniform
                 do {
