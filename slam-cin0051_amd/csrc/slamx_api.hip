@@ -869,8 +869,8 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
     }
     const int pattern_len = static_cast<int>(b->det->pattern.size() / 4);
-    // The matrix-core scan (match.hip) wins for large sets (measured: 3.6 vs 4.9 ms per 256 frames of 10.4k
-    // keypoints) and loses for small ones (0.71 vs 0.59 ms per 512 frames of 2.1k): its slow path handles
+    // The matrix-core scan (match.hip) wins for large sets (measured: 3.05 vs 4.9 ms per 256 frames of 10.4k
+    // keypoints) and loses for small ones (0.69 vs 0.61 ms per 512 frames of 2.1k): its slow path handles
     // ~2 ln(n) filter passes per query, a cost per QUERY, while the scan it replaces is a cost per PAIR.
     // The keypoint count of a frame is only known on the device; the batch's capacity stands in for it.
     if (b->xdesc == nullptr && pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints()) {
