@@ -531,30 +531,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     const int chunk = (n2 + mv.nsplit - 1) / mv.nsplit;
     const int t_begin = split * chunk;
     const int t_end = min(n2, t_begin + chunk);
+    // thread t stages train descriptor t0 + t: its 64 expanded bytes.  The loads of a stage are issued a whole
+    // stage ahead (into 16 registers), so their latency passes under the tiles of the current one.
+    auto fetch = [&](int t0, uint4* x) {
+        const int t = threadIdx.x;
+        if (t0 + t < t_end) {
+            const uint4* src = reinterpret_cast<const uint4*>(xtr + static_cast<size_t>(t0 + t) * 64);
+            x[0] = src[0];
+            x[1] = src[1];
+            x[2] = src[2];
+            x[3] = src[3];
+        } else {
+            // past the end of the train set: distance 127 + |q|, which no bound below 127 lets through
+            // (and the slow path checks the index anyway)
+            x[0] = x[1] = x[2] = make_uint4(0u, 0u, 0u, 0u);
+            x[3] = make_uint4(0u, 0u, 0u, 0x017f0000u);
+        }
+    };
+    uint4 xnext[4];
+    fetch(t_begin, xnext);
     for (int t0 = t_begin; t0 < t_end; t0 += MM_STAGE) {
         const int tn = min(MM_STAGE, t_end - t0);
-        __syncthreads();
+        __syncthreads();  // every wave is done with the previous stage
         {
-            // thread t stages train descriptor t0 + t: its 64 expanded bytes
-            const int t = threadIdx.x;
-            uint4 x0, x1, x2, x3;
-            if (t < tn) {
-                const uint4* src = reinterpret_cast<const uint4*>(xtr + static_cast<size_t>(t0 + t) * 64);
-                x0 = src[0];
-                x1 = src[1];
-                x2 = src[2];
-                x3 = src[3];
-            } else {
-                // past the end of the train set: distance 127 + |q|, which no bound below 127 lets through
-                // (and the slow path checks the index anyway)
-                x0 = x1 = x2 = make_uint4(0u, 0u, 0u, 0u);
-                x3 = make_uint4(0u, 0u, 0u, 0x017f0000u);
-            }
-            uint4* dst = reinterpret_cast<uint4*>(xt + t * MM_XSTRIDE);
-            dst[0] = x0;
-            dst[1] = x1;
-            dst[2] = x2;
-            dst[3] = x3;
+            uint4* dst = reinterpret_cast<uint4*>(xt + threadIdx.x * MM_XSTRIDE);
+            dst[0] = xnext[0];
+            dst[1] = xnext[1];
+            dst[2] = xnext[2];
+            dst[3] = xnext[3];
+        }
+        if (t0 + MM_STAGE < t_end) {
+            fetch(t0 + MM_STAGE, xnext);
         }
         __syncthreads();
         if (!wave_has_queries) {
