@@ -48,11 +48,35 @@ def build():
         out[tag + "_match_nokp"] = o.match(d1, d2, None, None, M).view(np.uint8).reshape(-1, 12)  # test_pose_estimator.cpp:138
         M0 = oracle_binding.MatcherParams(0, 20, 1, 0.5)
         out[tag + "_best_kp"] = o.match(d1, d2, k1, k2, M0).view(np.uint8).reshape(-1, 12)
+    # ---- build-side extensions (no reference counterpart): the oracle's own outputs, to catch drift / accidental edits
+    img = load_gray(os.path.join(HERE, "ref_data", "images_test_loop/0.png"))
+    levels = o.pyramid_images(img, 5, 1.2)
+    out["pyramid_loop0_level_shapes"] = np.array([l.shape for l in levels], np.int32)
+    out["pyramid_loop0_level_sums"] = np.array([int(l.astype(np.uint64).sum()) for l in levels], np.uint64)
+    out["pyramid_loop0_level4"] = levels[4]
+    pk, pd = o.pyramid_detect_and_compute(img, P, 5, 1.2)
+    out["pyramid_loop0_kps"] = pk.view(np.uint8).reshape(len(pk), 20)
+    out["pyramid_loop0_desc"] = pd
     return out
+
+
+def build_gn():
+    """Floating-point vectors of the Gauss-Newton oracle (one window, 4 cameras, 30 landmarks): kept apart from the
+    exact vectors because they are compared with a tolerance (1e-12 relative)."""
+    import gn_scene
+
+    o = oracle_binding.load()
+    w = gn_scene.make_window(20261004, 4, 30)
+    r = o.gn_step_dense(w["poses0"], w["X0"], w["obs"], w["K"], 1e-3, 2)
+    assert r["rc"] == 0
+    return {"gn_S": r["S"], "gn_g": r["g"], "gn_delta_c": r["delta_c"], "gn_delta_x": r["delta_x"],
+            "gn_cost": np.array([r["cost"]]), "gn_active": r["active"], "gn_obs": w["obs"], "gn_poses0": w["poses0"],
+            "gn_X0": w["X0"]}
 
 
 if __name__ == "__main__":
     data = build()
     path = os.path.join(HERE, "oracle_golden.npz")
     np.savez_compressed(path, **data)
+    np.savez_compressed(os.path.join(HERE, "gn_golden.npz"), **build_gn())
     print("wrote", path, os.path.getsize(path), "bytes;", {k: v.shape for k, v in data.items() if "kps" in k})

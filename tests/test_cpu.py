@@ -79,6 +79,21 @@ def test_oracle_matches_golden_vectors(oracle):
             assert np.array_equal(g[k], fresh[k]), "golden vector %s changed" % k
 
 
+def test_gn_oracle_matches_golden_vectors(oracle):
+    """The Gauss-Newton oracle on a committed window (inputs and outputs in tests/golden/gn_golden.npz): floating
+    point, so 1e-12 relative instead of bit for bit (libm's sin / cos are not involved in a single step)."""
+    with np.load(os.path.join(ROOT, "tests", "golden", "gn_golden.npz")) as g:
+        K = np.array([1700.0, 1700.0, 960.0, 540.0])
+        r = oracle.gn_step_dense(g["gn_poses0"], g["gn_X0"], g["gn_obs"], K, 1e-3, 2)
+        assert r["rc"] == 0
+        np.testing.assert_array_equal(r["active"], g["gn_active"])
+        np.testing.assert_allclose(r["S"], g["gn_S"], rtol=0, atol=1e-12 * np.abs(g["gn_S"]).max())
+        np.testing.assert_allclose(r["g"], g["gn_g"], rtol=0, atol=1e-12 * np.abs(g["gn_g"]).max())
+        np.testing.assert_allclose(r["delta_c"], g["gn_delta_c"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(r["delta_x"], g["gn_delta_x"], rtol=0, atol=1e-10)
+        assert r["cost"] == pytest.approx(float(g["gn_cost"][0]), rel=1e-13)
+
+
 def test_oracle_hamming_and_matcher_edge_cases(oracle):
     import oracle_binding
 

@@ -212,3 +212,20 @@ def test_full_size_windows_of_the_c4_workload(slamx, oracle):
         np.testing.assert_allclose(X[i], X_ref, rtol=0, atol=X_ATOL)
         assert cost[i, 1] == pytest.approx(oracle.gn_cost(p_ref, X_ref, w["obs"], w["K"], lam), rel=1e-7)
         assert cost[i, 1] < 0.05 * cost[i, 0]
+
+
+def test_against_committed_golden_vectors(slamx):
+    """tests/golden/gn_golden.npz: inputs and the oracle's reduced system / step of one window, committed -- the
+    GPU against the fixture without the oracle in the loop (1e-9 relative on S and g, 1e-8 on the step)."""
+    import os
+
+    from conftest import ROOT
+
+    with np.load(os.path.join(ROOT, "tests", "golden", "gn_golden.npz")) as g:
+        gn = slamx.GaussNewton(1, 4, 30)
+        gn.upload(g["gn_poses0"][None], g["gn_X0"][None], g["gn_obs"][None])
+        S, gv, d, c = gn.normal_equations(np.array([1700.0, 1700.0, 960.0, 540.0]), 1e-3, 2)
+        np.testing.assert_allclose(S[0], g["gn_S"], rtol=0, atol=S_RTOL * np.abs(g["gn_S"]).max())
+        np.testing.assert_allclose(gv[0], g["gn_g"], rtol=0, atol=S_RTOL * np.abs(g["gn_g"]).max())
+        np.testing.assert_allclose(d[0], g["gn_delta_c"].reshape(-1), rtol=0, atol=1e-6)
+        assert c[0] == pytest.approx(float(g["gn_cost"][0]), rel=COST_RTOL)

@@ -140,3 +140,21 @@ def test_full_size_pyramid_workload_bit_exact(slamx, oracle):
     for q, t_ in ((1, 0), (0, 1)):
         want = oracle.match(ref[q][1], ref[t_][1], ref[q][0], ref[t_][0], mp)
         assert_records_equal(b.download_matches(m, q), want, "c3p matches %d->%d" % (q, t_))
+
+
+def test_pyramid_against_committed_golden_vectors(slamx, ref_data):
+    """tests/golden/oracle_golden.npz holds the 5-level pyramid of images_test_loop/0.png: level shapes, pixel sums,
+    the smallest level and the merged keypoints / descriptors -- compared without the oracle in the loop."""
+    from conftest import ROOT
+
+    det = slamx.FeatureDetector(os.path.join(ref_data, "feature_detector.yml"))
+    img = load_gray(os.path.join(ref_data, "images_test_loop/0.png"))
+    pyr = run_pyramid(slamx, det, [img], 5, 1.2)
+    with np.load(os.path.join(ROOT, "tests", "golden", "oracle_golden.npz")) as g:
+        assert [list(s) for s in pyr.shapes] == g["pyramid_loop0_level_shapes"].tolist()
+        sums = [int(pyr.level(l).download_image(0).astype(np.uint64).sum()) for l in range(5)]
+        assert sums == g["pyramid_loop0_level_sums"].tolist()
+        assert np.array_equal(pyr.level(4).download_image(0), g["pyramid_loop0_level4"])
+        k, d = pyr.level(0).download(0)
+        assert np.array_equal(k.view(np.uint8).reshape(len(k), 20), g["pyramid_loop0_kps"])
+        assert np.array_equal(d, g["pyramid_loop0_desc"])
