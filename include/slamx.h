@@ -333,7 +333,8 @@ int slamx_gn_iterate(slamx_gn* gn, const double* K, double lambda, int n_fixed, 
 int slamx_gn_download(slamx_gn* gn, double* poses, double* landmarks, double* cost, int32_t* status);
 /* Per-kernel device time of the iterations enqueued since profiling was switched on: hipEvent pairs on the
  * context stream around every launch.  avg_ms[3] = accumulate, solve, back-substitution; launches[3]
- * (optional) = how many launches each average covers. */
+ * (optional) = how many launches each average covers.  on = 0: off; 1: every iteration records; n > 1: every
+ * n-th iteration (an event between two kernels keeps the second from starting while the first drains). */
 int slamx_gn_set_profiling(slamx_gn* gn, int on);
 int slamx_gn_stage_ms(slamx_gn* gn, float* avg_ms, int32_t* launches);
 /* Linearise at the current state WITHOUT stepping: S [n_windows][6 n_cams][6 n_cams], g and delta

@@ -803,8 +803,8 @@ class GaussNewton:
         _check(self.lib.slamx_gn_download(self.h, _ptr(poses), _ptr(lm), _ptr(cost), _ptr(status)))
         return poses, lm, cost, status
 
-    def set_profiling(self, on=True):
-        _check(self.lib.slamx_gn_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on=True, every=1):
+        _check(self.lib.slamx_gn_set_profiling(self.h, (max(1, int(every)) if on else 0)))
 
     def stage_ms(self):
         """-> ({"accumulate": ms, "solve": ms, "backsub": ms}, launches per stage)"""

@@ -2033,6 +2033,9 @@ struct slamx_gn {
     // profiling: event pairs around every kernel of the iterations since it was switched on
     // (stage 0 accumulate, 1 solve, 2 back-substitution), on the context stream
     bool profiling = false;
+    int prof_every = 1;       // only every prof_every-th iteration records (an event between two kernels keeps the
+    long long prof_iter = 0;  // second from starting while the first drains)
+    bool prof_now = false;
     std::vector<hipEvent_t> ev[3];
     size_t ev_used[3] = {0, 0, 0};
 };
@@ -2041,7 +2044,7 @@ namespace {
 
 // record the next unused event of a stage (grown on demand); pairs are (2k, 2k + 1)
 void gn_mark(slamx_gn* g, int stage) {
-    if (!g->profiling) {
+    if (!g->profiling || !g->prof_now) {
         return;
     }
     if (g->ev_used[stage] == g->ev[stage].size()) {
@@ -2160,6 +2163,8 @@ int slamx_gn_set_profiling(slamx_gn* g, int on) {
     }
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));
     g->profiling = on != 0;
+    g->prof_every = on > 1 ? on : 1;  // on = n > 1: every n-th iteration records
+    g->prof_iter = 0;
     for (auto& u : g->ev_used) {
         u = 0;
     }
@@ -2226,6 +2231,7 @@ int slamx_gn_iterate(slamx_gn* g, const double* K, double lambda, int n_fixed, i
     hipStream_t s = g->ctx->stream;
     for (int it = 0; it <= iterations; ++it) {
         const GnLaunch a = gn_launch_of(g, K, lambda, n_fixed, it);
+        g->prof_now = g->profiling && (g->prof_iter++ % g->prof_every) == 0;
         gn_mark(g, 0);
         launch_gn_accumulate(a, s);
         gn_mark(g, 0);
