@@ -469,7 +469,8 @@ def main():
         kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
                      "brief": "brief_kernel", "nms_build": "nms_greedy_kernel", "sort": "sort_kernel",
                      "moments": "describe_fused_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
-        mfma_match = wl["max_kp"] >= mod.load_library().slamx_matcher_mfma_threshold()
+        thr = mod.load_library().slamx_matcher_mfma_threshold()
+        mfma_match = wl["max_kp"] >= thr and N >= thr  # (per frame pair on the device; N is the batch average)
         if mfma_match:
             kernel_of["match"] = "match_mfma_kernel"
         if dom == "match" and mfma_match:

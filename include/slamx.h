@@ -93,10 +93,11 @@ typedef struct slamx_batch slamx_batch;
 
 const char* slamx_last_error(void);
 const char* slamx_version(void);
-/* Train-set size (keypoint capacity of a batch / n2 of slamx_matcher_match) from which the matcher
- * computes its all-pairs Hamming distances on the int8 matrix cores instead of with xor + popcount
- * (descriptors with <= 62 live bits only; results are identical either way).  Built-in 6144,
- * overridden by the environment variable SLAMX_MATCH_MFMA_MIN_KEYPOINTS. */
+/* Train-set size from which the matcher computes the all-pairs Hamming distances of a frame pair on the
+ * int8 matrix cores instead of with xor + popcount (descriptors with <= 62 live bits only; results are
+ * identical either way; in a batch the choice is made per frame pair on the device, a batch whose keypoint
+ * capacity is below the value never takes the matrix-core scan).  Built-in 3072, overridden by the
+ * environment variable SLAMX_MATCH_MFMA_MIN_KEYPOINTS. */
 int slamx_matcher_mfma_threshold(void);
 
 /* ---- context: one per GPU; owns (or borrows) the HIP stream all work is enqueued on. ---- */

@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void match_kernel(MatchView mv, int first_quer
     if (block_first >= n1) {
         return;  // whole workgroup idle (uniform)
     }
+    if (mv.xdesc != nullptr && n2 >= mv.mfma_min_train) {
+        return;  // this pair belongs to match_mfma_kernel (uniform)
+    }
     const bool use_kp = mv.kps != nullptr;
     const uint32_t* qd = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(qf) * mv.maxK * mv.width);
     const uint32_t* td = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(tf) * mv.maxK * mv.width);
@@ -308,10 +311,17 @@ constexpr unsigned long long MM_KEY_NONE = 0x7fffffffffffffffull;  // distance I
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // desc (compact bits) -> train-form expanded descriptors, 64 bytes each; 4 lanes per keypoint
+// A frame is only expanded when a pair that takes the matrix-core scan uses it: as a train set of at least
+// min_train keypoints, or as the query frame of such a train set (its predecessor; first_train_frame for frame 0).
 __global__ __launch_bounds__(256) void xdesc_kernel(const uint8_t* __restrict__ desc, const int* __restrict__ n_kp, int maxK,
-                                                    int width, uint8_t* __restrict__ xdesc, int first_frame) {
+                                                    int width, uint8_t* __restrict__ xdesc, int first_frame,
+                                                    int first_train_frame, int min_train) {
     const int f = first_frame + blockIdx.y;
     const int n = n_kp[f];
+    const int pred = f > 0 ? f - 1 : first_train_frame;
+    if (n < min_train && (pred < 0 || n_kp[pred] < min_train)) {
+        return;
+    }
     const int stride = width / 4;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n * 4; e += gridDim.x * 256) {
         const int i = e >> 2;
@@ -378,8 +388,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
     const int block_first = qblock * (QW * 4);
-    if (block_first >= n1) {
-        return;
+    if (block_first >= n1 || n2 < mv.mfma_min_train) {
+        return;  // no queries here, or a pair of match_kernel's
     }
     const bool use_kp = mv.kps != nullptr;
     const int lane = threadIdx.x & 63;
@@ -754,30 +764,40 @@ void launch_words(const MatchView& mv, int first_query_frame, int npairs, int fi
 
 }  // namespace
 
-void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
+void launch_match_consecutive(const MatchView& mv_in, int first_query_frame, int npairs, int first_train_frame,
                               hipStream_t stream, hipEvent_t ev_mid) {
     if (npairs <= 0) {
         return;
     }
+    MatchView mv = mv_in;
     const int stride = mv.width / 4;
-    if (mv.xdesc != nullptr && mv.width % 4 == 0 && mv.live_bits > 0 && mv.live_bits <= MM_MAX_BITS && mv.maxK <= 65536) {  // (pair entries hold the train index in 16 bits)
-        // expanded descriptors of every frame that is a query or a train set of this call, then the matrix-core scan
+    const bool mfma = mv.xdesc != nullptr && mv.width % 4 == 0 && mv.live_bits > 0 && mv.live_bits <= MM_MAX_BITS &&
+                      mv.maxK <= 65536;  // (pair entries hold the train index in 16 bits)
+    if (!mfma) {
+        mv.xdesc = nullptr;  // match_kernel then takes every pair
+    }
+    if (mfma) {
+        // Expanded descriptors of every frame that is a query or a train set of this call, then the matrix-core scan
+        // of the pairs with large train sets; the popcount scan below takes the other pairs (the keypoint counts
+        // are only known on the device: both kernels are launched and each leaves the other's pairs alone).
         const int qblocks = (mv.maxK + 64 * MM_QT - 1) / (64 * MM_QT);
         // frames in use: the queries, their predecessors, and first_train_frame when frame 0 is a query
         const int lo_frame = first_query_frame > 0 ? first_query_frame - 1 : 0;
         const int hi_frame = first_query_frame + npairs - 1;
         dim3 gx(grid_x(mv.maxK * 4, 256, hi_frame - lo_frame + 1), hi_frame - lo_frame + 1);
-        hipLaunchKernelGGL(xdesc_kernel, gx, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc, lo_frame);
+        hipLaunchKernelGGL(xdesc_kernel, gx, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc, lo_frame,
+                           first_train_frame, mv.mfma_min_train);
         if (first_query_frame == 0 && first_train_frame >= 0 && (first_train_frame < lo_frame || first_train_frame > hi_frame)) {
             dim3 g1(grid_x(mv.maxK * 4, 256, 1), 1);
             hipLaunchKernelGGL(xdesc_kernel, g1, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc,
-                               first_train_frame);
+                               first_train_frame, first_train_frame, mv.mfma_min_train);
         }
         const int pair_slots = npairs >= 8 ? 8 * ((npairs + 7) / 8) : npairs;
         dim3 grid(static_cast<unsigned>(qblocks) * pair_slots * mv.nsplit);
         hipLaunchKernelGGL(match_mfma_kernel, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame, stride,
                            npairs, qblocks);
-    } else if (mv.width % 4 == 0 && stride <= 16) {
+    }
+    if (mv.width % 4 == 0 && stride <= 16) {
         int live = mv.live_words > 0 && mv.live_words < stride ? mv.live_words : stride;
         switch (live) {
             case 1: launch_words<1>(mv, first_query_frame, npairs, first_train_frame, stream); break;

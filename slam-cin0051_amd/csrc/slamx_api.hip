@@ -869,11 +869,14 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
     }
     const int pattern_len = static_cast<int>(b->det->pattern.size() / 4);
-    // The matrix-core scan (match.hip) wins for large sets (measured: 3.05 vs 4.9 ms per 256 frames of 10.4k
-    // keypoints) and loses for small ones (0.69 vs 0.61 ms per 512 frames of 2.1k): its slow path handles
-    // ~2 ln(n) filter passes per query, a cost per QUERY, while the scan it replaces is a cost per PAIR.
-    // The keypoint count of a frame is only known on the device; the batch's capacity stands in for it.
-    if (b->xdesc == nullptr && pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints()) {
+    // The matrix-core scan (match.hip) wins for large train sets (3.05 vs 4.9 ms per 256 frames of 10.4k keypoints,
+    // 1.37 vs 1.63 ms per 512 frames of 4.0k) and loses for small ones (0.69 vs 0.61 ms per 512 frames of 2.1k;
+    // even at 2.8k): its slow path handles ~2 ln(n) filter passes per query, a cost per QUERY, while the scan it
+    // replaces is a cost per PAIR.  The keypoint counts are only known on the device, so when the batch's capacity
+    // allows large sets BOTH kernels are launched and every frame pair is taken by one of them according to the
+    // size of its train set (MatchView::mfma_min_train).
+    const bool use_mfma = pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints();
+    if (use_mfma && b->xdesc == nullptr) {
         SLAMX_TRY(dev_alloc(&b->xdesc, F * b->v.maxK * 64));
     }
     MatchView mv{};
@@ -889,9 +892,10 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     // descriptors of a batch come from describe_kernel: bits >= pattern_len are never set
     mv.live_words = std::max(1, (pattern_len + 31) / 32);
     mv.live_bits = std::max(1, pattern_len);
-    mv.xdesc = b->xdesc;
+    mv.xdesc = use_mfma ? b->xdesc : nullptr;
+    mv.mfma_min_train = match_mfma_min_keypoints();
     // (the matrix-core path takes 256 queries per workgroup, the popcount path 512)
-    mv.nsplit = match_split_for(nframes, b->xdesc != nullptr ? b->v.maxK * 2 : b->v.maxK);
+    mv.nsplit = match_split_for(nframes, b->v.maxK);  // one split for both scans: they share the per-chunk result slots
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
     if (!recorded(b, 10)) {
@@ -1506,6 +1510,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
             mv.live_bits = std::max(1, 32 * (live - 1) + hb);
             if (n2 >= match_mfma_min_keypoints()) {  // see slamx_batch_match_consecutive
                 mv.xdesc = m->xdesc;
+                mv.mfma_min_train = 0;  // n2 is known here: the one pair takes the matrix-core scan
                 mv.nsplit = match_split_for(1, m->cap * 2);
             }
         }

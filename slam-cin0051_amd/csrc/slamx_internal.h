@@ -21,7 +21,7 @@ constexpr uint8_t NMS_UNDECIDED = 0;
 constexpr uint8_t NMS_KEPT = 1;
 constexpr uint8_t NMS_SUPPRESSED = 2;
 constexpr int MATCH_MAX_SPLIT = 8;
-constexpr int MATCH_MFMA_MIN_KEYPOINTS = 6144;  // smaller train sets take the xor + popcount scan (match.hip)
+constexpr int MATCH_MFMA_MIN_KEYPOINTS = 3072;  // smaller train sets take the xor + popcount scan (match.hip)
 constexpr int NBR_CAP = 16;            // cached earlier-ranked neighbours per candidate
 constexpr uint8_t NBR_OVERFLOW = 255;  // more than NBR_CAP: re-enumerate every round
 
@@ -200,6 +200,8 @@ struct MatchView {
     int live_words;  // 32-bit words that can be non-zero in any descriptor (0 = unknown: all)
     int live_bits;   // highest bit that can be set in any descriptor, plus one (0 = unknown)
     uint8_t* xdesc;  // [F][maxK][64] scratch for the matrix-core path (expanded descriptors), or nullptr
+    int mfma_min_train;  // with xdesc: pairs whose TRAIN set has at least this many keypoints take the matrix-core
+                         // scan, the others the popcount scan (both kernels are launched, each skips the other's pairs)
     int use_ratio;
     float ratio;
 };

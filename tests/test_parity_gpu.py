@@ -405,7 +405,7 @@ def test_match_random_descriptors(slamx, oracle, width, n1, n2):
 
 @pytest.fixture
 def mfma_scan_for_all_sizes(monkeypatch):
-    """The matrix-core scan is only taken for train sets of >= 6144 keypoints (smaller ones are faster on
+    """The matrix-core scan is only taken for train sets of >= 3072 keypoints (smaller ones are faster on
     the popcount scan); the override sends every size through it."""
     monkeypatch.setenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", "0")
 
@@ -475,7 +475,7 @@ def test_match_matrix_core_scan_descriptor_widths(slamx, oracle, width, bits, mf
 
 
 def test_match_large_train_set_takes_the_matrix_core_scan(slamx, oracle):
-    """7000 train descriptors with 46 live bits: above the built-in threshold, no override."""
+    """7000 train descriptors with 46 live bits: above the built-in threshold (3072), no override."""
     rng = np.random.default_rng(77)
     n1, n2 = 900, 7000
     d1 = np.zeros((n1, 32), np.uint8)
@@ -514,6 +514,28 @@ def test_batch_matching_through_the_matrix_core_scan(slamx, oracle, mfma_scan_fo
     for k in range(1, 4):
         want = oracle.match(ref[k][1], ref[k - 1][1], None, None, mp)
         assert_records_equal(b.download_matches(m, k), want, "no keypoints, frame %d" % k)
+
+
+def test_batch_with_both_scans_in_one_launch(slamx, oracle, monkeypatch):
+    """Frames of very different keypoint counts in one batch, threshold between them: some frame pairs are taken
+    by match_kernel, the others by match_mfma_kernel -- chosen on the device by the size of the pair's train set."""
+    monkeypatch.setenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", "600")
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
+    mp = oracle.match_params(m.cfg)
+    frames = [synth(slamx, k, 360, 500, n, rmin=3, rmax=20) for k, n in enumerate((80, 1500, 120, 1700, 60))]
+    b = slamx.Batch(d, 360, 500, 5, 32768, 8192)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(5)
+    b.match_consecutive(m, 5, use_keypoints=True, first_train_frame=4)
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    sizes = [len(r[0]) for r in ref]
+    assert min(sizes) < 600 < max(sizes)
+    for k in range(5):
+        t = (k - 1) % 5
+        want = oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], mp)
+        assert_records_equal(b.download_matches(m, k), want, "frame %d (%d kp) vs %d (%d kp)" % (k, sizes[k], t, sizes[t]))
 
 
 def test_match_penalty_fractional_keypoints(slamx, oracle):
