@@ -8,8 +8,8 @@
 //
 // MI355X design: integer-only, one image read.
 //   K1  fast_detect : one workgroup = 256 x 32 pixel tile, staged through LDS with a 3-px halo as
-//                     aligned dword loads; the cardinal pretest on 4 pixels per lane with packed
-//                     16-bit math, the segment test (and the score, while the circle is in LDS)
+//                     aligned dword loads; a cardinal quick reject on 4 pixels per lane and instruction
+//                     (6-bit bytes, plain 32-bit adds), the segment test (and the score, while the circle is in LDS)
 //                     only on the compacted survivors.  Written: the corner predicate of every
 //                     64-pixel row segment as one 64-bit word of a corner bitmap (W*H/8 bytes), the
 //                     popcount of every word, and the tile's corners as (position, score) entries.
@@ -56,49 +56,59 @@ __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
     if (arc <= 0) {
         return true;  // "0 >= 0" fires on the first step
     }
-    uint32_t mb = B | (B << 16);
-    uint32_t md = D | (D << 16);
-    uint32_t rb = mb;
-    uint32_t rd = md;
-    for (int s = 1; s < arc; ++s) {
-        rb &= mb >> s;
-        rd &= md >> s;
+    // bit i of rb / rd: the doubled sequence holds a run of `len` starting at i; runs double, the rest of the
+    // arc is one more overlapping step (arc <= 16, at most five steps instead of arc - 1)
+    uint32_t rb = B | (B << 16);
+    uint32_t rd = D | (D << 16);
+    int len = 1;
+    while (2 * len <= arc) {
+        rb &= rb >> len;
+        rd &= rd >> len;
+        len *= 2;
     }
+    const int rest = arc - len;  // < len
+    rb &= rb >> rest;
+    rd &= rd >> rest;
     return (rb | rd) != 0;
 }
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// Quick reject on FOUR pixels per register (a superset of the reference's pretest B, feature_detector.cpp:
+// 98-113; pretest A, :81-96, is implied -- 3 of 4 cardinals include pixel 0 or pixel 8).  Pixels are
+// reduced to 6 bits (p >> 2) so that every byte keeps two guard bits and whole dwords can be compared
+// with plain 32-bit adds and subtracts, which issue faster than any packed or three-operand form
+// (profiles/r03_op_rates_microbench.txt).  With t6 = (t + 1) >> 2:
+//     n > c + t  =>  (n >> 2) >= (c >> 2) + t6          n < c - t  =>  (n >> 2) <= (c >> 2) - t6
+// (floor is monotone and superadditive), so a pixel the reference's pretest lets through always
+// passes here; the few extra survivors fail the exact segment test of phase 2.
+//   brighter:  n6 + (128 - t6 - c6)   has bit 7 set  <=>  n6 >= c6 + t6      (range 2 .. 191: no carry)
+//   darker:    (c6 + 128 - t6) - n6   has bit 7 set  <=>  n6 <= c6 - t6      (range 2 .. 191: no borrow)
+constexpr uint32_t SWAR_LOW6 = 0x3f3f3f3fu;
+constexpr uint32_t SWAR_FLAG = 0x80808080u;
 
-// bytes (0,1) / (2,3) of w zero-extended to two u16 lanes (v_perm_b32)
-__device__ __forceinline__ us2 unpack_lo(uint32_t w) {
-    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u));
-}
-__device__ __forceinline__ us2 unpack_hi(uint32_t w) {
-    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u));
+__device__ __forceinline__ uint32_t to6(uint32_t w) { return (w >> 2) & SWAR_LOW6; }
+
+// bit 7 of every byte: at least 3 of the 4 words a, b, c, d have it set
+__device__ __forceinline__ uint32_t three_of_four(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t maj = __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8);   // at least two of a, b, c
+    const uint32_t all3 = __builtin_amdgcn_bitop3_b32(a, b, c, 0x80);  // a & b & c
+    return __builtin_amdgcn_bitop3_b32(all3, d, maj, 0xf8);            // all3 | (d & maj)
 }
 
-// Pretest B of the reference (feature_detector.cpp:98-113) for two pixels at once, in packed
-// 16-bit arithmetic: "at least 3 of the 4 cardinal circle pixels are brighter than c + t" is
-// "the second smallest of them is", "at least 3 are darker than c - t" is "the second largest
-// is"; both order statistics come out of one 4-input sorting network.  Non-zero lane = pass.
-// Pretest A (:81-96, pixels 0 and 8) is implied: 3 of 4 cardinals include pixel 0 or pixel 8.
-__device__ __forceinline__ uint32_t cardinal_test(us2 c, us2 u, us2 d, us2 l, us2 r, us2 t) {
-    const us2 hi = c + t;                                  // <= 510, no wrap
-    const us2 lo = __builtin_elementwise_sub_sat(c, t);    // max(c - t, 0): nothing is < 0
-    const us2 a = __builtin_elementwise_min(u, d), b = __builtin_elementwise_max(u, d);
-    const us2 e = __builtin_elementwise_min(l, r), f = __builtin_elementwise_max(l, r);
-    const us2 mac = __builtin_elementwise_max(a, e);
-    const us2 mbd = __builtin_elementwise_min(b, f);
-    const us2 second_smallest = __builtin_elementwise_min(mac, mbd);
-    const us2 second_largest = __builtin_elementwise_max(mac, mbd);
-    const us2 pass = __builtin_elementwise_sub_sat(second_smallest, hi) | __builtin_elementwise_sub_sat(lo, second_largest);
-    return __builtin_bit_cast(uint32_t, pass);
+// c6: centre pixels, u / d / l / r: the cardinal circle pixels 0, 8, 12, 4 of the same four centres, all as
+// 6-bit bytes; gt = 128 - t6 in every byte.  Bit 7 of byte i of the result = pixel i passes.
+__device__ __forceinline__ uint32_t cardinal_test4(uint32_t c6, uint32_t u, uint32_t d, uint32_t l, uint32_t r, uint32_t gt) {
+    const uint32_t kb = gt - c6;
+    const uint32_t kd = c6 + gt;
+    const uint32_t bright = three_of_four(u + kb, d + kb, l + kb, r + kb);
+    const uint32_t dark = three_of_four(kd - u, kd - d, kd - l, kd - r);
+    return bright | dark;
 }
 
 // Two phases per 256 x 32 tile (a lane owns 4 horizontally adjacent pixels = one dword).
-//  phase 1: the cardinal pretest on 4 pixels per lane (centre row dwords unpacked once and
-//           reused as the up / down rows of the rows 3 below / above; left / right neighbours
-//           picked with v_perm); about 1 % of the pixels survive and go to an LDS list.
+//  phase 1: a byte-parallel quick reject on 4 pixels per lane and instruction (cardinal_test4; centre
+//           row dwords reduced to 6 bits once and reused as the up / down rows of the rows 3 below /
+//           above; left / right neighbours with v_alignbyte); about 1 % of the pixels survive and
+//           go to an LDS list.
 //  phase 2: the 16-pixel segment test on the survivors, on dense waves.
 // Pixels that fail the pretest can never be corners, so the bitmap is the reference's.
 __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc, int nframes, int tiles_x, int tiles_y) {
@@ -163,46 +173,34 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     }
     __syncthreads();
     const int x = tx * TILE_W + lane * 4;
-    const us2 t2 = {static_cast<unsigned short>(threshold), static_cast<unsigned short>(threshold)};
-    // ---- phase 1: a wave walks its ROWS_PER_WAVE consecutive rows; every LDS row is unpacked
-    // once and serves as the centre row, as the "up" row 3 rows later and the "down" row 3 rows
-    // earlier.  Pass flags are collected as bits (acc01: pixel 0 of row k -> bit k, pixel 1 ->
-    // bit 16 + k; acc23 likewise for pixels 2, 3) and compacted once at the end.
-    uint32_t acc01 = 0, acc23 = 0;
+    // ---- phase 1: a wave walks its ROWS_PER_WAVE consecutive rows; every LDS row is reduced to 6-bit
+    // bytes once and serves as the centre row, as the "up" row 3 rows later and the "down" row 3 rows
+    // earlier.  Pass flags are collected as bits (pixel i of row k -> bit 8 i + k) and compacted once
+    // at the end.
+    uint32_t acc = 0;
     {
+        const int t6 = min((threshold + 1) >> 2, 63);
+        uint32_t gt = SWAR_FLAG - static_cast<uint32_t>(t6) * 0x01010101u;
+        // a vector register: the fast 32-bit forms lose their issue rate with a scalar operand
+        asm volatile("v_mov_b32 %0, %0" : "+v"(gt));
         const uint32_t* col = tile + (wave * ROWS_PER_WAVE) * LDS_ROW_DW + lane + 1;  // LDS row of tile row ry-3
-        us2 clo[ROWS_PER_WAVE + 2 * HALO], chi[ROWS_PER_WAVE + 2 * HALO];
-        uint32_t craw[ROWS_PER_WAVE + 2 * HALO];
+        uint32_t c6[ROWS_PER_WAVE + 2 * HALO];
 #pragma unroll
         for (int j = 0; j < 2 * HALO; ++j) {
-            craw[j] = col[j * LDS_ROW_DW];
-            clo[j] = unpack_lo(craw[j]);
-            chi[j] = unpack_hi(craw[j]);
+            c6[j] = to6(col[j * LDS_ROW_DW]);
         }
 #pragma unroll
         for (int k = 0; k < ROWS_PER_WAVE; ++k) {
             const int jn = k + 2 * HALO;
-            craw[jn] = col[jn * LDS_ROW_DW];
-            clo[jn] = unpack_lo(craw[jn]);
-            chi[jn] = unpack_hi(craw[jn]);
+            c6[jn] = to6(col[jn * LDS_ROW_DW]);
             const int jc = k + HALO;
-            const uint32_t C = craw[jc];
-            const uint32_t Pv = col[jc * LDS_ROW_DW - 1];
-            const uint32_t Nx = col[jc * LDS_ROW_DW + 1];
-            // left neighbours (x-3, x-2 | x-1, x) and right neighbours (x+3, x+4 | x+5, x+6) as u16 pairs
-            const us2 l_lo = __builtin_bit_cast(us2, __builtin_amdgcn_perm(C, Pv, 0x0c020c01u));
-            const us2 l_hi = __builtin_bit_cast(us2, __builtin_amdgcn_perm(C, Pv, 0x0c040c03u));
-            const us2 r_lo = __builtin_bit_cast(us2, __builtin_amdgcn_perm(Nx, C, 0x0c040c03u));
-            const us2 r_hi = __builtin_bit_cast(us2, __builtin_amdgcn_perm(Nx, C, 0x0c060c05u));
-            const uint32_t p01 = cardinal_test(clo[jc], clo[k], clo[jn], l_lo, r_lo, t2);
-            const uint32_t p23 = cardinal_test(chi[jc], chi[k], chi[jn], l_hi, r_hi, t2);
-            // non-zero u16 -> 1: one v_pk_min_u16 each (spelled as asm: the compiler otherwise turns
-            // min(x, 1) into two compares, two selects and a permute)
-            uint32_t b01, b23;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(b01) : "v"(p01), "v"(0x00010001u));
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(b23) : "v"(p23), "v"(0x00010001u));
-            acc01 |= b01 << k;
-            acc23 |= b23 << k;
+            const uint32_t C = c6[jc];
+            const uint32_t Pv = to6(col[jc * LDS_ROW_DW - 1]);
+            const uint32_t Nx = to6(col[jc * LDS_ROW_DW + 1]);
+            const uint32_t l = __builtin_amdgcn_alignbyte(C, Pv, 1);   // pixels x-3 .. x
+            const uint32_t r = __builtin_amdgcn_alignbyte(Nx, C, 3);   // pixels x+3 .. x+6
+            const uint32_t pass = cardinal_test4(C, c6[k], c6[jn], l, r, gt);
+            acc = (acc >> 1) | (pass & SWAR_FLAG);  // after the last row: row k at bit k of every byte
         }
     }
     {
@@ -219,22 +217,20 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         const uint32_t ok1 = (x + 1 >= HALO && x + 1 < v.cols - HALO) ? rowbits : 0u;
         const uint32_t ok2 = (x + 2 >= HALO && x + 2 < v.cols - HALO) ? rowbits : 0u;
         const uint32_t ok3 = (x + 3 >= HALO && x + 3 < v.cols - HALO) ? rowbits : 0u;
-        acc01 &= ok0 | (ok1 << 16);
-        acc23 &= ok2 | (ok3 << 16);
-        const int cnt = __popc(acc01) + __popc(acc23);
+        acc &= ok0 | (ok1 << 8) | (ok2 << 16) | (ok3 << 24);
+        const int cnt = __popc(acc);
         if (cnt != 0) {
-            int pos = atomicAdd(&n_survivors, cnt);
-            const uint32_t ent0 = static_cast<uint32_t>((wave * ROWS_PER_WAVE) << 8) | static_cast<uint32_t>(lane * 4);
-            uint32_t m01 = acc01, m23 = acc23;
-            while (m01 != 0 && pos < SURVIVOR_CAP) {
-                const int b = __ffs(static_cast<int>(m01)) - 1;
-                m01 &= m01 - 1;
-                survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + (b >> 4));
-            }
-            while (m23 != 0 && pos < SURVIVOR_CAP) {
-                const int b = __ffs(static_cast<int>(m23)) - 1;
-                m23 &= m23 - 1;
-                survivors[pos++] = static_cast<uint16_t>(ent0 + ((b & 15) << 8) + 2 + (b >> 4));
+            // entry = thread << 5 | flag bit (13 bits), decoded by phase 2.  A lane whose entries do not all
+            // fit skips the list: the total then exceeds the capacity and phase 2 takes the dense path.
+            const int pos = atomicAdd(&n_survivors, cnt);
+            if (pos + cnt <= SURVIVOR_CAP) {
+                uint16_t* dst = survivors + pos;
+                const uint32_t ent0 = threadIdx.x << 5;
+                uint32_t m = acc;
+                do {
+                    *dst++ = static_cast<uint16_t>(ent0 + static_cast<uint32_t>(__ffs(static_cast<int>(m)) - 1));
+                    m &= m - 1;
+                } while (m != 0);
             }
         }
     }
@@ -270,19 +266,14 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     if (total <= SURVIVOR_CAP) {  // block-uniform
         for (int s = threadIdx.x; s < total; s += 256) {
             const int e = survivors[s];
-            test_pixel(e >> 8, e & 255);
+            test_pixel(((e >> 11) * ROWS_PER_WAVE) + (e & 7), ((e >> 5) & 63) * 4 + ((e >> 3) & 3));
         }
     } else {
         // dense tile: every lane tests the pixels it flagged itself
-        while (acc01 != 0) {
-            const int b = __ffs(static_cast<int>(acc01)) - 1;
-            acc01 &= acc01 - 1;
-            test_pixel(wave * ROWS_PER_WAVE + (b & 15), lane * 4 + (b >> 4));
-        }
-        while (acc23 != 0) {
-            const int b = __ffs(static_cast<int>(acc23)) - 1;
-            acc23 &= acc23 - 1;
-            test_pixel(wave * ROWS_PER_WAVE + (b & 15), lane * 4 + 2 + (b >> 4));
+        while (acc != 0) {
+            const int b = __ffs(static_cast<int>(acc)) - 1;
+            acc &= acc - 1;
+            test_pixel(wave * ROWS_PER_WAVE + (b & 7), lane * 4 + (b >> 3));
         }
     }
     __syncthreads();

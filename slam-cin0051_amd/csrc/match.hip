@@ -1,6 +1,6 @@
 // match.hip -- brute-force Hamming 1-NN with second-best tracking, jump-radius penalty and
 // Lowe ratio test.  Two all-pairs scans with identical results: match_kernel (xor + popcount, below) and
-// match_mfma_kernel (int8 matrix cores, further down; taken for train sets of >= 6144 keypoints).
+// match_mfma_kernel (int8 matrix cores, further down; taken per frame pair when the train set has >= mfma_min_train = 3072 keypoints).
 //
 // Reference (paths relative to the reference root):
 //   calculateHammingDistance   include/slam/common/common.hpp:40-50   (byte LUT popcount)
