@@ -100,12 +100,13 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         const bool ca = x >= 0 && x + 4 <= v.pitch;
         const int xoff = ca ? x : 0;  // lanes outside the frame read a valid address and drop the value
         uint32_t va[NLOAD];
+        const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int yy = y0 + wave + 4 * i;  // wave-uniform
             const bool row_ok = yy >= 0 && yy < v.rows;
-            const uint8_t* row = img + static_cast<size_t>(row_ok ? yy : 0) * v.pitch;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(row + xoff);
+            // buffer load: row offset in a scalar register, column offset in the lane -- no 64-bit vector address math
+            const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(frame, xoff, (row_ok ? yy : 0) * v.pitch, 0);
             va[i] = row_ok && ca ? w : 0u;
         }
 #pragma unroll
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     }
     __syncthreads();
     if (writer) {
+        const __amdgpu_buffer_rsrc_t blurred = __builtin_amdgcn_make_buffer_rsrc(out, 0, v.rows * v.pitch, 0x00020000);
 #pragma unroll
         for (int k = 0; k < ROWS_PER_WAVE; ++k) {
             const int ry = wave * ROWS_PER_WAVE + k;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
             const uint32_t packed = outt[ry * LDS_ROW_DW + lane];
             uint8_t* dst = out + static_cast<size_t>(y) * v.pitch + x;
             if (x + 4 <= v.cols) {
-                *reinterpret_cast<uint32_t*>(dst) = packed;
+                __builtin_amdgcn_raw_buffer_store_b32(packed, blurred, x, y * v.pitch, 0);  // scalar row offset
             } else {
                 for (int p = 0; p < v.cols - x; ++p) {
                     dst[p] = static_cast<uint8_t>(packed >> (8 * p));

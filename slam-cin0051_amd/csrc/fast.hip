@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t cardinal_test4(uint32_t c6, uint32_t u, uint
 //           go to an LDS list.
 //  phase 2: the 16-pixel segment test on the survivors, on dense waves.
 // Pixels that fail the pretest can never be corners, so the bitmap is the reference's.
-__global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc, int nframes, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int threshold, int arc, int nframes, int tiles_x, int tiles_y, uint32_t tiles_x_recip) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint16_t survivors[SURVIVOR_CAP];
     __shared__ uint32_t row_mask[TILE_H][TILE_W / 32];
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
     if (!frame_block(nframes, tiles_x * tiles_y, &f, &tile_id)) {
         return;
     }
-    const int ty = tile_id / tiles_x;
+    // tile_id / tiles_x as a multiply-high by ceil(2^32 / tiles_x): exact while tile_id * tiles_x < 2^32, and a frame
+    // of 65535 x 65535 pixels has 2^19 tiles in rows of 2^8 (0 stands for tiles_x == 1, whose reciprocal does not fit)
+    const int ty = tiles_x_recip != 0 ? static_cast<int>(__umulhi(static_cast<uint32_t>(tile_id), tiles_x_recip)) : tile_id;
     const int tx = tile_id - ty * tiles_x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // scalar: row addresses on the SALU
@@ -133,26 +135,29 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         // a wave stages whole rows (lane -> dword column), threads 0..2*LDS_ROWS-1 the two extra
         // halo dwords of every row; all loads are issued before the first LDS store
         constexpr int NLOAD = (LDS_ROWS + 3) / 4;
+        // Buffer loads: the row offset travels in a scalar register and the column offset in the lane, so a load
+        // costs no vector address math, and what lies outside the frame is zero-filled by the range check
+        // instead of selects: lanes left / right of the frame carry an offset beyond every buffer, rows above /
+        // below it go through a descriptor of 0 bytes.
+        const int frame_bytes = v.rows * v.pitch;
         const int xa = x0 + lane * 4;
-        const bool ca = xa >= 0 && xa + 4 <= v.pitch;
-        const int xoff = ca ? xa : 0;  // lanes outside the frame read a valid address and drop the value
+        const uint32_t xoff = xa >= 0 && xa + 4 <= v.pitch ? static_cast<uint32_t>(xa) : 0xffffffffu;
         uint32_t va[NLOAD];
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int r = wave + 4 * i;  // wave-uniform from here to `row`
+            const int r = wave + 4 * i;  // wave-uniform
             const int yy = y0 + r;
             const bool row_ok = r < LDS_ROWS && yy >= 0 && yy < v.rows;
-            const uint8_t* row = img + static_cast<size_t>(row_ok ? yy : 0) * v.pitch;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(row + xoff);
-            va[i] = row_ok && ca ? w : 0u;
+            const __amdgpu_buffer_rsrc_t rows_of_frame =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, row_ok ? frame_bytes : 0, 0x00020000);
+            va[i] = __builtin_amdgcn_raw_buffer_load_b32(rows_of_frame, xoff, (row_ok ? yy : 0) * v.pitch, 0);
         }
         const int hr = static_cast<int>(threadIdx.x) >> 1;
         const int hx = x0 + (64 + (static_cast<int>(threadIdx.x) & 1)) * 4;
         const int hy = y0 + hr;
         const bool hok = hr < LDS_ROWS && hy >= 0 && hy < v.rows && hx + 4 <= v.pitch;
-        const uint8_t* hsrc = hok ? img + static_cast<size_t>(hy) * v.pitch + hx : img;
-        uint32_t vh = *reinterpret_cast<const uint32_t*>(hsrc);
-        vh = hok ? vh : 0u;
+        const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, frame_bytes, 0x00020000);
+        const uint32_t vh = __builtin_amdgcn_raw_buffer_load_b32(frame, hok ? static_cast<uint32_t>(hy * v.pitch + hx) : 0xffffffffu, 0, 0);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int r = wave + 4 * i;
@@ -203,8 +208,9 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
             acc = (acc >> 1) | (pass & SWAR_FLAG);  // after the last row: row k at bit k of every byte
         }
     }
-    {
-        // image border: rows / columns < 3 or >= size - 3 are never tested (feature_detector.cpp:61-63)
+    // image border: rows / columns < 3 or >= size - 3 are never tested (feature_detector.cpp:61-63); most tiles
+    // do not touch it (block-uniform branch)
+    if (tx * TILE_W < HALO || (tx + 1) * TILE_W > v.cols - HALO || ty * TILE_H < HALO || (ty + 1) * TILE_H > v.rows - HALO) {
         const int ybase = ty * TILE_H + wave * ROWS_PER_WAVE;
         uint32_t rowbits = 0;
 #pragma unroll
@@ -218,6 +224,8 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(BatchView v, int thres
         const uint32_t ok2 = (x + 2 >= HALO && x + 2 < v.cols - HALO) ? rowbits : 0u;
         const uint32_t ok3 = (x + 3 >= HALO && x + 3 < v.cols - HALO) ? rowbits : 0u;
         acc &= ok0 | (ok1 << 8) | (ok2 << 16) | (ok3 << 24);
+    }
+    {
         const int cnt = __popc(acc);
         if (cnt != 0) {
             // entry = thread << 5 | flag bit (13 bits), decoded by phase 2.  A lane whose entries do not all
@@ -534,8 +542,9 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
 void launch_fast_detect(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream) {
     const int tiles_x = (v.cols + TILE_W - 1) / TILE_W;
     const int tiles_y = (v.rows + TILE_H - 1) / TILE_H;
-    hipLaunchKernelGGL(fast_detect_kernel, dim3(frame_grid(nframes, tiles_x * tiles_y)), dim3(256), 0, stream, v, p.threshold,
-                       p.arc, nframes, tiles_x, tiles_y);
+    const uint32_t tiles_x_recip = tiles_x > 1 ? 0xffffffffu / static_cast<uint32_t>(tiles_x) + 1u : 0u;
+    hipLaunchKernelGGL(fast_detect_kernel, frame_grid(nframes, tiles_x * tiles_y), dim3(256), 0, stream, v, p.threshold, p.arc,
+                       nframes, tiles_x, tiles_y, tiles_x_recip);
 }
 
 void launch_scan(const BatchView& v, int nframes, hipStream_t stream) {

@@ -144,28 +144,32 @@ inline int grid_x(int items, int per_block, int nframes) {
     return blocks < 1 ? 1 : blocks;
 }
 
-// 1-D grid -> (frame, block-in-frame).  The hardware deals consecutive workgroup ids round-robin
-// over the 8 XCDs, so a 2-D grid whose x extent is a multiple of 8 pins block column k to XCD k
+// 3-D grid -> (frame, block-in-frame).  The hardware deals consecutive workgroup ids (x fastest) round-robin
+// over the 8 XCDs, so a grid whose x extent is a multiple of 8 pins block column k to XCD k
 // (uneven columns then idle whole XCDs).  With 8 or more frames all blocks of a frame land on ONE
 // XCD, frame after frame: its 4 MB L2 then only has to hold the active row bands of the few frames
 // in flight, and neighbouring tiles / keypoint patches of a frame find each other's lines there.
 // With fewer frames the blocks are simply dealt round-robin.
 // Placement is a speed matter only.
-inline unsigned frame_grid(int nframes, int blocks_per_frame) {
-    const int slots = nframes >= 8 ? 8 * ((nframes + 7) / 8) : nframes;
-    return static_cast<unsigned>(slots) * static_cast<unsigned>(blocks_per_frame);
+inline dim3 frame_grid(int nframes, int blocks_per_frame) {
+    // x: the frame's slot among the 8 XCDs (workgroups are dealt to XCDs round robin in x-fastest order),
+    // y: block of the frame, z: group of 8 frames -- the kernel reads all three off blockIdx, no division.
+    // More blocks per frame than grid.y holds (frames beyond ~500 Mpixel) spill into z.
+    const unsigned y = static_cast<unsigned>(blocks_per_frame < 65535 ? (blocks_per_frame > 0 ? blocks_per_frame : 1) : 65535);
+    const unsigned parts = (static_cast<unsigned>(blocks_per_frame) + y - 1) / y;
+    const unsigned groups = nframes >= 8 ? static_cast<unsigned>((nframes + 7) / 8) : 1u;
+    return dim3(nframes >= 8 ? 8u : static_cast<unsigned>(nframes), y, groups * (parts > 0 ? parts : 1u));
 }
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool frame_block(int nframes, int blocks_per_frame, int* f, int* bx) {
-    const int id = static_cast<int>(blockIdx.x);
-    if (nframes >= 8) {
-        const int q = id >> 3;
-        *f = (id & 7) + 8 * (q / blocks_per_frame);  // an XCD takes its frames one after another
-        *bx = q - (q / blocks_per_frame) * blocks_per_frame;
-    } else {
-        *f = id % nframes;
-        *bx = id / nframes;
+    unsigned group = blockIdx.z, part = 0;
+    if (gridDim.y < static_cast<unsigned>(blocks_per_frame)) {
+        const unsigned parts = (static_cast<unsigned>(blocks_per_frame) + gridDim.y - 1) / gridDim.y;
+        group = blockIdx.z / parts;
+        part = blockIdx.z - group * parts;
     }
+    *f = static_cast<int>(blockIdx.x + 8 * group);  // an XCD takes its frames one after another
+    *bx = static_cast<int>(blockIdx.y + part * gridDim.y);
     return *f < nframes && *bx < blocks_per_frame;
 }
 #endif

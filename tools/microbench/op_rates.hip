@@ -93,6 +93,74 @@ DEFINE_MIX_KERNEL(k_dep_pairs, "v_xor_b32 %0, %0, %4", "v_add_u32 %0, %0, %4", "
 DEFINE_MIX_KERNEL(k_mix_f_pk, "v_add_u32 %0, %0, %4", "v_pk_min_u16 %1, %1, %4", "v_sub_u32 %2, %4, %2", "v_pk_max_u16 %3, %3, %4")
 DEFINE_MIX_KERNEL(k_mix_f_bitop3, "v_add_u32 %0, %0, %4", "v_sub_u32 %1, %4, %1", "v_bitop3_b32 %2, %2, %4, %4 bitop3:0xe8", "v_and_b32 %3, %4, %3")
 
+// 64-bit address arithmetic the compiler emits for pointer + lane offset
+__global__ __launch_bounds__(256) void k_mad_i64_i32(uint32_t* out, int iters, uint32_t seed) {
+    unsigned long long q[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        q[k] = seed * (threadIdx.x + 1) + k * 977u;
+    }
+    const uint32_t t = seed ^ (threadIdx.x * 2654435761u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                asm volatile("v_mad_i64_i32 %0, vcc, %1, %1, %0" : "+v"(q[k]) : "v"(t) : "vcc");
+            }
+        }
+    }
+    unsigned long long r = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        r += q[k];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<uint32_t>(r ^ (r >> 32));
+}
+__global__ __launch_bounds__(256) void k_lshl_add_u64(uint32_t* out, int iters, uint32_t seed) {
+    unsigned long long q[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        q[k] = seed * (threadIdx.x + 1) + k * 977u;
+    }
+    const unsigned long long t = (static_cast<unsigned long long>(seed) << 20) ^ (threadIdx.x * 2654435761u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[k]) : "v"(t));
+            }
+        }
+    }
+    unsigned long long r = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+        r += q[k];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<uint32_t>(r ^ (r >> 32));
+}
+// dword reads from the LDS at addresses that are 1 mod 4 (every read straddles two banks)
+__global__ __launch_bounds__(256) void k_lds_unaligned(uint32_t* out, int iters, uint32_t seed) {
+    __shared__ uint32_t buf[4096 + 4];
+    for (int i = threadIdx.x; i < 4096 + 4; i += 256) {
+        buf[i] = seed * i;
+    }
+    __syncthreads();
+    uint32_t acc = 0;
+    const char* base = reinterpret_cast<const char*>(buf);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int off = ((threadIdx.x * 4 + r * 4096 / 32 * 4 + i * 16) & (16384 - 4)) + 1;
+            uint32_t w;
+            __builtin_memcpy(&w, base + off, 4);
+            acc += w;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // packed f32 needs register pairs
 __global__ __launch_bounds__(256) void k_pk_fma_f32(uint32_t* out, int iters, uint32_t seed) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -245,8 +313,11 @@ int main() {
     RUN(k_mix_f_bitop3);
     run("k_pk_fma_f32 (instr)", k_pk_fma_f32, per, iters);
     run("k_fma_f64", k_fma_f64, per, iters);
+    run("k_mad_i64_i32", k_mad_i64_i32, per, iters);
+    run("k_lshl_add_u64", k_lshl_add_u64, per, iters);
     run("lds read u8", k_lds<1>, 32.0, 1000);
     run("lds read b32", k_lds<4>, 32.0, 1000);
+    run("lds read b32 at 1 mod 4", k_lds_unaligned, 32.0, 1000);
     run("lds read b64", k_lds<8>, 32.0, 1000);
     run("lds read b128", k_lds<16>, 32.0, 1000);
     hipFree(d);
