@@ -57,12 +57,14 @@ __device__ __forceinline__ uint32_t exact_pixel(const uint8_t* pc, const double*
     return static_cast<uint32_t>(static_cast<int>(round(acc)));
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // lane i <- lane i-1 / lane i+1 of the wave (lanes 0 / 63 receive 0)
 __device__ __forceinline__ float from_left(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));  // bound_ctrl: 0 shifted in
 }
 __device__ __forceinline__ float from_right(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 
 __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __restrict__ weights) {
@@ -97,17 +99,19 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         // a wave stages whole rows, lane -> dword column; all loads are issued before the first LDS store
         constexpr int NLOAD = LDS_ROWS / 4;
         static_assert(LDS_ROWS % 4 == 0, "rows are dealt to 4 waves");
-        const bool ca = x >= 0 && x + 4 <= v.pitch;
-        const int xoff = ca ? x : 0;  // lanes outside the frame read a valid address and drop the value
+        // Buffer loads: row offset in a scalar register, column offset in the lane (no 64-bit vector address
+        // math); what lies outside the frame is zero-filled by the range check -- lanes left / right of it carry
+        // an offset beyond every buffer, rows above / below it go through a descriptor of 0 bytes.
+        const int frame_bytes = v.rows * v.pitch;
+        const uint32_t xoff = x >= 0 && x + 4 <= v.pitch ? static_cast<uint32_t>(x) : 0xffffffffu;
         uint32_t va[NLOAD];
-        const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int yy = y0 + wave + 4 * i;  // wave-uniform
             const bool row_ok = yy >= 0 && yy < v.rows;
-            // buffer load: row offset in a scalar register, column offset in the lane -- no 64-bit vector address math
-            const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(frame, xoff, (row_ok ? yy : 0) * v.pitch, 0);
-            va[i] = row_ok && ca ? w : 0u;
+            const __amdgpu_buffer_rsrc_t rows_of_frame =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, row_ok ? frame_bytes : 0, 0x00020000);
+            va[i] = __builtin_amdgcn_raw_buffer_load_b32(rows_of_frame, xoff, (row_ok ? yy : 0) * v.pitch, 0);
         }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -161,24 +165,36 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
                 const float* rc = win[(k + 2) % 5];
                 const float* rp1 = win[(k + 3) % 5];
                 const float* rp2 = win[(k + 4) % 5];
-                float h[8];  // vertical pass of columns x-2 .. x+5; h[2..5] are this lane's own
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    h[2 + c] = fmaf(g0, rm2[c] + rp2[c], fmaf(g1, rm1[c] + rp1[c], g2 * rc[c]));
-                }
-                h[0] = from_left(h[4]);
-                h[1] = from_left(h[5]);
-                h[6] = from_right(h[2]);
-                h[7] = from_right(h[3]);
+                // Column pairs as 64-bit operands: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 do two columns per
+                // instruction with the roundings of the scalar forms.  Vertical pass of columns x-2 .. x+5 as the
+                // pairs h01, h23, h45, h67; h23 and h45 are this lane's own.
+                const f2 G0 = {g0, g0}, G1 = {g1, g1}, G2 = {g2, g2};
+                const f2 h23 = __builtin_elementwise_fma(
+                    G0, f2{rm2[0], rm2[1]} + f2{rp2[0], rp2[1]},
+                    __builtin_elementwise_fma(G1, f2{rm1[0], rm1[1]} + f2{rp1[0], rp1[1]}, G2 * f2{rc[0], rc[1]}));
+                const f2 h45 = __builtin_elementwise_fma(
+                    G0, f2{rm2[2], rm2[3]} + f2{rp2[2], rp2[3]},
+                    __builtin_elementwise_fma(G1, f2{rm1[2], rm1[3]} + f2{rp1[2], rp1[3]}, G2 * f2{rc[2], rc[3]}));
+                const f2 h01 = {from_left(h45.x), from_left(h45.y)};
+                const f2 h67 = {from_right(h23.x), from_right(h23.y)};
+                // horizontal pass: outputs (0, 1) and (2, 3); the odd-distance sums straddle the pairs and stay scalar
+                const f2 odd01 = {h01.y + h23.y, h23.x + h45.x};
+                const f2 odd23 = {h23.y + h45.y, h45.x + h67.x};
+                const f2 est01 = __builtin_elementwise_fma(G0, h01 + h45, __builtin_elementwise_fma(G1, odd01, G2 * h23));
+                const f2 est23 = __builtin_elementwise_fma(G0, h23 + h67, __builtin_elementwise_fma(G1, odd23, G2 * h45));
+                // est >= 0; round-to-nearest equals floor(est + 0.5) away from the .5 boundary
                 uint32_t acc = 0;
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(est01.x, 0, acc);
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(est01.y, 1, acc);
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(est23.x, 2, acc);
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(est23.y, 3, acc);
+                const f2 UNC = {UNC_LO, UNC_LO};
+                const f2 d01 = est01 - UNC, d23 = est23 - UNC;
                 float w[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float est = fmaf(g0, h[p] + h[p + 4], fmaf(g1, h[p + 1] + h[p + 3], g2 * h[p + 2]));
-                    // est >= 0; round-to-nearest equals floor(est + 0.5) away from the .5 boundary
-                    acc = __builtin_amdgcn_cvt_pk_u8_f32(est, p, acc);
-                    w[p] = __builtin_amdgcn_fractf(est - UNC_LO);
-                }
+                w[0] = __builtin_amdgcn_fractf(d01.x);
+                w[1] = __builtin_amdgcn_fractf(d01.y);
+                w[2] = __builtin_amdgcn_fractf(d23.x);
+                w[3] = __builtin_amdgcn_fractf(d23.y);
                 packed = (src & keep) | (acc & ~keep);
                 const bool some = writer && fminf(fminf(w[0], w[1]), fminf(w[2], w[3])) <= UNC_SPAN;
                 if (__ballot(some) != 0) {  // about a quarter of the wave-rows
