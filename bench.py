@@ -402,9 +402,10 @@ def main():
     ncand, nkp, nmatch = batch.counts(B)  # also surfaces capacity overflows loudly
 
     K = args.steps
-    # hipEvents between the kernels of every 4th timed step (of every step when there are few): an
-    # event between two kernels keeps the second from starting while the first drains, ~9 % of a step
-    every = 4 if K >= 8 else 1
+    # hipEvents between the kernels of every 8th timed step (every 4th / every step when there are few): an
+    # event between two kernels keeps the second from starting while the first drains, ~18 % of such a step
+    # (2.95 ms per step without events, 3.09 with events on every 4th step)
+    every = 8 if K >= 16 else (4 if K >= 8 else 1)
     sets = min((K + every - 1) // every, 256)
     batch.set_profiling(sets, every)
     if dist is not None:
@@ -415,6 +416,8 @@ def main():
     for _ in range(K):
         step()
     # end of the job: triangulate the newest pair and gather the map points of all ranks
+    ctx.synchronize()
+    t_tail = time.perf_counter()
     xyz = triangulate_last_pair(ctx, batch, matcher, B, wl["cols"], wl["rows"])
     n_map_points = xyz.shape[0]
     if dist is not None:
@@ -424,6 +427,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    end_of_job_ms = (time.perf_counter() - t_tail) * 1e3  # inside `elapsed`: downloads of the newest pair, triangulation, gather
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -530,7 +534,7 @@ def main():
                        "parallelism": "frames sharded one stream per GPU (dp%d), no data-path collective" % n_gpus},
             "matched_keypoints_per_s": N * fps,
             "map_points_gathered": n_map_points,
-            "stage_ms_per_step": stage,
+            "stage_ms_per_step": stage, "end_of_job_ms": end_of_job_ms,
             "roofline": roof,
             "kernel_rooflines": others,
             "frontend_hbm": {"achieved": b_fe / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None, "peak": HBM_PEAK_GBS,

@@ -76,7 +76,7 @@ __device__ __forceinline__ bool segment_test(uint32_t B, uint32_t D, int arc) {
 // 98-113; pretest A, :81-96, is implied -- 3 of 4 cardinals include pixel 0 or pixel 8).  Pixels are
 // reduced to 6 bits (p >> 2) so that every byte keeps two guard bits and whole dwords can be compared
 // with plain 32-bit adds and subtracts, which issue faster than any packed or three-operand form
-// (profiles/r03_op_rates_microbench.txt).  With t6 = (t + 1) >> 2:
+// (profiles/r02_op_rates_microbench.txt).  With t6 = (t + 1) >> 2:
 //     n > c + t  =>  (n >> 2) >= (c >> 2) + t6          n < c - t  =>  (n >> 2) <= (c >> 2) - t6
 // (floor is monotone and superadditive), so a pixel the reference's pretest lets through always
 // passes here; the few extra survivors fail the exact segment test of phase 2.

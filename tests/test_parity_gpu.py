@@ -86,6 +86,29 @@ def test_fast_candidates_dense_noise(slamx, oracle, arc, t):
     assert_records_equal(got, ref, "dense noise arc=%d t=%d" % (arc, t))
 
 
+@pytest.mark.parametrize("t,arc", [(0, 9), (1, 2), (2, 3), (3, 5), (4, 7), (5, 8), (7, 10), (62, 11), (63, 13), (64, 15),
+                                   (127, 12), (250, 4), (255, 6), (21, 12), (22, 12), (23, 12)])
+def test_fast_quick_reject_quantisation(slamx, oracle, t, arc):
+    """The quick reject of fast_detect_kernel compares pixels reduced to 6 bits against (t + 1) >> 2 and must
+    never drop a pixel the reference's pretest lets through: thresholds at and around the multiples of four, at
+    both ends of the range, centre / circle differences of exactly t - 1, t, t + 1, t + 2 at every alignment
+    modulo 4, saturated pixels, and arc lengths that take every path of the log-step run test."""
+    rng = np.random.default_rng(1000 * t + arc)
+    rows, cols = 96, 520  # three tile columns, the last one partial
+    base = rng.integers(0, 256, (rows, cols))
+    # blocks of constant level with single pixels offset by t-1 .. t+2 in both directions
+    level = rng.integers(0, 256, (rows // 8 + 1, cols // 8 + 1)).repeat(8, 0).repeat(8, 1)[:rows, :cols]
+    delta = rng.choice([-(t + 2), -(t + 1), -t, -(t - 1), 0, 0, 0, t - 1, t, t + 1, t + 2], (rows, cols))
+    flat = np.clip(level + np.where(rng.random((rows, cols)) < 0.4, delta, 0), 0, 255)
+    img = np.where(rng.random((rows, cols)) < 0.15, base, flat)
+    img[:, :40] = np.where(rng.random((rows, 40)) < 0.5, 255, 0)  # saturated ends
+    img = np.ascontiguousarray(img.astype(np.uint8))
+    d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=arc))
+    Pp = oracle.det_params(d.cfg)
+    got, ref = d.fast_candidates(img), oracle.fast_candidates(img, Pp)
+    assert_records_equal(got, ref, "quick reject t=%d arc=%d" % (t, arc))
+
+
 @pytest.mark.parametrize("shape", [(64, 96), (200, 700)])
 def test_more_than_a_quarter_of_the_pixels_are_corners(slamx, oracle, shape):
     """ContiguousPixelsThreshold 0 (accepted by the reference's validator) on noise: every pixel that

@@ -5,7 +5,7 @@
 #   3. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the default command (HBM traffic)
 #   4. separate --pmc passes for the instruction mix (SQ_INSTS_*) and the busy counters (TA, VALU)
 #   5. matrix-core counters: FP64 MFMA of gn_accumulate_kernel (c4), int8 MFMA of match_mfma_kernel (c3)
-#   6. tools/microbench: sustained FP64 MFMA rate
+#   6. tools/microbench: sustained FP64 MFMA rate, issue rates of the VALU / LDS instructions the kernels lean on
 # usage: tools/collect_profiles.sh <tag>      (writes under gpurun_out/<tag>/)
 set -e
 tag=${1:-r02}
@@ -23,6 +23,7 @@ echo "c3p done"
 python bench.py --workload c4 --steps 20 --warmup 3 > "$out/bench_c4.json"
 echo "c4 done"
 ./tools/microbench/mfma_f64_peak > "$out/mfma_f64_peak.txt"
+./tools/microbench/op_rates > "$out/op_rates.txt"
 P="--no-cpu-baseline --no-pcie"
 rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 $P > "$out/bench_under_rocprof.json"
 rocprofv3 --kernel-trace --stats -d "$out/stats_c3" -o stats --output-format csv -- python bench.py --workload c3 --steps 5 --warmup 2 $P > "$out/bench_c3_under_rocprof.json"
