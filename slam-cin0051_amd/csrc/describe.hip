@@ -264,11 +264,12 @@ struct TilePrefetch {
             off[k] = r * pitch + (ee - r * DW) * 4;
         }
     }
-    __device__ __forceinline__ void issue_inside(const uint8_t* img, int pitch, int x, int y, const int* off) {
-        const uint8_t* base = img + static_cast<size_t>(y - HALF) * pitch + ((x - HALF) & ~3);
+    // (buffer loads: the tile's first byte is a scalar offset, off[k] the lane's -- no 64-bit vector address math)
+    __device__ __forceinline__ void issue_inside(__amdgpu_buffer_rsrc_t frame, int pitch, int x, int y, const int* off) {
+        const int base = (y - HALF) * pitch + ((x - HALF) & ~3);
 #pragma unroll
         for (int k = 0; k < PER_LANE; ++k) {
-            reg[k] = *reinterpret_cast<const uint32_t*>(base + off[k]);
+            reg[k] = __builtin_amdgcn_raw_buffer_load_b32(frame, off[k], base, 0);
         }
     }
     __device__ __forceinline__ void commit(uint32_t* tile, int lane) const {
@@ -301,11 +302,11 @@ struct TilePrefetch12 {
         }
     }
     // tile entirely inside the padded frame (the caller checks)
-    __device__ __forceinline__ void issue_inside(const uint8_t* img, int pitch, int x, int y, const int* off) {
-        const uint8_t* base = img + static_cast<size_t>(y - HALF) * pitch + ((x - HALF) & ~3);
+    __device__ __forceinline__ void issue_inside(__amdgpu_buffer_rsrc_t frame, int pitch, int x, int y, const int* off) {
+        const int base = (y - HALF) * pitch + ((x - HALF) & ~3);  // scalar: x, y come from readlane
 #pragma unroll
         for (int k = 0; k < PER_LANE; ++k) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(base + off[k]);
+            const auto p = __builtin_amdgcn_raw_buffer_load_b96(frame, off[k], base, 0);
             reg[k][0] = p[0];
             reg[k][1] = p[1];
             reg[k][2] = p[2];
@@ -596,10 +597,11 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF> pf;
     int tile_off[TilePrefetch<TILE_ROWS, TILE_DW, TILE_HALF>::PER_LANE];
     pf.init_offsets(v.pitch, lane, tile_off);
+    const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
     auto fetch = [&](int x, int y) {  // wave-uniform choice: no per-element bounds checks when the tile is inside
         const int xa = (x - TILE_HALF) & ~3;
         if (x - TILE_HALF >= 0 && xa + TILE_DW * 4 <= v.pitch && y - TILE_HALF >= 0 && y + TILE_HALF < v.rows) {
-            pf.issue_inside(img, v.pitch, x, y, tile_off);
+            pf.issue_inside(frame_rsrc, v.pitch, x, y, tile_off);
         } else {
             pf.issue(v, img, x, y, lane);
         }
@@ -757,6 +759,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
     Prefetch pf[FUSED_PER_WAVE];  // the tiles of the NEXT group travel in registers while this one is worked on
     int tile_off[Prefetch::PER_LANE];
     pf[0].init_offsets(v.pitch, lane, tile_off);
+    const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
     // orientation patch = 31 rows x 8 dwords that start AT column x - 15: slot k of a lane is patch dword
     // e = lane + 64 k (row e / 8, dword e % 8), whose bytes straddle two tile dwords
     constexpr int SLOTS = MOMENT_ALIGNED_SLOTS;
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
             if ((masks >> q) & 1u) {  // wave-uniform
                 const int x = lane_value(kx, q), y = lane_value(ky, q);
                 if ((masks >> (16 + q)) & 1u) {
-                    pf[q].issue_inside(img, v.pitch, x, y, tile_off);
+                    pf[q].issue_inside(frame_rsrc, v.pitch, x, y, tile_off);
                 } else {
                     pf[q].issue(v, img, x, y, lane);
                 }
