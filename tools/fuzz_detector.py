@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the detector against the CPU restatement (oracle/): random shapes, thresholds, arc
+lengths and image statistics through FAST candidates, and detect + compute on the smaller ones.
+Test infrastructure (uses oracle/ as the checker).  usage: tools/fuzz_detector.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import importlib
+
+import oracle_binding
+
+
+def image(rng, rows, cols):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return rng.integers(0, 256, (rows, cols))
+    if kind == 1:  # blocks with small noise
+        b = int(rng.integers(2, 24))
+        lvl = rng.integers(0, 256, (rows // b + 1, cols // b + 1)).repeat(b, 0).repeat(b, 1)[:rows, :cols]
+        return np.clip(lvl + rng.integers(-6, 7, (rows, cols)), 0, 255)
+    if kind == 2:  # gradients: every difference value at every alignment
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        return (xx * int(rng.integers(1, 9)) + yy * int(rng.integers(0, 5))) % 256
+    if kind == 3:  # two levels
+        a, b = rng.integers(0, 256, 2)
+        return np.where(rng.random((rows, cols)) < rng.random(), a, b)
+    if kind == 4:  # sparse spikes on a flat background
+        bg = int(rng.integers(0, 256))
+        return np.where(rng.random((rows, cols)) < 0.03, rng.integers(0, 256, (rows, cols)), bg)
+    amp = int(rng.integers(1, 64))  # narrow band of values around a level near either end
+    base = int(rng.choice([0, 255, rng.integers(0, 256)]))
+    return np.clip(base + rng.integers(-amp, amp + 1, (rows, cols)), 0, 255)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    slamx = importlib.import_module("slam-cin0051_amd")
+    oracle = oracle_binding.load()
+    rng = np.random.default_rng(seed)
+    for case in range(cases):
+        rows = int(rng.integers(7, 140))
+        cols = int(rng.choice([rng.integers(7, 80), rng.integers(200, 300), rng.integers(500, 560)]))
+        t = int(rng.choice([rng.integers(0, 8), rng.integers(8, 64), rng.integers(64, 256)]))
+        arc = int(rng.integers(0, 17))
+        window = int(rng.integers(1, 16))
+        img = np.ascontiguousarray(image(rng, rows, cols).astype(np.uint8))
+        cfg = slamx.DetectorConfig(t, arc, 1, window, 31, 256)
+        det = slamx.FeatureDetector(cfg)
+        P = oracle.det_params(cfg)
+        got, ref = det.fast_candidates(img), oracle.fast_candidates(img, P)
+        tag = "case %d: %dx%d t=%d arc=%d window=%d" % (case, rows, cols, t, arc, window)
+        assert len(got) == len(ref) and np.array_equal(got, ref), "candidates differ, " + tag
+        if len(ref) < 4000:  # the oracle's greedy loop is quadratic
+            k_ref, d_ref = oracle.detect_and_compute(img, P)
+            k_got, d_got = det.detectAndCompute(img)
+            assert len(k_got) == len(k_ref) and np.array_equal(k_got, k_ref), "keypoints differ, " + tag
+            assert np.array_equal(d_got, d_ref), "descriptors differ, " + tag
+        det.close() if hasattr(det, "close") else None
+    print("fuzz_detector: %d cases identical (seed %d)" % (cases, seed))
+
+
+if __name__ == "__main__":
+    main()
