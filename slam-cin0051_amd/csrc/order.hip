@@ -447,13 +447,20 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
             nr += static_cast<uint32_t>(__popcll(__ballot(held[c] >= p) & m_in));
         }
     } else {
-        for (int base = w_lo; base < w_hi; base += 64) {
-            const int i = base + lane;
-            const bool in = i < w_hi;
-            const uint32_t sc = in ? score_of(a[i]) : 0u;
-            const unsigned long long m_in = __ballot(in);
-            nl += static_cast<uint32_t>(__popcll(__ballot(sc <= p) & m_in));
-            nr += static_cast<uint32_t>(__popcll(__ballot(sc >= p) & m_in));
+        // streamed in blocks of RC chunks: sixteen loads in flight per wave instead of one dependent load per 64 keys
+        for (int blk = w_lo; blk < w_hi; blk += 64 * RC) {
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const int i = blk + c * 64 + lane;
+                held[c] = i < w_hi ? score_of(a[i]) : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const bool in = blk + c * 64 + lane < w_hi;
+                const unsigned long long m_in = __ballot(in);
+                nl += static_cast<uint32_t>(__popcll(__ballot(held[c] <= p) & m_in));
+                nr += static_cast<uint32_t>(__popcll(__ballot(held[c] >= p) & m_in));
+            }
         }
     }
     if (lane == 0) {
@@ -516,9 +523,18 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
             }
         }
     } else {
-        for (int base = w_lo; base < w_hi; base += 64) {
-            const int i = base + lane;
-            classify(base, i < w_hi ? score_of(a[i]) : 0u);
+        for (int blk = w_lo; blk < w_hi; blk += 64 * RC) {
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const int i = blk + c * 64 + lane;
+                held[c] = i < w_hi ? score_of(a[i]) : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                if (blk + c * 64 < w_hi) {  // wave-uniform
+                    classify(blk + c * 64, held[c]);
+                }
+            }
         }
     }
     if (lane == 0) {
@@ -550,7 +566,7 @@ __device__ int SORT_BLOCK_MIN = 3072;  // segments at least this long are partit
 // sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
 // seq == t + 1).  Queued segments are disjoint ranges of more than SORT_LEAF keys, so at most
 // len / 17 of them exist at any time: with SORT_QCAP >= lds_keys / 17 + 32 the ring never fills.
-constexpr int SORT_QCAP = 2048;
+constexpr int SORT_QCAP = 1024;
 constexpr int SORT_LDS_KEYS_MAX = 16384;
 static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
 
@@ -790,7 +806,7 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q
 //   lists    : 3 * maxSeg int2 (global): two level lists + the list of LDS-sized segments
 // Segments longer than lds_keys are partitioned in global memory by the whole workgroup until
 // they fit; every remaining segment is then sorted in LDS.  Returns 0 or STATUS_SEG_OVERFLOW.
-__device__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* gsegbits,
+__device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* gsegbits,
                                int2* lists, int maxSeg, int n, SortShared& sh, uint32_t* rank_of = nullptr,
                                const uint32_t* xy = nullptr) {
     const bool all_in_lds = n <= lds_keys;
