@@ -2,6 +2,7 @@
 // gfx950 only: wave = 64 lanes everywhere in this code base.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -155,7 +156,13 @@ inline dim3 frame_grid(int nframes, int blocks_per_frame) {
     // x: the frame's slot among the 8 XCDs (workgroups are dealt to XCDs round robin in x-fastest order),
     // y: block of the frame, z: group of 8 frames -- the kernel reads all three off blockIdx, no division.
     // More blocks per frame than grid.y holds (frames beyond ~500 Mpixel) spill into z.
-    const unsigned y = static_cast<unsigned>(blocks_per_frame < 65535 ? (blocks_per_frame > 0 ? blocks_per_frame : 1) : 65535);
+    // (SLAMX_GRID_Y_LIMIT: a test hook that lowers the limit, so that ordinary frames exercise the spill into z)
+    static const int y_limit = [] {
+        const char* e = std::getenv("SLAMX_GRID_Y_LIMIT");
+        const int v = e != nullptr ? std::atoi(e) : 0;
+        return v >= 1 && v <= 65535 ? v : 65535;
+    }();
+    const unsigned y = static_cast<unsigned>(blocks_per_frame < y_limit ? (blocks_per_frame > 0 ? blocks_per_frame : 1) : y_limit);
     const unsigned parts = (static_cast<unsigned>(blocks_per_frame) + y - 1) / y;
     const unsigned groups = nframes >= 8 ? static_cast<unsigned>((nframes + 7) / 8) : 1u;
     return dim3(nframes >= 8 ? 8u : static_cast<unsigned>(nframes), y, groups * (parts > 0 ? parts : 1u));

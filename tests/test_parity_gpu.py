@@ -613,6 +613,25 @@ def test_match_errors(slamx):
 
 
 # ---------------------------------------------------------------- device-resident batches
+def test_block_ids_spill_into_grid_z():
+    """Kernels that take (frame, block) off a 3-D grid put the blocks of a frame in grid.y; beyond 65535 blocks
+    per frame (frames of half a gigapixel) the rest spills into grid.z.  SLAMX_GRID_Y_LIMIT lowers that limit to 5
+    in a child process, so that ordinary frames (21 FAST tiles, dozens of describe / downscale blocks) take the
+    spill path through FAST, expand, describe and the pyramid's downscale -- bit-exact against the oracle."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SLAMX_GRID_Y_LIMIT="5")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_parity_gpu.py"),
+                        os.path.join(here, "test_pyramid_gpu.py"), "-k",
+                        "batch_equals_single_frame or pipeline_odd_shapes or levels_match_the_cpu_downscale or pyramid_batch_with_matching or "
+                        "fast_candidates_shapes_and_thresholds"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and " passed" in out, out[-2000:]
+
+
 def test_batch_equals_single_frame(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     Pp = oracle.det_params(d.cfg)
