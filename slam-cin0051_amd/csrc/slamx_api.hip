@@ -70,6 +70,10 @@ struct slamx_ctx {
     bool owns_stream = false;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     std::string name;
+    int n_cus = 0;
+    // second queue of the context: the blur of a batch beside its sort + NMS (blur_beside_sort), created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
 };
 
 struct slamx_detector {
@@ -274,6 +278,47 @@ void enqueue_detect(slamx_batch* b, int nframes) {
     }
 }
 
+// FAST bitmap -> prefix -> candidates, without events (the overlapped form below is not taken on profiled calls)
+void enqueue_detect_until_sort(slamx_batch* b, int nframes) {
+    hipStream_t s = b->det->ctx->stream;
+    const DetectorParams p = params_of(b->det);
+    launch_fast_detect(b->v, p, nframes, s);
+    launch_scan(b->v, nframes, s);
+    launch_expand(b->v, p, nframes, s);
+}
+
+// Whether this call queues the blur beside sort + NMS (see slamx_batch_detect_and_compute): NMS on, the sort a single
+// round of workgroups, a batch large enough to be worth two more events, and no per-stage events on this call.
+// SLAMX_BLUR_BESIDE_SORT=0 / 1 switches it off / on for every batch of at least two frames (experiments, tests).
+bool blur_beside_sort(slamx_batch* b, int nframes) {
+    static const int forced = std::getenv("SLAMX_BLUR_BESIDE_SORT") ? std::atoi(std::getenv("SLAMX_BLUR_BESIDE_SORT")) : -1;
+    slamx_ctx* c = b->det->ctx;
+    if (forced == 0 || b->det->cfg.non_max_suppression == 0 || (b->n_sets > 0 && b->active) || nframes < 2) {
+        return false;
+    }
+    if (forced != 1 && (nframes < 16 || nframes > c->n_cus)) {
+        return false;
+    }
+    if (c->side == nullptr) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo) != hipSuccess) {
+            c->side = nullptr;
+        }
+    }
+    if (c->side != nullptr && c->e_fork == nullptr && hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming) != hipSuccess) {
+        c->e_fork = nullptr;
+    }
+    if (c->side != nullptr && c->e_join == nullptr && hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming) != hipSuccess) {
+        c->e_join = nullptr;
+    }
+    if (c->side == nullptr || c->e_fork == nullptr || c->e_join == nullptr) {
+        (void)hipGetLastError();
+        return false;  // the serial order is always available; what was created is released with the context
+    }
+    return true;
+}
+
 // compute part: blur -> orientation + BRIEF
 void enqueue_compute(slamx_batch* b, int nframes, bool after_nms) {
     hipStream_t s = b->det->ctx->stream;
@@ -412,6 +457,7 @@ int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
     auto* c = new slamx_ctx();
     c->device = device_ordinal;
     c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    c->n_cus = prop.multiProcessorCount;
     if (hip_stream != nullptr) {
         c->stream = static_cast<hipStream_t>(hip_stream);
     } else {
@@ -444,6 +490,16 @@ void slamx_ctx_destroy(slamx_ctx* ctx) {
     }
     if (ctx->t1 != nullptr) {
         (void)hipEventDestroy(ctx->t1);
+    }
+    if (ctx->side != nullptr) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->e_fork != nullptr) {
+        (void)hipEventDestroy(ctx->e_fork);
+    }
+    if (ctx->e_join != nullptr) {
+        (void)hipEventDestroy(ctx->e_join);
     }
     if (ctx->owns_stream && ctx->stream != nullptr) {
         (void)hipStreamDestroy(ctx->stream);
@@ -844,8 +900,27 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
     }
     HIP_TRY(hipSetDevice(b->det->ctx->device));
     begin_set(b);
-    enqueue_detect(b, nframes);
-    enqueue_compute(b, nframes, true);
+    if (blur_beside_sort(b, nframes)) {
+        // The blur needs the frames only, so it is queued on the context's second stream right before the sort and
+        // joined before the describe kernel.  Taken when the sort is ONE round of workgroups (a frame per CU, each
+        // for the whole launch: 110 KB of LDS and 64 registers leave room for two blur workgroups beside it):
+        // 7.87 -> 7.52 ms per 256 frames of 80k candidates.  With more frames than CUs the blur's workgroups take
+        // the LDS the next round of sort workgroups waits for and nothing is gained.
+        slamx_ctx* c = b->det->ctx;
+        const DetectorParams p = params_of(b->det);
+        enqueue_detect_until_sort(b, nframes);
+        (void)hipEventRecord(c->e_fork, c->stream);
+        (void)hipStreamWaitEvent(c->side, c->e_fork, 0);
+        launch_blur(b->v, b->det->weights_dev, nframes, c->side);
+        (void)hipEventRecord(c->e_join, c->side);
+        launch_sort(b->v, nframes, c->stream, !nms_uses_greedy_path(b->v, p));
+        launch_nms(b->v, p, nframes, c->stream, nullptr);
+        (void)hipStreamWaitEvent(c->stream, c->e_join, 0);
+        launch_describe(b->v, p, b->det->pattern_dev, nframes, true, c->stream, nullptr, nullptr);
+    } else {
+        enqueue_detect(b, nframes);
+        enqueue_compute(b, nframes, true);
+    }
     b->last_frames = nframes;
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
