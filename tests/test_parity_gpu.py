@@ -811,6 +811,7 @@ def test_pipeline_odd_shapes(slamx, oracle, shape, window):
     ("1080p_2k", 1080, 1920, 12, 6800, 3, 24),   # bench.py default workload (the metric's config)
     ("c2", 480, 640, 6, 5000, 3, 16),            # BASELINE.json configs[1]
     ("c3", 1080, 1920, 8, 32000, 3, 16),         # BASELINE.json configs[2]: ~80k candidates, ~10k keypoints
+    ("uhd", 2160, 3840, 10, 40000, 3, 20),       # beyond the bench sizes: 3840x2160, ~100k candidates, ~14k keypoints
 ])
 def test_full_size_workloads_bit_exact(slamx, oracle, name, rows, cols, window, n_rect, rmin, rmax):
     """The bench workloads themselves, two consecutive frames each: candidates, keypoint order,
