@@ -516,6 +516,30 @@ def test_match_large_train_set_takes_the_matrix_core_scan(slamx, oracle):
     assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, oracle.match_params(m.cfg)), "large train set")
 
 
+@pytest.mark.parametrize("n1,n2", [(300, 65535), (300, 65536), (300, 65537), (200, 90000), (66000, 40)])
+def test_match_train_sets_around_the_16_bit_index_limit(slamx, oracle, n1, n2):
+    """The matrix-core scan keeps train indices in 16 bits of its pair entries: sets of up to 65536 descriptors take
+    it, larger ones the popcount scan; the best match of many queries sits at the very end of the train set."""
+    rng = np.random.default_rng(n1 * 7 + n2)
+    mask = np.frombuffer(np.uint64((1 << 46) - 1).tobytes(), np.uint8)
+    d1 = np.zeros((n1, 32), np.uint8)
+    d2 = np.zeros((n2, 32), np.uint8)
+    d1[:, :8] = rng.integers(0, 256, (n1, 8), dtype=np.uint8) & mask
+    d2[:, :8] = rng.integers(0, 256, (n2, 8), dtype=np.uint8) & mask
+    tail = min(n1, n2) // 2
+    d2[n2 - tail:] = d1[:tail]                      # exact matches in the last positions
+    d2[rng.integers(0, n2, n2 // 50 + 1)] = d1[rng.integers(0, n1, n2 // 50 + 1)]
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for k in (k1, k2):
+        k["x"] = rng.integers(0, 1920, len(k))
+        k["y"] = rng.integers(0, 1080, len(k))
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.9))
+    for a1, a2 in ((k1, k2), (None, None)):
+        assert_records_equal(m.match(d1, d2, a1, a2), oracle.match(d1, d2, a1, a2, oracle.match_params(m.cfg)),
+                             "%d x %d descriptors" % (n1, n2))
+
+
 def test_batch_matching_through_the_matrix_core_scan(slamx, oracle, mfma_scan_for_all_sizes):
     """A device-resident batch (46 live bits by construction) with the override: frames matched to their
     predecessors, ragged keypoint counts, train sets of several LDS stages."""
