@@ -67,18 +67,23 @@ __device__ __forceinline__ float from_right(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 
-__global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __restrict__ weights) {
+__global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __restrict__ weights, int nframes, int tiles_x,
+                                                    int tiles_y, uint32_t tiles_x_recip) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint32_t outt[TILE_H * LDS_ROW_DW];
     __shared__ uint16_t fix[FIX_CAP];
     __shared__ int nfix;
     __shared__ double wgt[25];
     __shared__ float g[5];
-    // 2-D tile grid: with 8 tile columns (1920 / 248) a tile column stays on one XCD, whose L2
-    // then serves the halo rows shared by vertically adjacent tiles
-    const int tx = blockIdx.x;
-    const int ty = blockIdx.y;
-    const int f = blockIdx.z;
+    // all tiles of a frame on ONE XCD (frame_block): its L2 serves the halo rows shared by vertically adjacent
+    // tiles AND the 128-byte lines that horizontally adjacent tiles share (a tile row starts at x0 - 4: with a tile
+    // column per XCD every L2 fetched its own copy of those lines, 1.43x the frame bytes)
+    int f, tile_id;
+    if (!frame_block(nframes, tiles_x * tiles_y, &f, &tile_id)) {
+        return;
+    }
+    const int ty = tiles_x_recip != 0 ? static_cast<int>(__umulhi(static_cast<uint32_t>(tile_id), tiles_x_recip)) : tile_id;
+    const int tx = tile_id - ty * tiles_x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // scalar: row addresses on the SALU
     const uint8_t* img = v.frames + static_cast<size_t>(f) * v.frame_stride;
@@ -263,8 +268,12 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
 }  // namespace
 
 void launch_blur(const BatchView& v, const double* weights_dev, int nframes, hipStream_t stream) {
-    dim3 grid((v.cols + TILE_W - 1) / TILE_W, (v.rows + TILE_H - 1) / TILE_H, nframes);
-    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, stream, v, weights_dev);
+    const int tiles_x = (v.cols + TILE_W - 1) / TILE_W;
+    const int tiles_y = (v.rows + TILE_H - 1) / TILE_H;
+    // tile_id / tiles_x as a multiply-high (exact while tile_id * tiles_x < 2^32; 0 stands for tiles_x == 1)
+    const uint32_t tiles_x_recip = tiles_x > 1 ? 0xffffffffu / static_cast<uint32_t>(tiles_x) + 1u : 0u;
+    hipLaunchKernelGGL(blur_kernel, frame_grid(nframes, tiles_x * tiles_y), dim3(256), 0, stream, v, weights_dev, nframes, tiles_x,
+                       tiles_y, tiles_x_recip);
 }
 
 }  // namespace slamx
