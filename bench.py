@@ -400,6 +400,10 @@ def main():
         step()
     ctx.synchronize()
     ncand, nkp, nmatch = batch.counts(B)  # also surfaces capacity overflows loudly
+    if args.warmup > 0:
+        # the job's one-off end (downloads of the newest pair, triangulation) once untimed as well: its first call
+        # pays for lazily created buffers, 1.5 - 2.6 ms of the timed region otherwise
+        triangulate_last_pair(ctx, batch, matcher, B, wl["cols"], wl["rows"])
 
     K = args.steps
     # hipEvents between the kernels of every 8th timed step (every 4th / every step when there are few): an
