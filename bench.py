@@ -407,8 +407,8 @@ def main():
 
     K = args.steps
     # hipEvents between the kernels of every 8th timed step (every 4th / every step when there are few): an
-    # event between two kernels keeps the second from starting while the first drains, ~18 % of such a step
-    # (2.95 ms per step without events, 3.09 with events on every 4th step)
+    # event between two kernels keeps the second from starting while the first drains (round 1 measured ~9 % of
+    # such a step; over the 20 default steps the events now cost about 1 %: 2.97 ms per step without any, 3.00 with)
     every = 8 if K >= 16 else (4 if K >= 8 else 1)
     sets = min((K + every - 1) // every, 256)
     batch.set_profiling(sets, every)
