@@ -24,7 +24,11 @@ rank; the cost after the last step is evaluated once at the end of the job, insi
 
 Multi-GPU: frames shard embarrassingly (one independent stream per rank, seed + rank), no
 data-path collective; at the end of the timed job every rank triangulates its newest frame pair
-and the map points are exchanged with one RCCL all_gather (counts + padded points).
+and the map points are exchanged with one RCCL all_gather (counts + padded points).  One process per
+GPU: started by `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when
+`--gpus N` is given with no launcher around it -- by this script itself (`launch_ranks`: N fresh children,
+started before torch or HIP are touched in the parent).  `--backend gloo --share-device` rehearses the N > 1
+path on one card, `--dry-run` the rank plumbing with no GPU at all.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
 dominant kernel and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N == 1 only).  The default
@@ -63,6 +67,7 @@ GN_WORKLOAD = dict(windows=500, cams=10, landmarks=2048, lam=1e-4, n_fixed=2,
 # SIMD at 2.4 GHz on 1024 SIMDs = 78.6; tools/microbench/mfma_f64_peak.hip measures the sustained rate)
 MFMA_F64_PEAK_TFLOPS = 78.6
 SEED = 0x5EED0051
+METRIC = "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Sustained rate of the Hamming inner loop's instruction mix (v_xor_b32 + v_bcnt_u32_b32 with fused
 # accumulate) measured on MI355X with tools/microbench/valu_peak.hip: 42.1 Tera lane-ops/s
@@ -234,7 +239,115 @@ def cpu_baseline(mod, wl, frames, budget_s=15.0):
     }
 
 
-def main_gn(args, rank, local_rank, world, dist, torch):
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the launcher.  It starts N
+    fresh children of this script -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment exactly as `torch.distributed.run` would set them -- BEFORE torch is imported or anything touches
+    HIP here (the parent never initialises the GPU and never execs), relays rank 0's JSON line, and fails if any
+    rank fails.  A rank that dies takes the others down with it (they would wait in the rendezvous for ever):
+    the parent ends exactly the processes it started."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b""
+    rc = 0
+    try:
+        alive = set(range(n))
+        import selectors
+
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        open0 = True
+        while alive:
+            if open0:
+                for key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        sel.unregister(key.fileobj)
+                        open0 = False
+            else:
+                time.sleep(0.2)
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                    for q in alive:
+                        procs[q].terminate()
+        if open0:
+            out0 += procs[0].stdout.read()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def main_dry_run(args, rank, world, dist):
+    """--dry-run: the rank plumbing of the multi-GPU path with NO GPU and NO kernels (gloo, CPU tensors): every rank
+    builds its own synthetic stream (seed + rank), "map points" of a rank-dependent count stand in for the
+    triangulated ones, and the two collectives of the real run (gather_map_points inside the timed region,
+    gather_summary after it) and the max-over-ranks timing run as they do on the GPUs.  `value` is null: nothing
+    was measured."""
+    import numpy as np
+    import torch
+
+    mod = load_product()  # the host-side generator only; no context is created
+    seed = shard_seed(rank)
+    frames = [mod.synth_frame(seed, k, 48, 64, 20, 3, 12) for k in range(3)]
+    checksum = float(sum(int(f.sum()) for f in frames))
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    xyz = (np.arange((5 + 3 * rank) * 3, dtype=np.float64).reshape(-1, 3) + 1000.0 * rank)
+    n_map_points = xyz.shape[0]
+    if dist is not None:
+        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, "cpu"))
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rows = [[float(rank), float(seed), checksum, float(xyz.shape[0])]]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        rows = gather_summary(dist, rows[0], "cpu")
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": 0, "warmup": 0,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic", "dry_run": True,
+            "config": {"workload": "dry run of the rank plumbing: no GPU, no kernels, gloo", "name": "dry_run",
+                       "parallelism": "frames sharded one stream per rank (dp%d), no data-path collective" % world},
+            "map_points_gathered": n_map_points,
+            "ranks": [{"rank": int(r[0]), "seed": int(r[1]), "stream_checksum": r[2], "map_points": int(r[3])} for r in rows],
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main_gn(args, rank, local_rank, world, dist, torch, coll_device="cuda"):
     """--workload c4: BASELINE.json configs[3].  Windows shard across ranks like frames do (independent
     windows, no data-path collective); the gather at the end of the job exchanges the optimised poses."""
     import numpy as np
@@ -278,14 +391,14 @@ def main_gn(args, rank, local_rank, world, dist, torch):
     poses, _, cost, status = gn.download()  # end of the job: results leave the device
     n_gathered = nw
     if dist is not None:
-        n_gathered = sum(a.shape[0] for a in gather_map_points(dist, poses.reshape(-1, 3), "cuda")) // (W * 4)
+        n_gathered = sum(a.shape[0] for a in gather_map_points(dist, poses.reshape(-1, 3), coll_device)) // (W * 4)
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms, launches = gn.stage_ms()
@@ -298,7 +411,7 @@ def main_gn(args, rank, local_rank, world, dist, torch):
         achieved = mfma_flops / acc_s / 1e12 if acc_s > 0 else 0.0
         err = float(np.abs(poses - np.stack([w["poses_gt"] for w in wins])).max())
         out = {
-            "metric": "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": nw * K * n_gpus / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -340,7 +453,7 @@ def main_gn(args, rank, local_rank, world, dist, torch):
         dist.destroy_process_group()
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -352,23 +465,48 @@ def main():
     ap.add_argument("--no-keypoints", action="store_true", help="diagnostic: match without the jump-radius penalty")
     ap.add_argument("--no-extras", action="store_true",
                     help="default workload only: skip the short runs of c3 / c3p / c4 reported under other_workloads")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 run: nccl (= RCCL, the product path) or gloo (rehearsal: "
+                         "the collectives run on CPU tensors)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: every rank uses device 0 (needs --backend gloo; "
+                         "RCCL refuses two ranks on one device)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only: no GPU, no kernels, gloo (tests/test_distributed_cpu.py)")
+    args = ap.parse_args(argv)
+    if args.dry_run:
+        args.backend = "gloo"
+    if args.share_device and args.backend != "gloo":
+        ap.error("--share-device needs --backend gloo")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become it (children are started before torch / HIP are touched in this process)
+        return launch_ranks(args, list(sys.argv[1:] if argv is None else argv))
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0 and (world > 1 or args.gpus > 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d; running (and reporting) %d ranks\n"
+                         % (args.gpus, world, world))
     import torch  # loaded first: libslamx then binds to the HIP runtime already in the process
 
     dist = None
+    coll_device = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    if args.dry_run:
+        return main_dry_run(args, rank, world, dist)
     n_gpus = world
     if args.workload == "c4":
-        return main_gn(args, rank, local_rank, world, dist, torch)
+        return main_gn(args, rank, local_rank, world, dist, torch, coll_device)
 
     mod = load_product()
     import numpy as np
@@ -425,7 +563,7 @@ def main():
     xyz = triangulate_last_pair(ctx, batch, matcher, B, wl["cols"], wl["rows"])
     n_map_points = xyz.shape[0]
     if dist is not None:
-        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, "cuda"))
+        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, coll_device))
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -433,11 +571,11 @@ def main():
     elapsed = time.perf_counter() - t0
     end_of_job_ms = (time.perf_counter() - t_tail) * 1e3  # inside `elapsed`: downloads of the newest pair, triangulation, gather
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # result summary of every rank (the map points themselves were gathered inside the timed region)
-        rows = gather_summary(dist, [nkp.sum(), nmatch.sum(), ncand.sum()], "cuda")
+        rows = gather_summary(dist, [nkp.sum(), nmatch.sum(), ncand.sum()], coll_device)
         tot_kp = sum(r[0] for r in rows)
         tot_match = sum(r[1] for r in rows)
         tot_cand = sum(r[2] for r in rows)
@@ -529,7 +667,7 @@ def main():
         fe_ms = sum(stage[k] for k in stage if k not in ("match", "emit"))
         b_fe = (4.0 * px + 16.0 * M + 52.0 * N) * B
         out = {
-            "metric": "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -589,4 +727,4 @@ def other_workloads():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -1,0 +1,50 @@
+"""bench.py on the GPU box: the N > 1 code path of main() rehearsed on ONE card (two ranks share device 0, gloo
+for the collectives -- RCCL refuses two ranks on one device, and 8-GPU runs are the driver's), plus the shape of
+the default JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(argv, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_two_ranks_on_one_card_run_the_real_step():
+    """Both ranks create their own context on device 0 next to torch, run the real detect / describe / match step on
+    their own stream (seed + rank), triangulate their newest pair and gather the map points: everything of the
+    multi-GPU path except RCCL itself."""
+    rc, lines, err = _bench(["--gpus", "2", "--backend", "gloo", "--share-device", "--workload", "c2", "--batch", "64",
+                             "--steps", "3", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["frames_per_step_per_gpu"] == 64
+    assert d["value"] == pytest.approx(2 * 64 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)  # whole-job aggregate
+    assert d["config"]["keypoints_per_frame"] > 500 and d["map_points_gathered"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N == 1 only
+
+
+def test_single_rank_line_has_the_contract_keys():
+    rc, lines, err = _bench(["--workload", "c2", "--batch", "64", "--steps", "4", "--warmup", "1", "--no-extras",
+                             "--no-cpu-baseline", "--no-pcie"])
+    assert rc == 0, err[-2000:]
+    d = lines[-1]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    assert d["n_gpus"] == 1 and d["dtype"] == "u8" and d["vs_baseline"] is None
