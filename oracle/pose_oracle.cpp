@@ -150,30 +150,11 @@ int oracle_pose_rows_available(void) { return 1; }
 // generic SVD access for the tests (row-major)
 void oracle_svd(int m, int n, const double* A, double* U, double* S, double* V) { svd_jacobi(m, n, A, U, S, V); }
 
-// a11 solvePnP, loop_closure.cpp:238-274.  p3d: n x 3, p2d: n x 2.  Returns 0 if n < 6.
-// nullvec (optional, 12 doubles) receives the DLT null vector p before the column-major re-map.
-int oracle_solve_pnp(int n, const double* p3d, const double* p2d, double* R, double* t, double* nullvec) {
-    if (n < 6) {
-        return 0;
-    }
-    std::vector<double> A(static_cast<size_t>(2 * n) * 12, 0.0);
-    for (int i = 0; i < n; ++i) {
-        const double X = p3d[3 * i], Y = p3d[3 * i + 1], Z = p3d[3 * i + 2];
-        const double u = p2d[2 * i], v = p2d[2 * i + 1];
-        const double r0[12] = {X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u};
-        const double r1[12] = {0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v};
-        std::memcpy(&A[static_cast<size_t>(2 * i) * 12], r0, sizeof(r0));
-        std::memcpy(&A[static_cast<size_t>(2 * i + 1) * 12], r1, sizeof(r1));
-    }
-    std::vector<double> U(static_cast<size_t>(2 * n) * 12), S(12), V(144);
-    svd_jacobi(2 * n, 12, A.data(), U.data(), S.data(), V.data());
-    double p[12];
-    for (int k = 0; k < 12; ++k) {
-        p[k] = V[static_cast<size_t>(k) * 12 + 11];  // svd.matrixV().col(11)
-    }
-    if (nullvec != nullptr) {
-        std::memcpy(nullvec, p, sizeof(p));
-    }
+// Second half of solvePnP, loop_closure.cpp:260-271, from a GIVEN null vector p (12 doubles): the column-major re-map,
+// R = U diag(1, 1, det(U V^T)) V^T of R0's SVD, t = t0 / ||R0||_F.  The reference's result is not covariant with the
+// sign of p (R of -p is neither R nor -R), and Eigen's JacobiSVD leaves that sign unpinned, so the
+// tests run this half on whichever sign the device's null vector has and compare R, t for EVERY hypothesis.
+int oracle_pnp_from_null_vector(const double* p, double* R, double* t) {
     // :260  P = Map<Matrix<double,3,4>>(p.data()) -- COLUMN-major map of the row-major DLT vector
     double P[12];  // row-major 3x4
     for (int c = 0; c < 4; ++c) {
@@ -211,6 +192,33 @@ int oracle_solve_pnp(int n, const double* p3d, const double* p2d, double* R, dou
         t[k] = t0[k] / fro;
     }
     return 1;
+}
+
+// a11 solvePnP, loop_closure.cpp:238-274.  p3d: n x 3, p2d: n x 2.  Returns 0 if n < 6.
+// nullvec (optional, 12 doubles) receives the DLT null vector p before the column-major re-map.
+int oracle_solve_pnp(int n, const double* p3d, const double* p2d, double* R, double* t, double* nullvec) {
+    if (n < 6) {
+        return 0;
+    }
+    std::vector<double> A(static_cast<size_t>(2 * n) * 12, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double X = p3d[3 * i], Y = p3d[3 * i + 1], Z = p3d[3 * i + 2];
+        const double u = p2d[2 * i], v = p2d[2 * i + 1];
+        const double r0[12] = {X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u};
+        const double r1[12] = {0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v};
+        std::memcpy(&A[static_cast<size_t>(2 * i) * 12], r0, sizeof(r0));
+        std::memcpy(&A[static_cast<size_t>(2 * i + 1) * 12], r1, sizeof(r1));
+    }
+    std::vector<double> U(static_cast<size_t>(2 * n) * 12), S(12), V(144);
+    svd_jacobi(2 * n, 12, A.data(), U.data(), S.data(), V.data());
+    double p[12];
+    for (int k = 0; k < 12; ++k) {
+        p[k] = V[static_cast<size_t>(k) * 12 + 11];  // svd.matrixV().col(11)
+    }
+    if (nullvec != nullptr) {
+        std::memcpy(nullvec, p, sizeof(p));
+    }
+    return oracle_pnp_from_null_vector(p, R, t);
 }
 
 // a12 inlier count of one (R,t), loop_closure.cpp:201-215

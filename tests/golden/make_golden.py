@@ -19,8 +19,11 @@ sys.path.insert(0, os.path.dirname(HERE))
 import oracle_binding  # noqa: E402
 from conftest import load_gray  # noqa: E402
 
-IMAGES = ["images/0000000000.png", "images/0000000001.png", "images_test_loop/0.png", "images_test_loop/1.png",
-          "images_test_loop/2.png", "images_test_loop/3.png"]
+# all 14 mode-L PNGs of the reference's test data (SURVEY.md 8d "parity inputs")
+IMAGES = ["images/%010d.png" % k for k in range(10)] + ["images_test_loop/%d.png" % k for k in range(4)]
+# frame pairs the matcher vectors are taken on: consecutive frames, as test_feature_matcher.cpp:17-21 pairs them
+PAIRS = [("images/%010d.png" % k, "images/%010d.png" % (k + 1), "kitti%d%d" % (k, k + 1)) for k in range(9)] + \
+        [("images_test_loop/%d.png" % k, "images_test_loop/%d.png" % (k + 1), "loop%d%d" % (k, k + 1)) for k in range(3)]
 
 
 def build():
@@ -41,8 +44,7 @@ def build():
         out[key + "_moments"] = mom.astype(np.int32)
         out[key + "_blur_sum"] = np.array([int(o.gaussian_blur(img).astype(np.uint64).sum())], np.uint64)
         feats[name] = (kps2, desc)
-    for a, b, tag in [("images/0000000000.png", "images/0000000001.png", "kitti01"),
-                      ("images_test_loop/0.png", "images_test_loop/1.png", "loop01")]:
+    for a, b, tag in PAIRS:
         (k1, d1), (k2, d2) = feats[a], feats[b]
         out[tag + "_match_kp"] = o.match(d1, d2, k1, k2, M).view(np.uint8).reshape(-1, 12)       # test_feature_matcher.cpp:62
         out[tag + "_match_nokp"] = o.match(d1, d2, None, None, M).view(np.uint8).reshape(-1, 12)  # test_pose_estimator.cpp:138

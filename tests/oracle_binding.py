@@ -131,6 +131,13 @@ class Oracle:
         self.lib.oracle_svd(m, n, _p(A), _p(U), _p(S), _p(V))
         return U, S, V
 
+    def pnp_from_null_vector(self, nullvec):
+        """loop_closure.cpp:260-271 from a given DLT null vector (either sign)."""
+        p = np.ascontiguousarray(nullvec, np.float64)
+        R, t = np.empty((3, 3)), np.empty(3)
+        self.lib.oracle_pnp_from_null_vector(_p(p), _p(R), _p(t))
+        return R, t
+
     def solve_pnp(self, p3d, p2d):
         a = np.ascontiguousarray(p3d, np.float64)
         b = np.ascontiguousarray(p2d, np.float64)

@@ -253,3 +253,19 @@ def test_oracle_pyramid_downscale_properties(oracle):
     ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (40, 1))
     small = oracle.downscale(ramp, 33, 83).astype(int)
     assert (np.diff(small, axis=1) >= 0).all() and (small == small[0]).all()
+
+
+def test_oracle_pnp_second_half_from_either_sign(oracle):
+    """oracle_pnp_from_null_vector is the tail of oracle_solve_pnp (loop_closure.cpp:260-271): the same R, t from the
+    oracle's own null vector; from the negated vector a proper rotation again (NOT -R) and t negated."""
+    rng = np.random.default_rng(2)
+    X = rng.uniform(-2, 2, (8, 3)) + np.array([0, 0, 6.0])
+    uv = rng.uniform(0, 1000, (8, 2))
+    ok, R, t, nv = oracle.solve_pnp(X, uv)
+    assert ok == 1
+    R1, t1 = oracle.pnp_from_null_vector(nv)
+    assert np.array_equal(R1, R) and np.array_equal(t1, t)
+    R2, t2 = oracle.pnp_from_null_vector(-nv)
+    assert np.abs(R2.T @ R2 - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R2) - 1.0) < 1e-12
+    assert np.allclose(t2, -t, rtol=0, atol=1e-15)
+    assert np.abs(R2 - R).max() > 1e-3 and np.abs(R2 + R).max() > 1e-3  # not sign-covariant (SURVEY.md 8a a11)

@@ -13,12 +13,9 @@ from conftest import load_gray
 
 pytestmark = pytest.mark.gpu
 
-REF_IMAGES = [
-    "images/0000000000.png",  # 1392x512 KITTI frame, the reference's test_feature_detector input
-    "images/0000000001.png",
-    "images_test_loop/0.png",  # 640x480
-    "images_test_loop/1.png",
-]
+# all 14 mode-L PNGs of the reference's test data: ten 1392x512 KITTI frames (0000000000.png is the
+# reference's test_feature_detector input), four 640x480 loop frames
+REF_IMAGES = ["images/%010d.png" % k for k in range(10)] + ["images_test_loop/%d.png" % k for k in range(4)]
 
 
 def cfg_of(slamx, t=20, arc=12, nms=1, window=12, patch=31, pairs=256):
@@ -224,7 +221,7 @@ def test_detect_no_corners(det):
 
 
 # ---------------------------------------------------------------- a4 blur
-@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[2:3])
+@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[10:11])
 def test_blur_reference_images(det, oracle, ref_data, name):
     img = load_gray(os.path.join(ref_data, name))
     assert np.array_equal(det.gaussian_blur(img), oracle.gaussian_blur(img))
@@ -361,7 +358,7 @@ def test_compute_other_patterns(slamx, oracle, patch, pairs):
     assert np.array_equal(d_got, d_ref)
 
 
-@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[2:3])
+@pytest.mark.parametrize("name", REF_IMAGES[:1] + REF_IMAGES[10:11])
 def test_detect_and_compute(det, oracle, P, ref_data, name):
     img = load_gray(os.path.join(ref_data, name))
     k_ref, d_ref = oracle.detect_and_compute(img, P)
@@ -860,3 +857,52 @@ def test_full_size_workloads_bit_exact(slamx, oracle, name, rows, cols, window, 
         want = oracle.match(ref[q][1], ref[t_][1], ref[q][0], ref[t_][0], mp)
         assert_records_equal(b.download_matches(m, q), want, "%s matches %d->%d" % (name, q, t_))
     assert len(ref[0][0]) > 1500
+
+
+# ---------------------------------------------------------------- HIP path against the COMMITTED vectors (no oracle in the loop)
+def _golden():
+    from conftest import ROOT
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "oracle_golden.npz"))
+
+
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_frontend_against_committed_golden_vectors(slamx, det, ref_data, name):
+    """tests/golden/oracle_golden.npz (generator: tests/golden/make_golden.py, run in the build container) holds
+    candidates, keypoints (order, response, angle bits), descriptors and a blur checksum of every reference PNG.
+    The HIP path is compared with those bytes directly: on the GPU box this does not depend on which oracle .so
+    travelled there."""
+    img = load_gray(os.path.join(ref_data, name))
+    key = name.replace("/", "_").replace(".png", "")
+    with _golden() as g:
+        cand = det.fast_candidates(img)
+        got = np.stack([cand["x"], cand["y"], cand["response"]], 1).astype(np.uint16)
+        assert np.array_equal(got, g[key + "_cand_xys"]), "candidates " + name
+        kps, desc = det.detectAndCompute(img)
+        assert np.array_equal(kps.view(np.uint8).reshape(len(kps), 20), g[key + "_kps"]), "keypoints " + name
+        assert np.array_equal(desc, g[key + "_desc"]), "descriptors " + name
+        assert int(det.gaussian_blur(img).astype(np.uint64).sum()) == int(g[key + "_blur_sum"][0]), "blur " + name
+
+
+def test_matcher_against_committed_golden_vectors(slamx, det, ref_data):
+    """Matches of every consecutive reference frame pair with the shipped matcher YAML (filter on: top-20 through the
+    host's std::partial_sort), with and without keypoints, plus the unfiltered best matches -- against the committed
+    bytes."""
+    import importlib.util
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    m_ship = slamx.FeatureMatcher(os.path.join(ref_data, "feature_matcher.yml"))
+    m_all = slamx.FeatureMatcher(slamx.MatcherConfig(0, 0, 20, 1, 0.5))
+    feats = {}
+    with _golden() as g:
+        for a, b, tag in mg.PAIRS:
+            for n in (a, b):
+                if n not in feats:
+                    feats[n] = det.detectAndCompute(load_gray(os.path.join(ref_data, n)))
+            (k1, d1), (k2, d2) = feats[a], feats[b]
+            assert m_ship.match(d1, d2, k1, k2).tobytes() == g[tag + "_match_kp"].tobytes(), tag + " with keypoints"
+            assert m_ship.match(d1, d2).tobytes() == g[tag + "_match_nokp"].tobytes(), tag + " without keypoints"
+            assert m_all.match(d1, d2, k1, k2).tobytes() == g[tag + "_best_kp"].tobytes(), tag + " unfiltered"

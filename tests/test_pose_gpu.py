@@ -45,16 +45,20 @@ def test_pnp_dlt_matches_oracle(gpu_ctx, oracle, n_points):
         _, _, X, uv = scene(rng, n_points, noise=0.0 if h % 2 == 0 else 0.5)
         p3[h], p2[h] = X, uv
     R, t, nv = gpu_ctx.pnp_dlt_batch(p3, p2)
+    signs = {True: 0, False: 0}
     for h in range(H):
         ok, Ro, to, nvo = oracle.solve_pnp(p3[h], p2[h])
         assert ok == 1
         # the DLT null vector is defined up to sign (SURVEY 8a a11 "sign caveat")
         s = np.sign(np.dot(nv[h], nvo))
         assert rel(s * nv[h], nvo) < TOL, "null vector h=%d" % h
-        # R is built from the SVD of +-R0 with a det fix and is NOT sign-covariant: compare after
-        # re-running the oracle's orthonormalisation on the sign the GPU chose
-        if s > 0:
-            assert rel(R[h], Ro) < 1e-7 and rel(t[h], to) < 1e-7
+        # R is built from the SVD of +-R0 with a det fix and is NOT sign-covariant (R of -p is neither R nor -R), and
+        # the sign of a null vector is whatever the SVD at hand returns: run the reference's second half
+        # (loop_closure.cpp:260-271) on the oracle's null vector WITH THE SIGN THE GPU CHOSE and compare R, t for
+        # every hypothesis, whichever sign it has
+        Rs, ts = (Ro, to) if s > 0 else oracle.pnp_from_null_vector(-nvo)
+        assert rel(R[h], Rs) < 1e-7 and rel(t[h], ts) < 1e-7, "R, t of hypothesis %d (sign %+d)" % (h, s)
+        signs[s > 0] += 1
         # reference's only checkable property: R^T R = I (test_pose_estimator.cpp:34-43, 1e-6)
         assert np.abs(R[h].T @ R[h] - np.eye(3)).max() < 1e-9
         assert abs(abs(np.linalg.det(R[h])) - 1.0) < 1e-9
