@@ -9,9 +9,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <functional>
 #include <limits>
+#include <stdexcept>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include <slam/backend/map.hpp>
@@ -31,27 +34,52 @@ public:
 
     explicit Backend(slam::Map& map) : m_map(map) {}
     Backend(slam::Map& map, const Options& o) : m_map(map), m_options(o) {}
-    ~Backend() { join(); }
+    ~Backend() { wait(); }
     Backend(const Backend&) = delete;
     Backend& operator=(const Backend&) = delete;
 
     void setOptions(const Options& o) { m_options = o; }
 
-    // Starts the backend thread; one optimisation pass per call.  join() (or the destructor) waits for it.
+    // Starts the backend thread; one optimisation pass per call.  join() waits for it and rethrows what the pass
+    // threw (an exception must not leave the thread function: that would be std::terminate); the destructor waits
+    // and drops it.  Intrinsics are checked here, before a thread exists: the reference-signature constructor
+    // `Backend(Map&)` leaves them at zero, and setOptions() must be called first.
     void run() {
         join();
-        m_backendThread = std::thread([this] { optimise(); });
+        if (!(m_options.fx > 0.0) || !(m_options.fy > 0.0)) {
+            throw std::invalid_argument("slam::Backend::run: focal lengths must be positive (setOptions / Options ctor)");
+        }
+        m_failed = false;
+        m_error = nullptr;
+        m_backendThread = std::thread([this] {
+            try {
+                optimise();
+            } catch (...) {
+                m_error = std::current_exception();
+                m_failed = true;
+            }
+        });
     }
     void join() {
-        if (m_backendThread.joinable()) {
-            m_backendThread.join();
+        wait();
+        if (m_error) {
+            std::exception_ptr e = m_error;
+            m_error = nullptr;
+            std::rethrow_exception(e);
         }
     }
+    // true iff the last pass ended in an error that join() has reported or will report
+    bool failed() const { return m_failed; }
     // sum of squared reprojection residuals before the first and after the last step of the last pass
     double initialCost() const { return m_cost0; }
     double finalCost() const { return m_cost1; }
 
 private:
+    void wait() {
+        if (m_backendThread.joinable()) {
+            m_backendThread.join();
+        }
+    }
     void optimise() {
         const Options o = m_options;
         std::vector<Map::Keyframe> kfs;
@@ -112,6 +140,11 @@ private:
         std::vector<double> cost(static_cast<std::size_t>(its) + 1);
         int32_t status = 0;
         detail::check(slamx_gn_download(gn, poses.data(), X.data(), cost.data(), &status));
+        if (status != 0) {
+            // bit 0: a step was skipped (reduced system not positive definite); nothing is written back
+            throw std::runtime_error("slam::Backend: Gauss-Newton window status " + std::to_string(status) +
+                                     " (reduced camera system not positive definite); the map is unchanged");
+        }
         m_cost0 = cost.front();
         m_cost1 = cost.back();
         std::lock_guard<std::mutex> lock(m_map.get().m_mapMutex);
@@ -130,6 +163,8 @@ private:
     std::thread m_backendThread;
     Options m_options;
     double m_cost0 = 0.0, m_cost1 = 0.0;
+    std::exception_ptr m_error;  // written by the backend thread, read after it has been joined
+    bool m_failed = false;
 };
 
 }  // namespace slam

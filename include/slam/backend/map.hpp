@@ -8,6 +8,7 @@
 #include <array>
 #include <cstddef>
 #include <mutex>
+#include <stdexcept>
 #include <vector>
 
 namespace slam {
@@ -39,8 +40,13 @@ public:
         m_points.push_back(xyz);
         return static_cast<int>(m_points.size()) - 1;
     }
+    // throws std::out_of_range for a keyframe / map point that does not exist (the backend indexes with both)
     void addObservation(int keyframe, int point, float u, float v) {
         std::lock_guard<std::mutex> lock(m_mapMutex);
+        if (keyframe < 0 || static_cast<std::size_t>(keyframe) >= m_keyframes.size() || point < 0 ||
+            static_cast<std::size_t>(point) >= m_points.size()) {
+            throw std::out_of_range("slam::Map::addObservation: no such keyframe / map point");
+        }
         m_observations.push_back(Observation{keyframe, point, u, v});
     }
 

@@ -84,37 +84,50 @@ public:
                                  int nLevels = 8, double scaleFactor = 1.2) {
         const int rows = static_cast<int>(image.rows());
         const int cols = static_cast<int>(image.cols());
-        if (m_pyramid == nullptr || rows != m_pyrRows || cols != m_pyrCols || nLevels != m_pyrLevels || scaleFactor != m_pyrScale) {
-            slamx_pyramid_destroy(m_pyramid);
-            m_pyramid = nullptr;
-            slamx_batch_shape shape{};
-            shape.rows = rows;
-            shape.cols = cols;
-            shape.max_frames = 1;
-            shape.max_candidates = std::max(1024, rows * cols / 4);
-            shape.max_keypoints = std::max(1024, rows * cols / 8);
-            detail::check(slamx_pyramid_create(m_handle, &shape, nLevels, scaleFactor, &m_pyramid));
-            m_pyrRows = rows;
-            m_pyrCols = cols;
-            m_pyrLevels = nLevels;
-            m_pyrScale = scaleFactor;
-        }
-        slamx_batch* level0 = slamx_pyramid_batch(m_pyramid, 0);
-        detail::check(slamx_batch_upload(level0, 0, 1, image.data(), cols, 0));
-        detail::check(slamx_pyramid_detect_and_compute(m_pyramid, 1));
         const int width = slamx_detector_descriptor_width(m_handle);
-        int n = 0;
-        int rc = slamx_batch_download(level0, 0, nullptr, nullptr, 0, &n);  // the count first
-        if (rc != SLAMX_OK && rc != SLAMX_ERR_CAPACITY) {
+        // Capacities: a quarter of the pixels as corners, an eighth as keypoints; a frame that overflows either (or the
+        // merged list) is run once more with "every pixel" sizing, as the single-frame path does -- an overflow must
+        // never come back as an empty keypoint list.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool big = attempt == 1 || m_pyrBig;
+            if (m_pyramid == nullptr || rows != m_pyrRows || cols != m_pyrCols || nLevels != m_pyrLevels ||
+                scaleFactor != m_pyrScale || big != m_pyrBig) {
+                slamx_pyramid_destroy(m_pyramid);
+                m_pyramid = nullptr;
+                slamx_batch_shape shape{};
+                shape.rows = rows;
+                shape.cols = cols;
+                shape.max_frames = 1;
+                shape.max_candidates = big ? std::min(rows * cols, 1 << 20) : std::max(1024, rows * cols / 4);
+                shape.max_keypoints = big ? std::min(nLevels * rows * cols, 1 << 21) : std::max(1024, rows * cols / 8);
+                detail::check(slamx_pyramid_create(m_handle, &shape, nLevels, scaleFactor, &m_pyramid));
+                m_pyrRows = rows;
+                m_pyrCols = cols;
+                m_pyrLevels = nLevels;
+                m_pyrScale = scaleFactor;
+                m_pyrBig = big;
+            }
+            slamx_batch* level0 = slamx_pyramid_batch(m_pyramid, 0);
+            detail::check(slamx_batch_upload(level0, 0, 1, image.data(), cols, 0));
+            detail::check(slamx_pyramid_detect_and_compute(m_pyramid, 1));
+            // the count through slamx_batch_counts: it reports a candidate / keypoint / merge overflow of the frame as
+            // SLAMX_ERR_CAPACITY (slamx_batch_download(cap = 0) uses that same code for "buffer too small")
+            int32_t n32 = 0;
+            const int rc = slamx_batch_counts(level0, 1, nullptr, &n32, nullptr);
+            if (rc == SLAMX_ERR_CAPACITY && !big) {
+                continue;
+            }
             detail::check(rc);
-        }
-        keypoints.resize(static_cast<size_t>(n));
-        if (n == 0) {
-            descriptors = DescriptorMatrix(0, 0);
+            int n = n32;
+            keypoints.resize(static_cast<size_t>(n));
+            if (n == 0) {
+                descriptors = DescriptorMatrix(0, 0);
+                return;
+            }
+            descriptors.resize(n, width);
+            detail::check(slamx_batch_download(level0, 0, reinterpret_cast<slamx_keypoint*>(keypoints.data()), descriptors.data(), n, &n));
             return;
         }
-        descriptors.resize(n, width);
-        detail::check(slamx_batch_download(level0, 0, reinterpret_cast<slamx_keypoint*>(keypoints.data()), descriptors.data(), n, &n));
     }
 
 private:
@@ -159,6 +172,7 @@ private:
     slamx_detector* m_handle{};
     slamx_pyramid* m_pyramid{};  // lazily created by detectAndComputePyramid, one frame deep
     int m_pyrRows{}, m_pyrCols{}, m_pyrLevels{};
+    bool m_pyrBig{};  // "every pixel" capacities after an overflow
     double m_pyrScale{};
 };
 

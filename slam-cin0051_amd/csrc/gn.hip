@@ -513,7 +513,9 @@ __global__ __launch_bounds__(256) void gn_solve_kernel(GnSolveView s) {
     }
     __syncthreads();
     if (tid < 64) {
-        s.delta[static_cast<size_t>(w) * 64 + tid] = (tid < n && !failed) ? gv[tid] : 0.0;
+        // slot 63 (n <= 60) carries "this step was skipped" to gn_backsub_kernel: with delta_c = 0 the
+        // back-substitution would still move every landmark by A_l^-1 b_l
+        s.delta[static_cast<size_t>(w) * 64 + tid] = tid == 63 ? (failed ? 1.0 : 0.0) : ((tid < n && !failed) ? gv[tid] : 0.0);
     }
     if (tid == 0 && failed) {
         atomicOr(&s.status[w], 1);
@@ -543,6 +545,9 @@ __global__ __launch_bounds__(64) void gn_backsub_kernel(GnView g) {
     const int w = static_cast<int>(blockIdx.x) / g.nslices;
     const int slice = static_cast<int>(blockIdx.x) - w * g.nslices;
     const int lane = threadIdx.x;
+    if (g.delta[static_cast<size_t>(w) * 64 + 63] != 0.0) {
+        return;  // gn_solve_kernel skipped this window's step (status bit 0): poses AND landmarks stay
+    }
     const int nL = g.n_landmarks[w];
     const int nchunks = (nL + GN_CHUNK - 1) / GN_CHUNK;
     __shared__ double pose_lds[GN_POSE_SLOTS * 12];

@@ -1065,10 +1065,19 @@ void allow_big_lds(const void* fn) {
 }  // namespace
 
 void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_rank_of) {
+    // Experiment switch ("environment"): SLAMX_SORT_BLOCK_MIN = smallest segment that is still
+    // partitioned by the whole workgroup (default 3072 keys).  Any value gives the same permutation;
+    // values outside [128, 65536] are ignored.  Read once, on the first launch of the process.
     static const bool once_bm = [] {
-        if (getenv("SORT_BLOCK_MIN")) {
-            int bm = atoi(getenv("SORT_BLOCK_MIN"));
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(SORT_BLOCK_MIN), &bm, sizeof(int));
+        if (const char* e = getenv("SLAMX_SORT_BLOCK_MIN")) {
+            char* end = nullptr;
+            const long bm = strtol(e, &end, 10);
+            if (end != e && *end == '\0' && bm >= 128 && bm <= 65536) {
+                const int v = static_cast<int>(bm);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(SORT_BLOCK_MIN), &v, sizeof(int));
+            } else {
+                fprintf(stderr, "slamx: SLAMX_SORT_BLOCK_MIN=%s ignored (want an integer in [128, 65536])\n", e);
+            }
         }
         return true;
     }();

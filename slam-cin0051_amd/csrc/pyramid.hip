@@ -95,31 +95,24 @@ __global__ __launch_bounds__(256) void merge_level_kernel(const slamx_keypoint* 
         k.size = __fmul_rn(k.size, scale);
         dk[i] = k;
     }
-    const uint32_t* sd = reinterpret_cast<const uint32_t*>(src_desc + static_cast<size_t>(f) * src_maxK * width);
-    uint32_t* dd = reinterpret_cast<uint32_t*>(dst_desc + (static_cast<size_t>(f) * dst_maxK + off) * width);
-    const int words = n * (width / 4);  // the launcher passes width 0 for widths that are not a multiple of 4 bytes
-    for (int i = threadIdx.x; i < words; i += 256) {
-        dd[i] = sd[i];
+    if ((width & 3) == 0) {
+        const uint32_t* sd = reinterpret_cast<const uint32_t*>(src_desc + static_cast<size_t>(f) * src_maxK * width);
+        uint32_t* dd = reinterpret_cast<uint32_t*>(dst_desc + (static_cast<size_t>(f) * dst_maxK + off) * width);
+        const int words = n * (width / 4);
+        for (int i = threadIdx.x; i < words; i += 256) {
+            dd[i] = sd[i];
+        }
+    } else {
+        // descriptor widths that are not a multiple of 4 bytes: byte copy, in this same kernel, so that a level that
+        // was NOT merged (the early return above) can never be copied over the descriptors of earlier levels
+        const uint8_t* sd = src_desc + static_cast<size_t>(f) * src_maxK * width;
+        uint8_t* dd = dst_desc + (static_cast<size_t>(f) * dst_maxK + off) * width;
+        for (int i = threadIdx.x; i < n * width; i += 256) {
+            dd[i] = sd[i];
+        }
     }
     if (threadIdx.x == 0) {
         dst_count[f] = off + n;
-    }
-}
-
-// descriptor widths that are not a multiple of 4 bytes: byte copy
-__global__ __launch_bounds__(256) void merge_desc_bytes_kernel(const uint8_t* __restrict__ src_desc, const int* __restrict__ src_count,
-                                                               int src_maxK, uint8_t* __restrict__ dst_desc,
-                                                               const int* __restrict__ dst_count_after, int dst_maxK, int width) {
-    const int f = blockIdx.x;
-    const int n = src_count[f];
-    const int off = dst_count_after[f] - n;
-    if (off < 0) {
-        return;  // the level was not merged (overflow): nothing to copy
-    }
-    const uint8_t* sd = src_desc + static_cast<size_t>(f) * src_maxK * width;
-    uint8_t* dd = dst_desc + (static_cast<size_t>(f) * dst_maxK + off) * width;
-    for (int i = threadIdx.x; i < n * width; i += 256) {
-        dd[i] = sd[i];
     }
 }
 
@@ -135,15 +128,8 @@ void launch_downscale(const BatchView& src, const BatchView& dst, const uint32_t
 }
 
 void launch_merge_level(const BatchView& src, const BatchView& dst, float scale, int nframes, hipStream_t stream) {
-    if (src.width % 4 == 0) {
-        hipLaunchKernelGGL(merge_level_kernel, dim3(nframes), dim3(256), 0, stream, src.kps, src.desc, src.n_kp, src.status,
-                           src.maxK, dst.kps, dst.desc, dst.n_kp, dst.status, dst.maxK, src.width, scale);
-    } else {
-        hipLaunchKernelGGL(merge_level_kernel, dim3(nframes), dim3(256), 0, stream, src.kps, src.desc, src.n_kp, src.status,
-                           src.maxK, dst.kps, dst.desc, dst.n_kp, dst.status, dst.maxK, 0, scale);
-        hipLaunchKernelGGL(merge_desc_bytes_kernel, dim3(nframes), dim3(256), 0, stream, src.desc, src.n_kp, src.maxK, dst.desc,
-                           dst.n_kp, dst.maxK, src.width);
-    }
+    hipLaunchKernelGGL(merge_level_kernel, dim3(nframes), dim3(256), 0, stream, src.kps, src.desc, src.n_kp, src.status,
+                       src.maxK, dst.kps, dst.desc, dst.n_kp, dst.status, dst.maxK, src.width, scale);
 }
 
 }  // namespace slamx

@@ -210,6 +210,19 @@ class Oracle:
         self.lib.oracle_sort_desc(_p(s), s.shape[0], _p(perm))
         return perm
 
+    # ---- the restated CPU path over a sequence of frames on T threads (oracle/cpu_sequence.cpp)
+    def sequence_mt(self, frames, P, M, use_keypoints=True, n_threads=1):
+        """frames [n][rows][cols] u8; frame k matched against k-1 (frame 0 against the last).  Returns (wall seconds,
+        per_frame [n][3] = keypoints, matches, FNV-1a of keypoints + descriptors + matches)."""
+        f = np.ascontiguousarray(frames, np.uint8)
+        out = np.zeros((f.shape[0], 3), np.uint64)
+        fn = self.lib.oracle_sequence_mt
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        dt = fn(_p(f), f.shape[0], f.shape[1], f.shape[2], C.addressof(P), C.addressof(M), 1 if use_keypoints else 0,
+                int(n_threads), _p(out))
+        return dt, out
+
     # ---- image pyramid (oracle/pyramid_oracle.cpp; build-defined, no reference counterpart)
     def downscale(self, img, drows, dcols):
         src = np.ascontiguousarray(img, np.uint8)

@@ -269,3 +269,39 @@ def test_oracle_pnp_second_half_from_either_sign(oracle):
     assert np.abs(R2.T @ R2 - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R2) - 1.0) < 1e-12
     assert np.allclose(t2, -t, rtol=0, atol=1e-15)
     assert np.abs(R2 - R).max() > 1e-3 and np.abs(R2 + R).max() > 1e-3  # not sign-covariant
+
+
+def test_oracle_sequence_threads_do_not_change_results(oracle, slamx):
+    """oracle/cpu_sequence.cpp shards frames over std::threads for the all-cores CPU baseline (SURVEY.md 8d): the
+    per-frame results (hash of keypoints, descriptors and matches) are those of the single-threaded run and of the
+    plain per-frame oracle calls."""
+    import oracle_binding
+
+    P = oracle_binding.DetectorParams(20, 12, 1, 12, 31, 256)
+    M = oracle_binding.MatcherParams(0, 20, 1, 0.5)
+    frames = np.stack([slamx.synth_frame(0x5EED0051, k, 120, 160, 200, 3, 16) for k in range(7)])
+    _, one = oracle.sequence_mt(frames, P, M, True, 1)
+    _, three = oracle.sequence_mt(frames, P, M, True, 3)
+    _, many = oracle.sequence_mt(frames, P, M, True, 64)  # clamped to one frame per thread
+    assert np.array_equal(one, three) and np.array_equal(one, many)
+    assert one[:, 0].min() > 20 and one[:, 1].min() > 0
+    feats = [oracle.detect_and_compute(f, P) for f in frames]
+    for k in range(7):
+        (kq, dq), (kt, dt) = feats[k], feats[k - 1]
+        m = oracle.match(dq, dt, kq, kt, M)
+        assert (len(kq), len(m)) == (int(one[k, 0]), int(one[k, 1]))
+        h = 0xCBF29CE484222325
+        for b in kq.tobytes() + dq.tobytes() + m.tobytes():
+            h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        assert h == int(one[k, 2])
+
+
+def test_backend_facade_host_errors():
+    """slam::Backend / slam::Map host-side error behaviour (ADVICE r2, medium): run() on the reference-signature
+    constructor (intrinsics zero) throws std::invalid_argument before a thread exists instead of std::terminate from
+    inside it; Map::addObservation refuses unknown keyframe / point indices.  Needs no GPU."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "bin/test_backend"])
+    p = subprocess.run([os.path.join(ROOT, "tools", "bin", "test_backend"), "--host-only"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert "host checks: ok" in p.stdout.decode()

@@ -146,6 +146,24 @@ def test_singular_window_is_skipped_loudly(slamx):
     assert cost[1].tolist() == [0.0, 0.0, 0.0]
 
 
+def test_skipped_step_moves_no_landmark(slamx):
+    """A window WITH observations whose factorisation fails: camera 3 sees nothing and there is no damping, so its
+    6 x 6 diagonal block is exactly zero and the Cholesky stops there.  slamx.h says a skipped step leaves the
+    window alone -- the landmarks too, although every one of them is active (seen by cameras 0..2) and the
+    back-substitution with delta_c = 0 would move it by A_l^-1 b_l."""
+    a = gn_scene.make_window(7, 4, 60)
+    a["obs"][:, 3, :] = np.nan
+    good = gn_scene.make_window(8, 4, 60)
+    gn = upload(slamx, [a, good])
+    gn.iterate(a["K"], 0.0, 2, 2)  # two held cameras fix the gauge incl. scale: the other window is regular
+    poses, X, cost, status = gn.download()
+    assert status.tolist() == [1, 0]
+    np.testing.assert_array_equal(poses[0], a["poses0"])
+    np.testing.assert_array_equal(X[0], a["X0"])
+    assert cost[0, 0] > 0 and cost[0, 0] == cost[0, 1] == cost[0, 2]  # same state, same cost, every iteration
+    assert np.abs(X[1] - good["X0"]).max() > 0 and cost[1, -1] < cost[1, 0]  # the other window stepped
+
+
 def test_runs_are_bit_identical(slamx):
     """Per-wave tiles are summed in slice order, no atomics: two runs of a many-slice batch agree bit for bit."""
     windows = [gn_scene.make_window(50 + k, 10, 700) for k in range(6)]

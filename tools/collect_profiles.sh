@@ -24,7 +24,9 @@ python bench.py --workload c4 --steps 20 --warmup 3 > "$out/bench_c4.json"
 echo "c4 done"
 ./tools/microbench/mfma_f64_peak > "$out/mfma_f64_peak.txt"
 ./tools/microbench/op_rates > "$out/op_rates.txt"
-P="--no-cpu-baseline --no-pcie"
+# --no-extras: exactly ONE program under every rocprofv3 invocation (the default workload would otherwise start the
+# c3 / c3p / c4 child benches inside the profiled process, and they would write into the same output directory)
+P="--no-cpu-baseline --no-pcie --no-extras"
 rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 $P > "$out/bench_under_rocprof.json"
 rocprofv3 --kernel-trace --stats -d "$out/stats_c3" -o stats --output-format csv -- python bench.py --workload c3 --steps 5 --warmup 2 $P > "$out/bench_c3_under_rocprof.json"
 rocprofv3 --kernel-trace --stats -d "$out/stats_c4" -o stats --output-format csv -- python bench.py --workload c4 --steps 20 --warmup 3 $P > "$out/bench_c4_under_rocprof.json"

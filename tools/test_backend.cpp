@@ -4,11 +4,46 @@
 // reprojection cost by more than 10x and the newest pose moved towards the truth.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
+#include <stdexcept>
 
 #include <slam/backend/backend.hpp>
 
-int main() {
+// Host-side error behaviour (needs no GPU): the reference-signature constructor leaves the intrinsics at zero, so
+// run() must refuse BEFORE a thread exists (an exception leaving the thread function would be std::terminate);
+// Map::addObservation refuses indices the backend would index with.
+static int host_checks() {
+    slam::Map map;
+    map.insertKeyframe({1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0});
+    map.insertMapPoint({0, 0, 5});
+    int bad = 0;
+    for (const auto& kp : {std::pair<int, int>{1, 0}, {0, 1}, {-1, 0}, {0, -1}}) {
+        try {
+            map.addObservation(kp.first, kp.second, 1.f, 1.f);
+            ++bad;
+        } catch (const std::out_of_range&) {
+        }
+    }
+    map.addObservation(0, 0, 960.f, 540.f);
+    slam::Backend refSignature(map);  // explicit Backend(slam::Map&), backend.hpp:12 of the reference
+    try {
+        refSignature.run();
+        ++bad;
+    } catch (const std::invalid_argument&) {
+    }
+    refSignature.join();  // nothing was started, nothing to rethrow
+    std::printf("host checks: %s\n", bad == 0 ? "ok" : "FAILED");
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    if (host_checks() != 0) {
+        return 2;
+    }
+    if (argc > 1 && std::strcmp(argv[1], "--host-only") == 0) {
+        return 0;
+    }
     std::mt19937 rng(7);
     std::normal_distribution<double> n01(0.0, 1.0);
     std::uniform_real_distribution<double> ux(-4, 6), uy(-2.5, 2.5), uz(4, 12);
@@ -46,5 +81,27 @@ int main() {
     const double e0 = std::fabs(before.t[0] + centres[9][0]) + std::fabs(before.t[1] + centres[9][1]) + std::fabs(before.t[2] + centres[9][2]);
     const double e1 = std::fabs(after.t[0] + centres[9][0]) + std::fabs(after.t[1] + centres[9][1]) + std::fabs(after.t[2] + centres[9][2]);
     std::printf("cost %.1f -> %.1f, newest keyframe off by %.4f -> %.4f\n", backend.initialCost(), backend.finalCost(), e0, e1);
+    // a pass that fails on the backend thread (no held keyframe, no damping: the reduced system has the 7 gauge
+    // freedoms and is not positive definite) must surface from join() as an exception and leave the map alone
+    slam::Backend::Options gaugeFree = o;
+    gaugeFree.heldKeyframes = 0;
+    gaugeFree.damping = 0.0;
+    gaugeFree.iterations = 1;
+    slam::Backend failing(map, gaugeFree);
+    const auto kept = map.keyframe(9);
+    bool threw = false;
+    failing.run();
+    try {
+        failing.join();
+    } catch (const std::runtime_error& e) {
+        threw = true;
+        std::printf("failing pass reported: %s\n", e.what());
+    }
+    const auto still = map.keyframe(9);
+    const bool untouched = kept.t == still.t && kept.R == still.R;
+    std::printf("failing pass: threw %d, failed() %d, map untouched %d\n", threw, failing.failed(), untouched);
+    if (!threw || !failing.failed() || !untouched) {
+        return 3;
+    }
     return backend.finalCost() < 0.1 * backend.initialCost() && e1 < 0.5 * e0 ? 0 : 1;
 }
