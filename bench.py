@@ -51,6 +51,10 @@ WORKLOADS = {
                      desc="1920x1080, ~2k keypoints/frame (shipped YAML: t=20 N=12 window=12), detect+describe+match-to-previous"),
     "c2": dict(rows=480, cols=640, window=6, n_rect=5000, rmin=3, rmax=16, batch=1024, max_cand=32768, max_kp=4096,
                desc="640x480, ~2k keypoints/frame (SuppressionWindowSize 6), detect+describe+match-to-previous"),
+    # configs[0], the reference's own CPU-runnable case: 50 synthetic 640x480 frames, ~500 keypoints per frame with the
+    # SHIPPED YAML (test/data/feature_detector.yml:3-7: t=20 N=12 window=12); one step = the 50-frame job
+    "c1": dict(rows=480, cols=640, window=12, n_rect=1950, rmin=3, rmax=24, batch=50, max_cand=16384, max_kp=2048,
+               desc="50 x 640x480, ~500 keypoints/frame (shipped YAML: t=20 N=12 window=12), detect+describe+match-to-previous"),
     "c3": dict(rows=1080, cols=1920, window=8, n_rect=32000, rmin=3, rmax=16, batch=256, max_cand=131072, max_kp=16384,
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
     # configs[2] as BASELINE.json words it: "1920x1080 8-level pyramid, 10k feats/frame" -- the pyramid is a build-side
@@ -160,83 +164,169 @@ def pmc_traffic_bytes(kernel, batch):
     return None
 
 
-def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=6):
-    """The same step with every frame coming from the host AND every result going back to it: the batch is
-    copied from page-locked host memory (slamx_batch_upload_async) before it is processed, and counts,
-    keypoints, descriptors and matches of all its frames are copied back to page-locked memory
-    (slamx_batch_download_results_async) after it.  Two contexts (two streams, two batches) alternate, so
-    the copies of one batch overlap the kernels of the other.  Reported next to `value`, never as it (the
-    timed region of `value` starts with the frames resident in HBM, as the task's measurement rule says;
-    SURVEY.md 8d's end-to-end definition is this leg)."""
+def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=9, n_lanes=3):
+    """SURVEY.md 8d's END-TO-END definition of frames/s: the same step with every frame coming from the host AND every
+    result going back to it.  The batch is copied from page-locked host memory (slamx_batch_upload_async) before it
+    is processed; after it, a device-side pack step gathers the VALID keypoints, descriptors and matches of all its
+    frames into one buffer and ONE copy brings them to page-locked memory (slamx_batch_download_packed_async; the
+    copy is sized from the previous batch of the lane plus 10 %, the tail call covers a wrong guess).  n_lanes
+    contexts (streams, batches) rotate, so the copies of one batch overlap the kernels and copies of the others.
+    Reported next to `value`, never as it (the timed region of `value` starts with the frames resident in HBM, as
+    the task's measurement rule says)."""
     pin = mod.pinned_array(frames.shape)
     pin[...] = frames
-    ctx2 = mod.Context(local_rank)
-    det2 = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), ctx2)
-    matcher2 = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx2)
-    batch2 = mod.Batch(det2, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
-    lanes = [main, (ctx2, batch2, matcher2)]
-    outs = [lanes[k][1].result_buffers(B, wl["max_kp"]) for k in range(2)]
+    lanes = [main]
+    for _ in range(n_lanes - 1):
+        c = mod.Context(local_rank)
+        d = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), c)
+        m = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), c)
+        lanes.append((c, mod.Batch(d, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"]), m))
+    outs = [lane[1].packed_buffer(B) for lane in lanes]
+    guess = [outs[0].nbytes] * len(lanes)  # first round: the worst case
+    sent = [0] * len(lanes)
+    tails = 0
 
     def step(i):
-        _, b, m = lanes[i % 2]
+        k = i % len(lanes)
+        _, b, m = lanes[k]
         b.upload_async(pin)
         b.detect_and_compute(B)
         b.match_consecutive(m, B, use_keypoints=use_keypoints, first_train_frame=B - 1)
-        b.download_results_async(B, outs[i % 2])
+        sent[k] = b.download_packed_async(B, outs[k], guess[k])
 
-    for i in range(2):
+    def collect(k):
+        """what a consumer does with a finished batch of lane k: check the header, fetch a tail if the guess was low"""
+        nonlocal tails
+        lanes[k][0].synchronize()
+        total = int(mod.packed_header(outs[k])["total_bytes"])
+        if total > sent[k]:
+            lanes[k][1].fetch_packed_tail(outs[k], sent[k])
+            tails += 1
+        guess[k] = min(outs[k].nbytes, int(total * 1.1) + 4096)
+        return total
+
+    for i in range(len(lanes)):
         step(i)
-    for c, _, _ in lanes:
-        c.synchronize()
+    for k in range(len(lanes)):
+        collect(k)
     t0 = time.perf_counter()
+    total_out = 0
     for i in range(steps):
+        if i >= len(lanes):
+            total_out += collect(i % len(lanes))  # the lane's previous batch is consumed before its buffers are reused
         step(i)
-    for c, _, _ in lanes:
-        c.synchronize()
+    for k in range(len(lanes)):
+        if k < steps:
+            total_out += collect(k)
     dt = time.perf_counter() - t0
     gb = steps * frames.nbytes / 1e9
-    gb_out = steps * sum(a.nbytes for a in outs[0]) / 1e9
-    assert int(outs[0][3].sum()) > 0 and int(outs[0][4].sum()) > 0  # the results did arrive
-    return {"value": steps * B / dt, "unit": "frames/s", "steps": steps, "host_to_hbm_GBps": gb / dt,
-            "hbm_to_host_GBps": gb_out / dt,
-            "note": "every batch uploaded from pinned host memory before it is processed and all its results (counts, "
-                    "keypoints, descriptors, matches: capacity-padded arrays) downloaded after; two contexts alternate"}
+    kp_first, m_first, status, kps, desc, matches = mod.unpack_results(outs[0])
+    assert kp_first[-1] > 0 and m_first[-1] > 0 and not status.any()  # the results did arrive
+    return {"value": steps * B / dt, "unit": "frames/s", "steps": steps, "contexts": len(lanes),
+            "host_to_hbm_GBps": gb / dt, "hbm_to_host_GBps": total_out / 1e9 / dt,
+            "result_bytes_per_frame": total_out / (steps * B), "tail_fetches": tails,
+            "note": "every batch uploaded from pinned host memory before it is processed; its valid results (counts, "
+                    "keypoints, descriptors, matches) packed on the device and downloaded with one copy after; %d "
+                    "contexts rotate" % len(lanes)}
 
 
-def cpu_baseline(mod, wl, frames, budget_s=15.0):
-    """The restated reference CPU path (oracle/, single thread) on a bounded sample of the SAME
-    frames: detectAndCompute + match(frame k, frame k-1) with keypoints."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where one is set
+    (a GPU box hands a one-GPU job a share of the host: 256 CPUs visible, ~16 granted)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(mod, wl, frames, budget_s=12.0, budget_mt_s=8.0):
+    """The restated reference CPU path (oracle/) on a bounded sample of the SAME frames:
+    detectAndCompute + match(frame k, frame k-1) with keypoints.  Two numbers: ONE thread -- the reference's own
+    execution model (it has no threading on this path), the primary baseline -- and ALL host cores this process
+    may use, frames sharded over std::threads (oracle/cpu_sequence.cpp).  Pyramid workloads: one thread only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding
 
     o = oracle_binding.load()
     P = oracle_binding.DetectorParams(20, 12, 1, wl["window"], 31, 256)
     M = oracle_binding.MatcherParams(0, 20, 1, 0.5)
-    def dac(img):
-        if "levels" in wl:
+    cores = usable_cores()
+    host = {"host_cpus": os.cpu_count(), "usable_cpus": cores, "cpu_model": cpu_model()}
+    if "levels" in wl:
+        def dac(img):
             return o.pyramid_detect_and_compute(img, P, wl["levels"], wl["scale"])
-        return o.detect_and_compute(img, P)
 
-    t0 = time.perf_counter()
-    prev = dac(frames[-1])  # predecessor of frame 0, not counted
-    o.match(prev[1], prev[1], prev[0], prev[0], M)  # (sizes the sample: matching is O(N^2) and dominates at 10k keypoints)
-    t_first = time.perf_counter() - t0
-    n = int(max(2, min(len(frames), budget_s / max(t_first, 1e-3))))
-    t0 = time.perf_counter()
-    kps_total = 0
-    for k in range(n):
-        cur = dac(frames[k])
-        o.match(cur[1], prev[1], cur[0], prev[0], M)
-        kps_total += len(cur[0])
-        prev = cur
-    dt = time.perf_counter() - t0
-    return {
-        "value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": "%d frames of the same workload, CPU restatement of the reference path (oracle/slam_oracle.cpp, "
-                  "g++ -O3 -ffp-contract=off, 1 thread), %.1f s, %.0f keypoints/frame" % (n, dt, kps_total / n),
-        "matched_keypoints_per_s": kps_total / dt,
-        "host_cpus": os.cpu_count(),
-    }
+        t0 = time.perf_counter()
+        prev = dac(frames[-1])  # predecessor of frame 0, not counted
+        o.match(prev[1], prev[1], prev[0], prev[0], M)  # (sizes the sample: matching is O(N^2) and dominates at 10k keypoints)
+        t_first = time.perf_counter() - t0
+        n = int(max(2, min(len(frames), budget_s / max(t_first, 1e-3))))
+        t0 = time.perf_counter()
+        kps_total = 0
+        for k in range(n):
+            cur = dac(frames[k])
+            o.match(cur[1], prev[1], cur[0], prev[0], M)
+            kps_total += len(cur[0])
+            prev = cur
+        dt = time.perf_counter() - t0
+        out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d frames of the same workload, CPU restatement of the reference path over the pyramid "
+                         "(oracle/, g++ -O3 -ffp-contract=off, 1 thread), %.1f s, %.0f keypoints/frame" % (n, dt, kps_total / n),
+               "matched_keypoints_per_s": kps_total / dt}
+        out.update(host)
+        return out
+    # size the samples from two frames
+    dt2, _ = o.sequence_mt(frames[:2], P, M, True, 1)
+    t_frame = max(dt2 / 3.0, 1e-4)  # 2 frames + the halo's detectAndCompute
+    n1 = int(max(2, min(len(frames), budget_s / t_frame)))
+    reps1 = int(max(1, budget_s / (t_frame * n1)))  # short jobs (c1: 50 frames) go round several times
+    dt1, per = o.sequence_mt(frames[:n1], P, M, True, 1, reps1)
+    kps1 = float(per[:, 0].sum()) * reps1
+    n1 *= reps1
+    out = {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same workload, CPU restatement of the reference path (oracle/slam_oracle.cpp, "
+                     "g++ -O3 -ffp-contract=off, 1 thread = the reference's execution model), %.1f s, %.0f keypoints/frame"
+                     % (n1, dt1, kps1 / n1),
+           "matched_keypoints_per_s": kps1 / dt1}
+    out.update(host)
+    if cores > 1:
+        T = min(cores, len(frames), 128)
+        per_thread = max(1, len(frames) // T)
+        nmt = per_thread * T
+        # one frame per thread first: what a frame costs with every core busy (clocks, shared caches, a quota the
+        # cgroup files did not show), then as many passes as the budget allows
+        dt_cal, _ = o.sequence_mt(frames[:T], P, M, True, T, 1)
+        t_busy = max(dt_cal / 2.0, 1e-4)  # a thread did its halo + one frame
+        reps = int(max(1, min(10000, budget_mt_s / (t_busy * per_thread))))
+        dtm, perm = o.sequence_mt(frames[:nmt], P, M, True, T, reps)
+        out["all_cores"] = {"value": nmt * reps / dtm, "unit": "frames/s", "cores": T, "kind": "port",
+                            "sample": "%d frames x %d passes sharded over %d std::threads (oracle/cpu_sequence.cpp; the "
+                                      "reference itself is single-threaded), %.1f s" % (nmt, reps, T, dtm),
+                            "matched_keypoints_per_s": float(perm[:, 0].sum()) * reps / dtm,
+                            "speedup_over_1_thread": (nmt * reps / dtm) / (n1 / dt1)}
+    return out
 
 
 def launch_ranks(args, argv):
@@ -693,6 +783,10 @@ def main(argv=None):
             batch.set_profiling(0, 1)
             out["pcie_inclusive"] = pcie_inclusive(mod, wl, B, frames, (ctx, batch, matcher), local_rank,
                                                    not args.no_keypoints)
+            # SURVEY.md 8d defines frames/s END TO END (host frames in, host results out): that is this leg
+            out["end_to_end"] = {"value": out["pcie_inclusive"]["value"], "unit": "frames/s",
+                                 "definition": "SURVEY.md 8d: H2D of every frame + detect/describe/match + D2H of every "
+                                               "result, batched (= pcie_inclusive); `value` is the HBM-resident rate"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mod, wl, frames)
         if n_gpus == 1 and args.workload == "1080p_2k" and not args.no_extras:

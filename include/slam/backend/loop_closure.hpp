@@ -56,10 +56,28 @@ inline PnPRansacResult pnpRansac(const std::vector<Vec3d>& points3d, const std::
     return r;
 }
 
+#ifdef SLAMX_HAVE_EIGEN
+// include/slam/backend/loop_closure.hpp:17-20 of the reference
+struct LoopResult {
+    int matchedKeyframeId{};
+    Eigen::Matrix4d relativeTransform = Eigen::Matrix4d::Identity();
+};
+#else
 struct LoopResult {
     int matchedKeyframeId{};
     std::array<double, 16> relativeTransform{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // row-major 4x4
 };
+#endif
+
+namespace detail {
+inline void set_transform(LoopResult& r, int i, int j, double v) {
+#ifdef SLAMX_HAVE_EIGEN
+    r.relativeTransform(i, j) = v;
+#else
+    r.relativeTransform[static_cast<size_t>(i * 4 + j)] = v;
+#endif
+}
+}  // namespace detail
 
 class LoopClosure {
 public:
@@ -81,6 +99,18 @@ public:
         m_keyframeDescriptors[keyframeId] = descriptors;
         m_lastKeyframeId = keyframeId;
     }
+
+#ifdef SLAMX_HAVE_EIGEN
+    // the reference's own signature (include/slam/backend/loop_closure.hpp:26-28)
+    void addKeyframe(int keyframeId, const DescriptorMatrix& descriptors, const std::vector<Keypoint>& keypoints,
+                     const std::vector<Eigen::Vector3d>& mapPoints) {
+        std::vector<Vec3d> pts(mapPoints.size());
+        for (size_t i = 0; i < mapPoints.size(); ++i) {
+            pts[i] = {mapPoints[i](0), mapPoints[i](1), mapPoints[i](2)};
+        }
+        addKeyframe(keyframeId, descriptors, keypoints, pts);
+    }
+#endif
 
     // loop_closure.cpp:111-151
     [[nodiscard]] std::optional<LoopResult> detect(const DescriptorMatrix& descriptors, const std::vector<Keypoint>& keypoints,
@@ -150,16 +180,16 @@ private:
                                 static_cast<double>(queryKeypoints[static_cast<size_t>(match.queryIdx)].y)});
             points3d.push_back(kf.mapPoints[static_cast<size_t>(match.trainIdx)]);
         }
-        const PnPRansacResult r = pnpRansac(points3d, points2d, camera.getIntrinsicMatrix(), m_params.ransac_max_iterations,
+        const PnPRansacResult r = pnpRansac(points3d, points2d, camera.intrinsics(), m_params.ransac_max_iterations,
                                             m_params.ransac_reprojection_threshold, m_seed);
         if (r.inliers >= m_params.min_inliers_for_pnp) {
             LoopResult result;
             result.matchedKeyframeId = candidateId;
             for (int i = 0; i < 3; ++i) {
                 for (int j = 0; j < 3; ++j) {
-                    result.relativeTransform[static_cast<size_t>(i * 4 + j)] = r.rotation[static_cast<size_t>(i * 3 + j)];
+                    detail::set_transform(result, i, j, r.rotation[static_cast<size_t>(i * 3 + j)]);
                 }
-                result.relativeTransform[static_cast<size_t>(i * 4 + 3)] = r.translation[static_cast<size_t>(i)];
+                detail::set_transform(result, i, 3, r.translation[static_cast<size_t>(i)]);
             }
             return result;
         }

@@ -2,6 +2,7 @@
 // (reference: include/slam/common/common.hpp:67-190 and :201-221) over the C ABI.
 #pragma once
 
+#include <memory>
 #include <vector>
 
 #include <slam/common/common.hpp>
@@ -25,19 +26,39 @@ public:
                                       out.data()));
         return out;
     }
-    [[nodiscard]] Mat3d getIntrinsicMatrix() const {
+    // K as the row-major array the C ABI takes (what the facade's own code uses, with or without Eigen)
+    [[nodiscard]] Mat3d intrinsics() const {
         Mat3d K{};
         for (int i = 0; i < 9; ++i) {
             K[static_cast<size_t>(i)] = m_cam.K[i];
         }
         return K;
     }
+#ifdef SLAMX_HAVE_EIGEN
+    // the reference's own signature (common.hpp:175): callers hand it to cv::eigen2cv
+    [[nodiscard]] const Eigen::Matrix3d& getIntrinsicMatrix() const {
+        if (!m_eigenK) {
+            m_eigenK = std::make_shared<Eigen::Matrix3d>();
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) {
+                    (*m_eigenK)(i, j) = m_cam.K[i * 3 + j];
+                }
+            }
+        }
+        return *m_eigenK;
+    }
+#else
+    [[nodiscard]] Mat3d getIntrinsicMatrix() const { return intrinsics(); }
+#endif
     [[nodiscard]] std::array<double, 5> getDistortionCoefficients() const {
         return {m_cam.k1, m_cam.k2, m_cam.p1, m_cam.p2, m_cam.k3};
     }
 
 private:
     slamx_camera m_cam{};
+#ifdef SLAMX_HAVE_EIGEN
+    mutable std::shared_ptr<Eigen::Matrix3d> m_eigenK;  // built on first use
+#endif
 };
 
 // common.hpp:201-221 + the conversion loop of PoseEstimator::triangulatePoints

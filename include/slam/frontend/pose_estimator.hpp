@@ -46,7 +46,7 @@ public:
             points1.push_back({keypoints1[static_cast<size_t>(m.first)].x, keypoints1[static_cast<size_t>(m.first)].y});
             points2.push_back({keypoints2[static_cast<size_t>(m.second)].x, keypoints2[static_cast<size_t>(m.second)].y});
         }
-        const Mat3d K = m_camera.get().getIntrinsicMatrix();
+        const Mat3d K = m_camera.get().intrinsics();
         Mat3d E{};
         int inliers = 0;
         detail::check(slamx_essential_ransac(detail::default_context(), reinterpret_cast<const float*>(points1.data()),
@@ -71,7 +71,7 @@ public:
     // pose_estimator.cpp:70-104
     std::vector<Point3d> triangulatePoints(const std::vector<Keypoint>& keypoints1, const std::vector<Keypoint>& keypoints2,
                                            const std::vector<Match>& matches, const Mat3d& R, const Vec3d& t) const {
-        const Mat3d K = m_camera.get().getIntrinsicMatrix();
+        const Mat3d K = m_camera.get().intrinsics();
         const Mat34d T1{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
         const Mat34d T2{R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
         auto mul = [&](const Mat34d& T) {
@@ -96,6 +96,63 @@ public:
         }
         return triangulate(mul(T1), mul(T2), points1, points2);
     }
+
+#ifdef SLAMX_HAVE_OPENCV
+    // ---- the reference's own signatures (include/slam/frontend/pose_estimator.hpp:15-32) ----
+    // src/frontend/pose_estimator.cpp:18-67: fewer than 8 matches, or no essential matrix, leave R and t untouched.
+    void estimate(const std::vector<KeyDescriptorPair>& pairs1, const std::vector<KeyDescriptorPair>& pairs2,
+                  const std::vector<std::pair<int, int>>& matches, cv::Mat& R, cv::Mat& t) const {
+        if (matches.size() < 8) {
+            return;  // pose_estimator.cpp:22-26
+        }
+        std::vector<Keypoint> k1(pairs1.size()), k2(pairs2.size());
+        for (size_t i = 0; i < pairs1.size(); ++i) {
+            k1[i].x = pairs1[i].first.pt.x;
+            k1[i].y = pairs1[i].first.pt.y;
+        }
+        for (size_t i = 0; i < pairs2.size(); ++i) {
+            k2[i].x = pairs2[i].first.pt.x;
+            k2[i].y = pairs2[i].first.pt.y;
+        }
+        Mat3d r{};
+        Vec3d tv{};
+        if (estimate(k1, k2, matches, r, tv)) {
+            detail::to_cv(r, R);
+            detail::to_cv(tv, t);
+        }
+    }
+
+    // src/frontend/pose_estimator.cpp:69-104
+    std::vector<cv::Point3d> triangulatePoints(const std::vector<cv::KeyPoint>& keypoints1,
+                                               const std::vector<cv::KeyPoint>& keypoints2,
+                                               const std::vector<cv::DMatch>& matches, const cv::Mat& R,
+                                               const cv::Mat& t) const {
+        const Mat3d r = detail::mat3_of(R, "triangulatePoints: R");
+        detail::require64(t, 3, 1, "triangulatePoints: t");
+        const Vec3d tv{t.at<double>(0, 0), t.at<double>(1, 0), t.at<double>(2, 0)};
+        std::vector<Keypoint> k1(keypoints1.size()), k2(keypoints2.size());
+        for (size_t i = 0; i < keypoints1.size(); ++i) {
+            k1[i].x = keypoints1[i].pt.x;
+            k1[i].y = keypoints1[i].pt.y;
+        }
+        for (size_t i = 0; i < keypoints2.size(); ++i) {
+            k2[i].x = keypoints2[i].pt.x;
+            k2[i].y = keypoints2[i].pt.y;
+        }
+        std::vector<Match> m(matches.size());
+        for (size_t i = 0; i < matches.size(); ++i) {
+            m[i].queryIdx = matches[i].queryIdx;
+            m[i].trainIdx = matches[i].trainIdx;
+            m[i].distance = matches[i].distance;
+        }
+        std::vector<cv::Point3d> out;
+        out.reserve(m.size());
+        for (const Point3d& p : triangulatePoints(k1, k2, m, r, tv)) {
+            out.emplace_back(p.x, p.y, p.z);
+        }
+        return out;
+    }
+#endif
 
 private:
     std::reference_wrapper<const Camera> m_camera;

@@ -218,6 +218,29 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
 int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoint* kps, uint8_t* desc,
                                        slamx_match* matches, int32_t* n_keypoints, int32_t* n_matches);
 
+/* The PACKED form of the streaming download.  A device-side pack step (a prefix over the per-frame counts, then one
+ * copy kernel) gathers the VALID keypoints, descriptors and matches of frames [0, nframes) -- what the reference
+ * returns per frame in its std::vector<Keypoint> / DescriptorMatrix / std::vector<Match> (feature_detector.cpp:49-54,
+ * feature_matcher.cpp:71-95) -- into ONE contiguous device buffer, and the first `bytes` of it are copied into
+ * PAGE-LOCKED `host` on the context stream (about 116 KB per 1080p frame of 2k keypoints instead of the 262 KB of
+ * the capacity-padded arrays).  Buffer layout, every section 16-byte aligned, offsets in bytes from its start:
+ *     slamx_packed_header
+ *     int32 kp_first[nframes + 1]      exclusive prefix of the keypoint counts: frame f owns [kp_first[f], kp_first[f+1])
+ *     int32 match_first[nframes + 1]   the same for the matches (all zero when no matcher has run on the batch)
+ *     int32 status[nframes]            per-frame overflow bits (0 = complete)
+ *     slamx_keypoint kps[total_keypoints]; uint8 desc[total_keypoints][width]; slamx_match matches[total_matches]
+ * The total is only known on the device, so the caller chooses `bytes` (at most slamx_batch_packed_bound(), the
+ * worst case; a streaming caller passes a little more than the previous batch needed).  After synchronising it
+ * reads header.total_bytes: if that exceeds `bytes`, slamx_batch_download_packed_tail fetches [from, total_bytes)
+ * of the same packed buffer (synchronous), valid until the next pack of this batch. */
+typedef struct slamx_packed_header {
+    int32_t nframes, width, total_keypoints, total_matches;
+    int64_t first_off, mfirst_off, status_off, kps_off, desc_off, matches_off, total_bytes;
+} slamx_packed_header;
+size_t slamx_batch_packed_bound(slamx_batch* b, int nframes);
+int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, size_t bytes);
+int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, size_t host_capacity);
+
 /* Per-stage device time from hipEvents recorded on the context stream between the kernels (no
  * synchronization is added).  slamx_batch_set_profiling(b, n_sets) keeps n_sets event sets
  * (0 = off); the i-th detect_and_compute call after it records into set i % n_sets, and the

@@ -75,10 +75,12 @@ extern "C" {
 
 // frames: [nframes][rows][cols] dense.  Frame k is matched against frame k-1, frame 0 against frame nframes-1 (the
 // convention of bench.py's step).  per_frame (optional, [nframes][3]) receives keypoints, matches and an FNV-1a hash of
-// the frame's keypoints + descriptors + matches: identical for every thread count.  Returns the wall seconds of the
-// threaded region (thread start to last join).
+// the frame's keypoints + descriptors + matches: identical for every thread count.  reps >= 1: every thread goes over
+// its chunk that many times (a long enough timed region on many cores without holding thousands of frames in memory;
+// nframes * reps frames are processed, the halo once per thread).  Returns the wall seconds of the threaded region
+// (thread start to last join).
 double oracle_sequence_mt(const uint8_t* frames, int nframes, int rows, int cols, const DetectorParams* P,
-                          const MatcherParams* M, int use_keypoints, int n_threads, uint64_t* per_frame) {
+                          const MatcherParams* M, int use_keypoints, int n_threads, int reps, uint64_t* per_frame) {
     if (nframes <= 0) {
         return 0.0;
     }
@@ -94,6 +96,7 @@ double oracle_sequence_mt(const uint8_t* frames, int nframes, int rows, int cols
         Features prev, cur;
         detect_and_compute(frames + fsz * static_cast<size_t>((first + nframes - 1) % nframes), rows, cols, *P, &prev);  // halo
         std::vector<Match> m;
+        for (int rep = 0; rep < (reps < 1 ? 1 : reps); ++rep)
         for (int k = first; k < last; ++k) {
             detect_and_compute(frames + fsz * static_cast<size_t>(k), rows, cols, *P, &cur);
             const int n1 = static_cast<int>(cur.kps.size()), n2 = static_cast<int>(prev.kps.size());
@@ -104,7 +107,7 @@ double oracle_sequence_mt(const uint8_t* frames, int nframes, int rows, int cols
                                   use_keypoints ? n1 : 0, use_keypoints ? prev.kps.data() : nullptr, use_keypoints ? n2 : 0, M,
                                   m.data(), static_cast<int>(m.size()));
             }
-            if (per_frame != nullptr) {
+            if (per_frame != nullptr && rep == 0) {  // later passes pair a chunk's first frame with its own last
                 uint64_t h = 0xCBF29CE484222325ULL;
                 h = fnv(h, cur.kps.data(), cur.kps.size() * sizeof(Keypoint));
                 h = fnv(h, cur.desc.data(), cur.desc.size());

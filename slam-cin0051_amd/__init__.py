@@ -95,7 +95,8 @@ EXPORTS = [
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
+    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_packed_bound", "slamx_batch_download_packed_async",
+    "slamx_batch_download_packed_tail", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_undistort",
     "slamx_pyramid_create", "slamx_pyramid_destroy", "slamx_pyramid_batch", "slamx_pyramid_level_shape",
@@ -164,6 +165,10 @@ def load_library():
     lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_download_results_async.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.slamx_batch_packed_bound.argtypes = [vp, C.c_int]
+    lib.slamx_batch_packed_bound.restype = C.c_size_t
+    lib.slamx_batch_download_packed_async.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.slamx_batch_download_packed_tail.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     lib.slamx_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.slamx_batch_set_profiling_every.argtypes = [vp, C.c_int, C.c_int]
     lib.slamx_batch_stage_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -692,6 +697,21 @@ class Batch:
         _check(self.lib.slamx_batch_download_results_async(self.h, nframes, kps.ctypes.data, desc.ctypes.data,
                                                            matches.ctypes.data, nk.ctypes.data, nm.ctypes.data))
 
+    def packed_buffer(self, nframes):
+        """Page-locked byte array large enough for the packed results of nframes frames in the worst case."""
+        return pinned_array((int(self.lib.slamx_batch_packed_bound(self.h, nframes)),), np.uint8)
+
+    def download_packed_async(self, nframes, buf, nbytes=None):
+        """Pack the valid results of frames [0, nframes) on the device and queue the copy of the first nbytes
+        (default: all of buf) into the page-locked buf; synchronise, then unpack_results(buf) -- or fetch_packed_tail
+        first when header.total_bytes > nbytes."""
+        n = buf.nbytes if nbytes is None else min(int(nbytes), buf.nbytes)
+        _check(self.lib.slamx_batch_download_packed_async(self.h, nframes, buf.ctypes.data, n))
+        return n
+
+    def fetch_packed_tail(self, buf, have):
+        _check(self.lib.slamx_batch_download_packed_tail(self.h, buf.ctypes.data, int(have), buf.nbytes))
+
     def set_profiling(self, n_sets=1, every=1):
         _check(self.lib.slamx_batch_set_profiling_every(self.h, n_sets, every))
 
@@ -699,6 +719,33 @@ class Batch:
         ms = (C.c_float * len(STAGES))()
         _check(self.lib.slamx_batch_stage_ms(self.h, set_index, ms))
         return dict(zip(STAGES, [float(x) for x in ms]))
+
+
+PACKED_HEADER_DTYPE = np.dtype([("nframes", "<i4"), ("width", "<i4"), ("total_keypoints", "<i4"), ("total_matches", "<i4"),
+                                ("first_off", "<i8"), ("mfirst_off", "<i8"), ("status_off", "<i8"), ("kps_off", "<i8"),
+                                ("desc_off", "<i8"), ("matches_off", "<i8"), ("total_bytes", "<i8")])
+
+
+def packed_header(buf):
+    """slamx_packed_header at the start of a packed results buffer (include/slamx.h)."""
+    return np.frombuffer(buf, PACKED_HEADER_DTYPE, 1)[0]
+
+
+def unpack_results(buf):
+    """Views into a packed results buffer: (kp_first, match_first, status, kps, desc, matches); frame f owns
+    kps[kp_first[f]:kp_first[f + 1]] (desc alike) and matches[match_first[f]:match_first[f + 1]]."""
+    h = packed_header(buf)
+    if int(h["total_bytes"]) > buf.nbytes:
+        raise CapacityError("packed results need %d bytes, the buffer holds %d" % (int(h["total_bytes"]), buf.nbytes))
+    F, w, nk, nm = int(h["nframes"]), int(h["width"]), int(h["total_keypoints"]), int(h["total_matches"])
+    raw = buf.view(np.uint8).reshape(-1)
+    kp_first = np.frombuffer(raw, np.int32, F + 1, int(h["first_off"]))
+    m_first = np.frombuffer(raw, np.int32, F + 1, int(h["mfirst_off"]))
+    status = np.frombuffer(raw, np.int32, F, int(h["status_off"]))
+    kps = np.frombuffer(raw, KEYPOINT_DTYPE, nk, int(h["kps_off"]))
+    desc = np.frombuffer(raw, np.uint8, nk * w, int(h["desc_off"])).reshape(nk, w)
+    matches = np.frombuffer(raw, MATCH_DTYPE, nm, int(h["matches_off"]))
+    return kp_first, m_first, status, kps, desc, matches
 
 
 class _BorrowedBatch(Batch):

@@ -112,6 +112,8 @@ struct slamx_batch {
     int2* best = nullptr;
     int* second = nullptr;
     uint8_t* xdesc = nullptr;  // [F][maxK][64] expanded descriptors of the matrix-core matcher
+    uint8_t* pack = nullptr;   // packed results of slamx_batch_download_packed_async (worst-case size, on first use)
+    size_t pack_bytes = 0;
     // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
     // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS_BUILD|5|NMS_ROUNDS|6|BLUR|7|MOMENTS|8|TRIG|9|BRIEF|10|MATCH|11|EMIT|12
     static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
@@ -805,6 +807,7 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.moments);
     dev_free(v.cos_sin);
     dev_free(v.status);
+    dev_free(b->pack);
     dev_free(v.nbr_cnt);
     dev_free(v.nbr);
     dev_free(b->matches);
@@ -1083,6 +1086,57 @@ int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoi
     }
     if (n_matches != nullptr) {
         HIP_TRY(hipMemcpyAsync(n_matches, b->n_matches, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    return SLAMX_OK;
+}
+
+size_t slamx_batch_packed_bound(slamx_batch* b, int nframes) {
+    if (b == nullptr || nframes < 0 || nframes > b->shape.max_frames) {
+        return 0;
+    }
+    return packed_bound_bytes(nframes, b->v.maxK, b->v.width, true);
+}
+
+int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, size_t bytes) {
+    if (b == nullptr || nframes <= 0 || nframes > b->shape.max_frames || host == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_async: nframes out of range or no host buffer");
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_async needs page-locked host memory (slamx_host_alloc)");
+    }
+    const size_t bound = packed_bound_bytes(nframes, b->v.maxK, b->v.width, true);
+    if (bytes < sizeof(slamx_packed_header)) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_async: the host buffer cannot even hold the header");
+    }
+    if (b->pack == nullptr) {
+        const size_t cap = packed_bound_bytes(b->shape.max_frames, b->v.maxK, b->v.width, true);
+        SLAMX_TRY(dev_alloc(&b->pack, cap));
+        b->pack_bytes = cap;
+    }
+    hipStream_t s = b->det->ctx->stream;
+    launch_pack_results(b->v, b->matches, b->n_matches, nframes, b->pack, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, b->pack, std::min(bytes, bound), hipMemcpyDeviceToHost, s));
+    return SLAMX_OK;
+}
+
+int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, size_t host_capacity) {
+    if (b == nullptr || host == nullptr || b->pack == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_tail: nothing has been packed on this batch");
+    }
+    HIP_TRY(hipSetDevice(b->det->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
+    slamx_packed_header h{};
+    HIP_TRY(hipMemcpy(&h, b->pack, sizeof(h), hipMemcpyDeviceToHost));
+    const size_t total = static_cast<size_t>(h.total_bytes);
+    if (total > b->pack_bytes || total > host_capacity) {
+        return fail(SLAMX_ERR_CAPACITY, "download_packed_tail: the host buffer is smaller than header.total_bytes");
+    }
+    if (from < total) {
+        HIP_TRY(hipMemcpy(static_cast<uint8_t*>(host) + from, b->pack + from, total - from, hipMemcpyDeviceToHost));
     }
     return SLAMX_OK;
 }

@@ -239,6 +239,9 @@ void launch_triangulate(const double* P1, const double* P2, const float* pts1, c
 // append of a level's results, scaled to level-0 coordinates, to level 0's keypoint / descriptor arrays
 void launch_downscale(const BatchView& src, const BatchView& dst, const uint32_t* xtab, const uint32_t* ytab, int nframes,
                       hipStream_t stream);
+size_t packed_bound_bytes(int nframes, int maxK, int width, bool with_matches);
+void launch_pack_results(const BatchView& v, const slamx_match* matches, const int* n_matches, int nframes, uint8_t* pack,
+                         hipStream_t stream);
 void launch_merge_level(const BatchView& src, const BatchView& dst, float scale, int nframes, hipStream_t stream);
 
 // sliding-window Gauss-Newton (gn.hip): device pointers of a batch of windows

@@ -211,16 +211,17 @@ class Oracle:
         return perm
 
     # ---- the restated CPU path over a sequence of frames on T threads (oracle/cpu_sequence.cpp)
-    def sequence_mt(self, frames, P, M, use_keypoints=True, n_threads=1):
+    def sequence_mt(self, frames, P, M, use_keypoints=True, n_threads=1, reps=1):
         """frames [n][rows][cols] u8; frame k matched against k-1 (frame 0 against the last).  Returns (wall seconds,
-        per_frame [n][3] = keypoints, matches, FNV-1a of keypoints + descriptors + matches)."""
+        per_frame [n][3] = keypoints, matches, FNV-1a of keypoints + descriptors + matches).  reps: passes of every
+        thread over its chunk (n * reps frames processed)."""
         f = np.ascontiguousarray(frames, np.uint8)
         out = np.zeros((f.shape[0], 3), np.uint64)
         fn = self.lib.oracle_sequence_mt
         fn.restype = C.c_double
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         dt = fn(_p(f), f.shape[0], f.shape[1], f.shape[2], C.addressof(P), C.addressof(M), 1 if use_keypoints else 0,
-                int(n_threads), _p(out))
+                int(n_threads), int(reps), _p(out))
         return dt, out
 
     # ---- image pyramid (oracle/pyramid_oracle.cpp; build-defined, no reference counterpart)

@@ -305,3 +305,40 @@ def test_backend_facade_host_errors():
                        stderr=subprocess.PIPE, timeout=60)
     assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
     assert "host checks: ok" in p.stdout.decode()
+
+
+@pytest.mark.parametrize("flags", [[], ["-DSLAMX_USE_OPENCV"], ["-DSLAMX_USE_EIGEN"], ["-DSLAMX_USE_OPENCV", "-DSLAMX_USE_EIGEN"]])
+def test_facade_headers_compile_with_and_without_reference_types(flags, tmp_path):
+    """Every facade header, in every combination of the reference-type switches: the SLAMX_USE_OPENCV / SLAMX_USE_EIGEN
+    branches (cv:: / Eigen::-typed overloads with the reference's exact signatures) are syntax-checked against the
+    API-subset headers of tests/compile_check -- the libraries themselves are not in this image."""
+    tu = tmp_path / "all_headers.cpp"
+    tu.write_text("\n".join("#include <slam/%s>" % h for h in (
+        "common/common.hpp", "common/camera.hpp", "frontend/feature_detector.hpp", "frontend/feature_matcher.hpp",
+        "frontend/simple_pose_recover.hpp", "frontend/pose_estimator.hpp", "backend/loop_closure.hpp", "backend/map.hpp",
+        "backend/backend.hpp", "preprocessing/preprocessor.hpp")) + "\nint main() { return 0; }\n")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "tests", "compile_check")] + flags + [str(tu)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
+def test_reference_typed_signatures_are_the_references():
+    """The overloads must be spelled as the reference spells them (its headers are not shipped: the expected
+    parameter lists are restated here from include/slam/frontend/pose_estimator.hpp:15-32,
+    simple_pose_recover.hpp:17-19 and backend/loop_closure.hpp:26-28)."""
+    def squash(s):
+        return re.sub(r"\s+", " ", s)
+    pe = squash(open(os.path.join(ROOT, "include/slam/frontend/pose_estimator.hpp")).read())
+    assert ("void estimate(const std::vector<KeyDescriptorPair>& pairs1, const std::vector<KeyDescriptorPair>& pairs2, "
+            "const std::vector<std::pair<int, int>>& matches, cv::Mat& R, cv::Mat& t)") in pe
+    assert ("std::vector<cv::Point3d> triangulatePoints(const std::vector<cv::KeyPoint>& keypoints1, "
+            "const std::vector<cv::KeyPoint>& keypoints2, const std::vector<cv::DMatch>& matches, const cv::Mat& R, "
+            "const cv::Mat& t)") in pe
+    sp = squash(open(os.path.join(ROOT, "include/slam/frontend/simple_pose_recover.hpp")).read())
+    assert ("void simpleRecoverPose(const cv::Mat& E, const std::vector<cv::Point2f>& points1, "
+            "const std::vector<cv::Point2f>& points2, const cv::Mat& K, cv::Mat& R, cv::Mat& t)") in sp
+    lc = squash(open(os.path.join(ROOT, "include/slam/backend/loop_closure.hpp")).read())
+    assert ("void addKeyframe(int keyframeId, const DescriptorMatrix& descriptors, const std::vector<Keypoint>& keypoints, "
+            "const std::vector<Eigen::Vector3d>& mapPoints)") in lc
+    assert "Eigen::Matrix4d relativeTransform = Eigen::Matrix4d::Identity();" in lc

@@ -224,3 +224,12 @@ def test_backend_program():
     text = _run([os.path.join(BIN, "test_backend")])
     assert text.startswith("host checks: ok\ncost ")
     assert "failing pass: threw 1, failed() 1, map untouched 1" in text
+
+
+def test_reference_typed_call_sequences(ref_data):
+    """tools/reference_call_sequence.cpp: the reference's own call sequences (test_pose_estimator.cpp:113-177,
+    test_loop_closure.cpp:46-79) written with cv::Mat / cv::KeyPoint / cv::DMatch / Eigen::Vector3d against the facade's
+    reference-typed overloads; every result is compared bit for bit with the plain-typed overload of the same call."""
+    text = _run([os.path.join(BIN, "reference_call_sequence"), ref_data])
+    assert "cv-typed == plain-typed: yes" in text and "Eigen-typed == plain-typed: yes" in text
+    assert "in front" in text

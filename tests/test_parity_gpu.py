@@ -778,6 +778,59 @@ def test_batch_download_results_async(slamx, oracle):
         b.download_results_async(3, (np.empty((3, 1024), slamx.KEYPOINT_DTYPE),) + bufs[1:])
 
 
+def test_batch_download_packed_async(slamx, oracle):
+    """The packed streaming download: a device-side pack step gathers the valid keypoints / descriptors / matches of
+    all frames into one buffer (prefix of the counts + copy kernel), ONE queued copy brings it to page-locked
+    memory; frames with different counts, an empty frame in the middle, the tail call when the first copy was cut
+    short, and a batch no matcher has run on."""
+    d = slamx.FeatureDetector(cfg_of(slamx, window=8))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.8))
+    frames = [synth(slamx, k, 200, 300, n, rmin=4, rmax=24) for k, n in enumerate((250, 120, 0, 400, 60))]
+    frames[2][:] = 128  # no corners at all
+    F = len(frames)
+    b = slamx.Batch(d, 200, 300, F, 8192, 1024)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(F)
+    buf = b.packed_buffer(F)
+    b.download_packed_async(F, buf)  # before any matcher has run: no matches section
+    d.ctx.synchronize()
+    kp_first, m_first, status, kps, desc, matches = slamx.unpack_results(buf)
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    assert np.diff(kp_first).tolist() == [len(r[0]) for r in ref] and not m_first.any() and len(matches) == 0
+    b.match_consecutive(m, F, use_keypoints=True, first_train_frame=F - 1)
+    buf[:] = 0xEE
+    b.download_packed_async(F, buf)
+    d.ctx.synchronize()
+    kp_first, m_first, status, kps, desc, matches = slamx.unpack_results(buf)
+    h = slamx.packed_header(buf)
+    assert h["nframes"] == F and h["width"] == 32 and not status.any()
+    assert h["total_bytes"] < 0.35 * buf.nbytes  # far below the capacity-padded worst case
+    assert kp_first[0] == 0 and kp_first[2] == kp_first[3]  # the empty frame owns an empty range
+    mp = oracle.match_params(m.cfg)
+    for k in range(F):
+        sl = slice(kp_first[k], kp_first[k + 1])
+        assert_records_equal(kps[sl], ref[k][0], "keypoints of frame %d" % k)
+        assert np.array_equal(desc[sl], ref[k][1])
+        t = (k - 1) % F
+        got = matches[m_first[k]:m_first[k + 1]]
+        if len(ref[k][0]) and len(ref[t][0]):
+            assert_records_equal(got, oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], mp), "matches of frame %d" % k)
+        else:
+            assert len(got) == 0
+    # a first copy that was cut short (a streaming caller guessing too low), completed by the tail call
+    total = int(h["total_bytes"])
+    short = b.packed_buffer(F)
+    short[:] = 0
+    have = b.download_packed_async(F, short, total // 3)
+    d.ctx.synchronize()
+    assert slamx.packed_header(short)["total_bytes"] == total and have < total
+    b.fetch_packed_tail(short, have)
+    assert np.array_equal(short[:total], buf[:total])
+    with pytest.raises(ValueError):  # pageable memory is refused
+        b.download_packed_async(F, np.empty(buf.nbytes, np.uint8))
+
+
 def test_batch_capacity_overflow_is_loud(slamx):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     frame = synth(slamx, 0, 240, 320, 1200, rmin=3, rmax=16)
@@ -857,6 +910,42 @@ def test_full_size_workloads_bit_exact(slamx, oracle, name, rows, cols, window, 
         want = oracle.match(ref[q][1], ref[t_][1], ref[q][0], ref[t_][0], mp)
         assert_records_equal(b.download_matches(m, q), want, "%s matches %d->%d" % (name, q, t_))
     assert len(ref[0][0]) > 1500
+
+
+def test_c1_job_bit_exact(slamx, oracle, ref_data):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case -- as bench.py --workload c1 runs it: the whole
+    job of 50 synthetic 640x480 frames (~500 keypoints each) with the SHIPPED detector YAML (window 12), every frame
+    detected, described and matched to its predecessor (frame 0 to frame 49).  Every frame's keypoints, descriptors
+    and matches are hashed and compared with the CPU sequence runner (oracle/cpu_sequence.cpp)."""
+    import importlib.util
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wl = bench.WORKLOADS["c1"]
+    B = wl["batch"]
+    assert (B, wl["rows"], wl["cols"], wl["window"]) == (50, 480, 640, 12)
+    d = slamx.FeatureDetector(os.path.join(ref_data, "feature_detector.yml"))
+    assert d.cfg.suppression_window_size == wl["window"]
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 20, 1, 0.5))
+    frames = np.stack([slamx.synth_frame(bench.SEED, k, wl["rows"], wl["cols"], wl["n_rect"], wl["rmin"], wl["rmax"]) for k in range(B)])
+    b = slamx.Batch(d, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
+    b.upload(frames)
+    b.detect_and_compute(B)
+    b.match_consecutive(m, B, use_keypoints=True, first_train_frame=B - 1)
+    _, want = oracle.sequence_mt(frames, oracle.det_params(d.cfg), oracle.match_params(m.cfg), True, 8)
+    ncand, nkp, nmatch = b.counts(B)
+    assert nkp.tolist() == want[:, 0].astype(int).tolist()
+    assert nmatch.tolist() == want[:, 1].astype(int).tolist()
+    assert 400 < nkp.mean() < 600
+    for k in range(B):
+        kps, desc = b.download(k)
+        mt = b.download_matches(m, k)
+        h = 0xCBF29CE484222325
+        for byte in kps.tobytes() + desc.tobytes() + mt.tobytes():
+            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        assert h == int(want[k, 2]), "frame %d" % k
 
 
 # ---------------------------------------------------------------- HIP path against the COMMITTED vectors (no oracle in the loop)
