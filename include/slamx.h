@@ -102,6 +102,8 @@ int slamx_matcher_mfma_threshold(void);
 
 /* ---- context: one per GPU; owns (or borrows) the HIP stream all work is enqueued on. ---- */
 /* hip_stream == NULL: the context creates its own non-blocking stream. */
+/* Number of usable HIP devices (0 when there is none or the runtime cannot be reached). */
+int slamx_device_count(void);
 int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out);
 void slamx_ctx_destroy(slamx_ctx* ctx);
 int slamx_ctx_synchronize(slamx_ctx* ctx);
@@ -381,6 +383,35 @@ int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out
  * ROW-major (the reference returns a column-major MatrixXd; same values). */
 int slamx_undistort(slamx_ctx* ctx, const slamx_camera* cam, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
                     double* out);
+
+/* ---- the one exchange of the multi-GPU path: all-gather of map points over RCCL ----
+ * Frames shard across GPUs with no collective on the data path; at the end of a job (or per keyframe batch) every
+ * rank contributes the map points it triangulated (PoseEstimator::triangulatePoints, pose_estimator.cpp:69-104:
+ * n x 3 doubles, n differs per rank) and receives everyone's.  The reference has no multi-GPU code; this is the
+ * C-ABI a C++17 host uses (one host thread or process + one context per GPU; tools/cli -g N); bench.py's Python
+ * ranks do the same exchange through torch.distributed.  librccl is loaded on first use (dlopen: $SLAMX_RCCL_LIBRARY,
+ * then librccl.so.1 / librccl.so), so the library has no link-time dependency on it.
+ *   rank 0:   slamx_mapgather_unique_id(id); hand the 128 bytes to the other ranks (shared memory, a file, a socket)
+ *   all:      slamx_mapgather_create(ctx, id, rank, world, &g)       -- ncclCommInitRank: every rank must call it
+ *             slamx_mapgather_allgather(g, xyz, n, counts, out, cap, &total)
+ * allgather = ncclAllGather of the counts, then ncclAllGather of the payload padded to the largest count (xGMI
+ * messages of KB to MB: latency-bound), on the context's stream; returns when `out` holds the points of rank 0,
+ * rank 1, ... back to back (total x 3 doubles) and counts[r] says how many are rank r's.  total > cap_points ->
+ * SLAMX_ERR_CAPACITY after the collectives have run (no rank is left waiting), *total set. */
+#define SLAMX_MAPGATHER_ID_BYTES 128
+typedef struct slamx_mapgather slamx_mapgather;
+int slamx_mapgather_unique_id(uint8_t id[SLAMX_MAPGATHER_ID_BYTES]);
+int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_BYTES], int rank, int world,
+                           slamx_mapgather** out);
+void slamx_mapgather_destroy(slamx_mapgather* g);
+int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts /* [world] */,
+                              double* out, int cap_points, int* total);
+/* The host-side bookkeeping of the exchange on its own (no GPU, no RCCL): the padded per-rank capacity (largest
+ * count, at least 1) and the total for a list of counts; and the unpacking of a gathered padded payload
+ * [world][padded_cap][3] into `out`.  slamx_mapgather_allgather uses exactly these. */
+int slamx_mapgather_plan(const int32_t* counts, int world, int* padded_cap, int* total);
+int slamx_mapgather_unpack(const double* padded, const int32_t* counts, int world, int padded_cap, double* out,
+                           int cap_points);
 
 /* ---- deterministic synthetic frames, host side, for tests and bench ---- */
 /* Frame k of the sequence with the given seed: background 96, n_rect filled rectangles with

@@ -86,7 +86,7 @@ class BatchShape(C.Structure):
 
 # every symbol include/slamx.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "slamx_last_error", "slamx_version", "slamx_matcher_mfma_threshold", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
+    "slamx_last_error", "slamx_version", "slamx_matcher_mfma_threshold", "slamx_device_count", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
     "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
     "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
@@ -103,6 +103,8 @@ EXPORTS = [
     "slamx_pyramid_detect_and_compute",
     "slamx_gn_create", "slamx_gn_destroy", "slamx_gn_upload", "slamx_gn_iterate", "slamx_gn_download",
     "slamx_gn_normal_equations", "slamx_gn_set_profiling", "slamx_gn_stage_ms",
+    "slamx_mapgather_unique_id", "slamx_mapgather_create", "slamx_mapgather_destroy", "slamx_mapgather_allgather",
+    "slamx_mapgather_plan", "slamx_mapgather_unpack",
 ]
 
 _lib = None
@@ -165,6 +167,12 @@ def load_library():
     lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
     lib.slamx_batch_download_matches.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_download_results_async.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.slamx_mapgather_unique_id.argtypes = [vp]
+    lib.slamx_mapgather_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.slamx_mapgather_destroy.argtypes = [vp]
+    lib.slamx_mapgather_allgather.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_mapgather_plan.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.slamx_mapgather_unpack.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
     lib.slamx_batch_packed_bound.argtypes = [vp, C.c_int]
     lib.slamx_batch_packed_bound.restype = C.c_size_t
     lib.slamx_batch_download_packed_async.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -285,10 +293,55 @@ def load_loop_closure_config(path):
     return cfg
 
 
-def _close_children(parent):
-    """Handles must go before the handle they were created on, whatever order the GC picks."""
-    for child in list(parent._children):
-        child.close()
+class _Handle:
+    """A C handle and the handles that have to be destroyed BEFORE it (a batch before its detector, a detector
+    before its context).  Plain cells with strong links both ways and no finaliser of their own: the wrapper
+    objects' __del__ only call close() here.  (WeakSets of the wrapper objects did not do: when the cyclic GC
+    collects a parent and a child together -- a failed test's traceback holds both -- it clears the weak
+    references first, the parent no longer finds the child, frees its own handle, and the child's destroy call
+    then runs on a dangling pointer.)"""
+
+    __slots__ = ("destroy", "value", "parent", "children")
+
+    def __init__(self, destroy, parent=None, value=None):
+        self.destroy = destroy  # None: a borrowed handle, only forgotten
+        self.value = C.c_void_p(value)
+        self.parent = parent
+        self.children = []
+        if parent is not None:
+            parent.children.append(self)
+
+    def close(self):
+        if self.value:
+            for c in list(self.children):
+                c.close()
+            if self.destroy is not None:
+                self.destroy(self.value)
+            self.value = C.c_void_p()
+        if self.parent is not None:
+            if self in self.parent.children:
+                self.parent.children.remove(self)
+            self.parent = None
+
+
+class _Owner:
+    """Mixin of the wrapper classes: `h` is the live C handle (NULL once closed, by whoever closed it)."""
+
+    _hd = None
+
+    @property
+    def h(self):
+        return self._hd.value
+
+    def close(self):
+        if self._hd is not None:
+            self._hd.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _live_contexts = weakref.WeakSet()
@@ -307,27 +360,14 @@ def _close_all_contexts():
 atexit.register(_close_all_contexts)
 
 
-class Context:
+class Context(_Owner):
     """One per GPU: owns the HIP stream every call is enqueued on."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load_library()
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_ctx_create(device, stream, C.byref(self.h)))
-        self._children = weakref.WeakSet()  # detectors / matchers: destroyed before the context
+        self._hd = _Handle(self.lib.slamx_ctx_destroy)  # detectors / matchers hang below it: destroyed before the context
+        _check(self.lib.slamx_ctx_create(device, stream, C.byref(self._hd.value)))
         _live_contexts.add(self)
-
-    def close(self):
-        if self.h:
-            _close_children(self)
-            self.lib.slamx_ctx_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def synchronize(self):
         _check(self.lib.slamx_ctx_synchronize(self.h))
@@ -459,30 +499,16 @@ def default_context():
     return _default_ctx
 
 
-class FeatureDetector:
+class FeatureDetector(_Owner):
     """slam::FeatureDetector (feature_detector.hpp:47-192).  config: YAML path or DetectorConfig."""
 
     def __init__(self, config, ctx=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.cfg = config if isinstance(config, DetectorConfig) else load_detector_config(config)
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_detector_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
+        self._hd = _Handle(self.lib.slamx_detector_destroy, self.ctx._hd)  # batches hang below it
+        _check(self.lib.slamx_detector_create(self.ctx.h, C.byref(self.cfg), C.byref(self._hd.value)))
         self.width = self.lib.slamx_detector_descriptor_width(self.h)
-        self._children = weakref.WeakSet()  # batches: destroyed before the detector
-        self.ctx._children.add(self)
-
-    def close(self):
-        if self.h:
-            _close_children(self)
-            self.lib.slamx_detector_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def pattern(self):
         n = C.c_int()
@@ -563,27 +589,15 @@ class FeatureDetector:
         return out
 
 
-class FeatureMatcher:
+class FeatureMatcher(_Owner):
     """slam::FeatureMatcher (feature_matcher.hpp:37-88).  config: YAML path or MatcherConfig."""
 
     def __init__(self, config, ctx=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.cfg = config if isinstance(config, MatcherConfig) else load_matcher_config(config)
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_matcher_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)))
-        self.ctx._children.add(self)
-
-    def close(self):
-        if self.h:
-            self.lib.slamx_matcher_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        self._hd = _Handle(self.lib.slamx_matcher_destroy, self.ctx._hd)
+        _check(self.lib.slamx_matcher_create(self.ctx.h, C.byref(self.cfg), C.byref(self._hd.value)))
 
     def match(self, descriptors1, descriptors2, keypoints1=None, keypoints2=None):
         d1 = np.ascontiguousarray(descriptors1, dtype=np.uint8)
@@ -602,28 +616,16 @@ class FeatureMatcher:
         return out[: n.value].copy()
 
 
-class Batch:
+class Batch(_Owner):
     """Device-resident frame batch: frames stay in HBM between the stages."""
 
     def __init__(self, detector, rows, cols, max_frames, max_candidates=0, max_keypoints=0):
         self.det = detector
         self.lib = detector.lib
         self.shape = BatchShape(rows, cols, max_frames, max_candidates, max_keypoints)
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_batch_create(detector.h, C.byref(self.shape), C.byref(self.h)))
+        self._hd = _Handle(self.lib.slamx_batch_destroy, detector._hd)
+        _check(self.lib.slamx_batch_create(detector.h, C.byref(self.shape), C.byref(self._hd.value)))
         self.rows, self.cols, self.max_frames = rows, cols, max_frames
-        detector._children.add(self)
-
-    def close(self):
-        if self.h:
-            self.lib.slamx_batch_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def frames_device(self):
         pitch, fstride = C.c_size_t(), C.c_size_t()
@@ -751,17 +753,14 @@ def unpack_results(buf):
 class _BorrowedBatch(Batch):
     """A level of a Pyramid: the handle belongs to the pyramid, so close() only forgets it."""
 
-    def __init__(self, detector, handle, rows, cols, max_frames):
+    def __init__(self, detector, handle, rows, cols, max_frames, owner):
         self.det = detector
         self.lib = detector.lib
-        self.h = C.c_void_p(handle)
+        self._hd = _Handle(None, owner, handle)  # forgotten (not destroyed) when the pyramid goes
         self.rows, self.cols, self.max_frames = rows, cols, max_frames
 
-    def close(self):
-        self.h = C.c_void_p()
 
-
-class Pyramid:
+class Pyramid(_Owner):
     """slamx_pyramid_* (include/slamx.h): n_levels batches, level l = cvRound(size / scale_factor ** l).
     Frames go into level(0) (upload), merged results come out of it (counts / download /
     match_consecutive / download_matches).  Build-side extension: the reference has no pyramid."""
@@ -770,29 +769,16 @@ class Pyramid:
         self.det = detector
         self.lib = detector.lib
         shape = BatchShape(rows, cols, max_frames, max_candidates, max_keypoints)
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_pyramid_create(detector.h, C.byref(shape), n_levels, float(scale_factor), C.byref(self.h)))
+        self._hd = _Handle(self.lib.slamx_pyramid_destroy, detector._hd)
+        _check(self.lib.slamx_pyramid_create(detector.h, C.byref(shape), n_levels, float(scale_factor), C.byref(self._hd.value)))
         self.n_levels, self.max_frames = n_levels, max_frames
         self._levels = []
         for l in range(n_levels):
             r, c, s = C.c_int(), C.c_int(), C.c_double()
             _check(self.lib.slamx_pyramid_level_shape(self.h, l, C.byref(r), C.byref(c), C.byref(s)))
-            self._levels.append(_BorrowedBatch(detector, self.lib.slamx_pyramid_batch(self.h, l), r.value, c.value, max_frames))
+            self._levels.append(_BorrowedBatch(detector, self.lib.slamx_pyramid_batch(self.h, l), r.value, c.value, max_frames,
+                                               self._hd))
         self.shapes = [(b.rows, b.cols) for b in self._levels]
-        detector._children.add(self)
-
-    def close(self):
-        if self.h:
-            for b in self._levels:
-                b.close()
-            self.lib.slamx_pyramid_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def level(self, l):
         return self._levels[l]
@@ -801,7 +787,53 @@ class Pyramid:
         _check(self.lib.slamx_pyramid_detect_and_compute(self.h, nframes))
 
 
-class GaussNewton:
+def mapgather_plan(counts):
+    """slamx_mapgather_plan: (padded per-rank capacity, total) for a list of per-rank point counts."""
+    c = np.ascontiguousarray(counts, np.int32)
+    cap, total = C.c_int(), C.c_int()
+    _check(load_library().slamx_mapgather_plan(_ptr(c), c.shape[0], C.byref(cap), C.byref(total)))
+    return cap.value, total.value
+
+
+def mapgather_unpack(padded, counts, cap_points=None):
+    """slamx_mapgather_unpack: [world][padded_cap][3] -> the ranks' points back to back."""
+    p = np.ascontiguousarray(padded, np.float64)
+    c = np.ascontiguousarray(counts, np.int32)
+    total = int(c.sum())
+    out = np.empty((total if cap_points is None else cap_points, 3))
+    _check(load_library().slamx_mapgather_unpack(_ptr(p), _ptr(c), c.shape[0], p.shape[1], _ptr(out), out.shape[0]))
+    return out[:total]
+
+
+class MapGather(_Owner):
+    """slamx_mapgather_* (include/slamx.h): the RCCL all-gather of map points a C++ multi-GPU host uses.  unique_id()
+    on rank 0, the 128 bytes handed to every rank, then MapGather(ctx, id, rank, world) on all of them."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        _check(load_library().slamx_mapgather_unique_id(_ptr(buf)))
+        return buf
+
+    def __init__(self, ctx, uid, rank, world):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.rank, self.world = rank, world
+        u = np.ascontiguousarray(uid, np.uint8)
+        self._hd = _Handle(self.lib.slamx_mapgather_destroy, ctx._hd)
+        _check(self.lib.slamx_mapgather_create(ctx.h, _ptr(u), rank, world, C.byref(self._hd.value)))
+
+    def allgather(self, xyz, cap_points=1 << 20):
+        p = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        counts = np.zeros(self.world, np.int32)
+        out = np.empty((cap_points, 3))
+        total = C.c_int()
+        _check(self.lib.slamx_mapgather_allgather(self.h, _ptr(p), p.shape[0], _ptr(counts), _ptr(out), cap_points,
+                                                  C.byref(total)))
+        return counts, out[: total.value].copy()
+
+
+class GaussNewton(_Owner):
     """A batch of sliding windows for slamx_gn_* (include/slamx.h): n_cams poses (world -> camera, R
     row-major + t), up to max_landmarks landmarks and a dense track table per window.  Build-defined
     (BASELINE.json configs[3]); the reference's backend is declaration-only."""
@@ -810,21 +842,9 @@ class GaussNewton:
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.n_windows, self.n_cams, self.max_landmarks = n_windows, n_cams, max_landmarks
-        self.h = C.c_void_p()
-        _check(self.lib.slamx_gn_create(self.ctx.h, n_windows, n_cams, max_landmarks, C.byref(self.h)))
+        self._hd = _Handle(self.lib.slamx_gn_destroy, self.ctx._hd)  # destroyed before the context (its stream is synchronised on destroy)
+        _check(self.lib.slamx_gn_create(self.ctx.h, n_windows, n_cams, max_landmarks, C.byref(self._hd.value)))
         self.iterations = -1
-        self.ctx._children.add(self)  # destroyed before the context (its stream is synchronised on destroy)
-
-    def close(self):
-        if self.h:
-            self.lib.slamx_gn_destroy(self.h)
-            self.h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def upload(self, poses, landmarks, obs, n_landmarks=None):
         W, L, n = self.n_cams, self.max_landmarks, self.n_windows

@@ -11,11 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
 
 #include "slamx_internal.h"
+#include <dlfcn.h>
 #include "yaml_lite.hpp"
 
 using namespace slamx;
@@ -440,6 +442,15 @@ extern "C" {
 const char* slamx_last_error(void) { return g_last_error.c_str(); }
 const char* slamx_version(void) { return "slamx 0.2 (gfx950)"; }
 int slamx_matcher_mfma_threshold(void) { return match_mfma_min_keypoints(); }
+
+int slamx_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
 
 int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
     if (out == nullptr) {
@@ -2554,6 +2565,209 @@ int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int 
         }
     }
     return SLAMX_OK;
+}
+
+
+// ---------------------------------------------------------------- map-point all-gather over RCCL
+int slamx_mapgather_plan(const int32_t* counts, int world, int* padded_cap, int* total) {
+    if (counts == nullptr || world < 1) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_plan: no counts");
+    }
+    long long sum = 0;
+    int cap = 1;  // an empty rank still sends one (zero) point: RCCL needs a non-empty, equal-sized send buffer
+    for (int r = 0; r < world; ++r) {
+        if (counts[r] < 0) {
+            return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_plan: negative count");
+        }
+        sum += counts[r];
+        cap = std::max(cap, static_cast<int>(counts[r]));
+    }
+    if (sum > 0x7fffffffLL) {
+        return fail(SLAMX_ERR_CAPACITY, "mapgather_plan: more than 2^31 points");
+    }
+    if (padded_cap != nullptr) {
+        *padded_cap = cap;
+    }
+    if (total != nullptr) {
+        *total = static_cast<int>(sum);
+    }
+    return SLAMX_OK;
+}
+
+int slamx_mapgather_unpack(const double* padded, const int32_t* counts, int world, int padded_cap, double* out,
+                           int cap_points) {
+    int cap = 0, total = 0;
+    SLAMX_TRY(slamx_mapgather_plan(counts, world, &cap, &total));
+    if (padded == nullptr || padded_cap < cap) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_unpack: padded payload smaller than the largest count");
+    }
+    if (total > cap_points || (out == nullptr && total > 0)) {
+        return fail(SLAMX_ERR_CAPACITY, "mapgather_unpack: output holds fewer points than were gathered");
+    }
+    size_t at = 0;
+    for (int r = 0; r < world; ++r) {
+        const size_t n = static_cast<size_t>(counts[r]) * 3;
+        if (n > 0) {
+            std::memcpy(out + at, padded + static_cast<size_t>(r) * padded_cap * 3, n * sizeof(double));
+        }
+        at += n;
+    }
+    return SLAMX_OK;
+}
+
+}  // extern "C" (C++ helpers of the gather follow)
+
+namespace {
+// librccl, bound on first use.  Signatures from /opt/rocm/include/rccl/rccl.h (ncclResult_t and the enums are ints;
+// ncclUniqueId is 128 opaque bytes passed BY VALUE; ncclInt32 = 2, ncclFloat64 = 8).
+struct RcclId {
+    char internal[SLAMX_MAPGATHER_ID_BYTES];
+};
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {std::getenv("SLAMX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (n != nullptr && *n != '\0' && (a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) {
+                break;
+            }
+        }
+        if (a.lib == nullptr) {
+            a.error = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set SLAMX_RCCL_LIBRARY";
+            return a;
+        }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) {
+            a.error = "librccl lacks an ncclGetUniqueId / CommInitRank / CommDestroy / AllGather / GetErrorString symbol";
+        }
+        return a;
+    }();
+    return api;
+}
+#define RCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        const int r_ = (expr);                                                                          \
+        if (r_ != 0) {                                                                                  \
+            return fail(SLAMX_ERR_RUNTIME, std::string(#expr) + ": " + rccl().GetErrorString(r_));      \
+        }                                                                                               \
+    } while (0)
+}  // namespace
+
+struct slamx_mapgather {
+    slamx_ctx* ctx = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    int32_t* d_counts = nullptr;  // [world + 1]: the gathered counts, then this rank's own
+    double* d_send = nullptr;     // [cap][3]
+    double* d_recv = nullptr;     // [world][cap][3]
+    int cap = 0;
+    std::vector<double> h_recv;
+};
+
+extern "C" {
+
+int slamx_mapgather_unique_id(uint8_t id[SLAMX_MAPGATHER_ID_BYTES]) {
+    if (id == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_unique_id: null");
+    }
+    if (!rccl().error.empty()) {
+        return fail(SLAMX_ERR_RUNTIME, rccl().error);
+    }
+    RcclId u{};
+    RCCL_TRY(rccl().GetUniqueId(&u));
+    std::memcpy(id, u.internal, SLAMX_MAPGATHER_ID_BYTES);
+    return SLAMX_OK;
+}
+
+int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_BYTES], int rank, int world,
+                           slamx_mapgather** out) {
+    if (ctx == nullptr || id == nullptr || out == nullptr || world < 1 || rank < 0 || rank >= world) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_create: bad context / id / rank / world");
+    }
+    if (!rccl().error.empty()) {
+        return fail(SLAMX_ERR_RUNTIME, rccl().error);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto g = std::make_unique<slamx_mapgather>();
+    g->ctx = ctx;
+    g->rank = rank;
+    g->world = world;
+    RcclId u{};
+    std::memcpy(u.internal, id, SLAMX_MAPGATHER_ID_BYTES);
+    RCCL_TRY(rccl().CommInitRank(&g->comm, world, u, rank));  // blocks until all `world` ranks have called it
+    SLAMX_TRY(dev_alloc(&g->d_counts, static_cast<size_t>(world) + 1));
+    *out = g.release();
+    return SLAMX_OK;
+}
+
+void slamx_mapgather_destroy(slamx_mapgather* g) {
+    if (g == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->comm != nullptr) {
+        (void)rccl().CommDestroy(g->comm);
+    }
+    dev_free(g->d_counts);
+    dev_free(g->d_send);
+    dev_free(g->d_recv);
+    delete g;
+}
+
+int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts, double* out,
+                              int cap_points, int* total) {
+    if (g == nullptr || n_points < 0 || (xyz == nullptr && n_points > 0) || counts == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_allgather: bad arguments");
+    }
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    constexpr int kInt32 = 2, kFloat64 = 8;  // ncclInt32, ncclFloat64
+    // 1. the counts
+    const int32_t mine = n_points;
+    HIP_TRY(hipMemcpyAsync(g->d_counts + g->world, &mine, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RCCL_TRY(rccl().AllGather(g->d_counts + g->world, g->d_counts, 1, kInt32, g->comm, s));
+    HIP_TRY(hipMemcpyAsync(counts, g->d_counts, sizeof(int32_t) * g->world, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int cap = 0, tot = 0;
+    SLAMX_TRY(slamx_mapgather_plan(counts, g->world, &cap, &tot));
+    if (total != nullptr) {
+        *total = tot;
+    }
+    // 2. the payload, padded to the largest count (every rank computes the same `cap` from the same counts)
+    if (cap > g->cap) {
+        dev_free(g->d_send);
+        dev_free(g->d_recv);
+        g->d_send = nullptr;
+        g->d_recv = nullptr;
+        const int grown = std::max(cap, 2 * g->cap);
+        SLAMX_TRY(dev_alloc(&g->d_send, static_cast<size_t>(grown) * 3));
+        SLAMX_TRY(dev_alloc(&g->d_recv, static_cast<size_t>(g->world) * grown * 3));
+        g->cap = grown;
+    }
+    HIP_TRY(hipMemsetAsync(g->d_send, 0, static_cast<size_t>(cap) * 3 * sizeof(double), s));
+    if (n_points > 0) {
+        HIP_TRY(hipMemcpyAsync(g->d_send, xyz, static_cast<size_t>(n_points) * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    RCCL_TRY(rccl().AllGather(g->d_send, g->d_recv, static_cast<size_t>(cap) * 3, kFloat64, g->comm, s));
+    g->h_recv.resize(static_cast<size_t>(g->world) * cap * 3);
+    HIP_TRY(hipMemcpyAsync(g->h_recv.data(), g->d_recv, g->h_recv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // 3. unpack (reports a too small `out` only now: no rank may leave before the collectives)
+    return slamx_mapgather_unpack(g->h_recv.data(), counts, g->world, cap, out, cap_points);
 }
 
 }  // extern "C"

@@ -342,3 +342,45 @@ def test_reference_typed_signatures_are_the_references():
     assert ("void addKeyframe(int keyframeId, const DescriptorMatrix& descriptors, const std::vector<Keypoint>& keypoints, "
             "const std::vector<Eigen::Vector3d>& mapPoints)") in lc
     assert "Eigen::Matrix4d relativeTransform = Eigen::Matrix4d::Identity();" in lc
+
+
+def test_mapgather_plan_and_unpack(slamx):
+    """Host-side bookkeeping of the RCCL map-point gather (slamx_mapgather_plan / _unpack): padded
+    capacity = largest count (at least 1), ranks back to back after unpacking, empty ranks, loud capacity errors."""
+    assert slamx.mapgather_plan([3, 0, 7, 7]) == (7, 17)
+    assert slamx.mapgather_plan([0, 0]) == (1, 0)
+    counts = [2, 0, 3]
+    padded = np.full((3, 3, 3), -1.0)
+    padded[0, :2] = np.arange(6).reshape(2, 3)
+    padded[2, :3] = 100 + np.arange(9).reshape(3, 3)
+    out = slamx.mapgather_unpack(padded, counts)
+    assert np.array_equal(out, np.concatenate([np.arange(6.0).reshape(2, 3), 100 + np.arange(9.0).reshape(3, 3)]))
+    with pytest.raises(slamx.CapacityError):
+        slamx.mapgather_unpack(padded, counts, cap_points=4)
+    with pytest.raises(ValueError):
+        slamx.mapgather_plan([1, -2])
+    with pytest.raises(ValueError):
+        slamx.mapgather_unpack(padded[:, :2], counts)  # padded capacity below the largest count
+
+
+def test_handle_cells_close_children_first_whoever_goes_first(slamx):
+    """The binding's _Handle cells: a child handle is destroyed before its parent's, once, whether the parent, the
+    child or the garbage collector closes first (a parent freed before its batch made the batch's destroy call run on
+    a dangling detector: the segfault at the end of a FAILED GPU test run, round 3)."""
+    log = []
+
+    def destroyer(name):
+        return lambda h: log.append(name)
+
+    ctx = slamx._Handle(destroyer("ctx"), None, 1)
+    det = slamx._Handle(destroyer("det"), ctx, 2)
+    b1 = slamx._Handle(destroyer("b1"), det, 3)
+    b2 = slamx._Handle(destroyer("b2"), det, 4)
+    lvl = slamx._Handle(None, b2, 5)  # borrowed: forgotten, never destroyed
+    b1.close()
+    assert log == ["b1"] and not b1.value and b1 not in det.children
+    ctx.close()  # the parent first: everything below it goes before it
+    assert log == ["b1", "b2", "det", "ctx"] and not lvl.value and not det.value
+    for h in (b2, det, ctx, lvl, b1):
+        h.close()  # late finalisers find nothing left to do
+    assert log == ["b1", "b2", "det", "ctx"]

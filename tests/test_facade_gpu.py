@@ -233,3 +233,38 @@ def test_reference_typed_call_sequences(ref_data):
     text = _run([os.path.join(BIN, "reference_call_sequence"), ref_data])
     assert "cv-typed == plain-typed: yes" in text and "Eigen-typed == plain-typed: yes" in text
     assert "in front" in text
+
+
+def test_cli_g1_gathers_its_map_points_over_rccl(ref_data):
+    """tools/cli -g 1: the multi-GPU driver (one host thread + context per GPU, frame chunks with a one-frame halo)
+    with a world of one: slamx_mapgather_unique_id / _create / _allgather run on the real librccl (ncclCommInitRank,
+    two ncclAllGather), everything but a second rank -- which needs a second GPU (the driver's 8-GPU node)."""
+    text = _run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images"), "-g", "1"])
+    plain = _run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images")])
+    frames = lambda t: [l for l in t.splitlines() if l.startswith("frame ") or l.strip().startswith("pose:")]
+    assert frames(text) == frames(plain)  # same results with and without the gather
+    line = [l for l in text.splitlines() if "map points gathered over RCCL" in l]
+    assert len(line) == 1 and "1 GPU, map points gathered over RCCL: 180 (per GPU: 180)" in line[0]
+
+
+def test_cli_refuses_more_gpus_than_there_are(ref_data):
+    p = subprocess.run([os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images"), "-g", "9"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"GPU(s) visible" in p.stderr
+
+
+def test_mapgather_world_of_one(slamx, gpu_ctx):
+    """slamx_mapgather_* through the C ABI on one rank: counts and payload come back unchanged, twice (the buffers are
+    reused and grow), an empty contribution, and a too small output is reported after the collectives."""
+    g = slamx.MapGather(gpu_ctx, slamx.MapGather.unique_id(), 0, 1)
+    pts = np.arange(21.0).reshape(7, 3)
+    counts, out = g.allgather(pts)
+    assert counts.tolist() == [7] and np.array_equal(out, pts)
+    big = np.random.default_rng(0).normal(size=(5000, 3))
+    counts, out = g.allgather(big)
+    assert counts.tolist() == [5000] and np.array_equal(out, big)
+    counts, out = g.allgather(np.zeros((0, 3)))
+    assert counts.tolist() == [0] and out.shape == (0, 3)
+    with pytest.raises(slamx.CapacityError):
+        g.allgather(big, cap_points=100)
+    g.close()
