@@ -310,6 +310,12 @@ constexpr unsigned long long MM_KEY_NONE = 0x7fffffffffffffffull;  // distance I
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// one wave's LDS accesses are issued in order; this only keeps the compiler from moving or caching them across it
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // desc (compact bits) -> train-form expanded descriptors, 64 bytes each; 4 lanes per keypoint
 // A frame is only expanded when a pair that takes the matrix-core scan uses it: as a train set of at least
 // min_train keypoints, or as the query frame of such a train set (its predecessor; first_train_frame for frame 0).
@@ -631,6 +637,529 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The matrix-core scan in SPATIAL order.
+//
+// What the scan above pays per QUERY is the convergence of its bound: `second` is an order statistic of the
+// penalised distances seen so far, and only trains within 500 px of the query enter it unpenalised (the jump
+// penalty multiplies the distance of everything farther away by 2..5), so in index order -- spatially random,
+// the keypoints are sorted by score -- a query's bound tightens as slowly as its NEAR neighbours turn up: ~48
+// filter passes per query at 10k keypoints, ~40 at 2k, every one of them a trip through the slow path (measured:
+// 54 % of the kernel's time at 10k keypoints, 73 % at 2k).  Both sets are therefore put into a spatial order first
+// (spatial_order_kernel: cells of ~64 keypoints, boustrophedon), a wave's 64 queries are neighbours, and the wave
+// visits the train set in STAGES of 64 neighbours, nearest stage first: the true match and the look-alikes that
+// set `second` come in the first few stages, and the far stages are scanned with the final bound (simulated on the
+// bench frames: 12-17 passes per query instead of 40-48).
+// Exactness does not depend on the order: the two keys (distance << 32 | ORIGINAL train index) end as the two
+// lexicographically smallest of all pairs whatever the order of the updates (see above) -- but the tile filter's
+// strict '<' relied on ascending indices.  In any order a pair of distance d may be dropped iff d > second, or
+// d == second > best (it could only replace the second key by an equal distance); a pair with d == second == best
+// may carry the lower index and passes.  The bound fed to the MFMA is therefore second + [best == second], read
+// stale (stale values only make it larger: a superset passes).
+// No LDS stage and no barrier: a wave reads its A operands straight from global memory (a tile = 16 consecutive
+// expanded descriptors = 1 KB, one dwordx4 per lane, the next stage's four tiles in flight while the current
+// stage's 16 MFMAs run); the expanded train set of a frame (0.7 MB at 10k keypoints) is L2-resident.
+#ifdef SLAMX_MATCH_STATS  // development build only (make FLAGS_match=-DSLAMX_MATCH_STATS): slow-path volume of the spatial scan
+__device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued, pairs that reached the keys, stages
+#define SP_STAT(i, v) sp_stat_##i += (v)
+#else
+#define SP_STAT(i, v) ((void)0)
+#endif
+constexpr int SP_STAGE = 64;          // trains per stage (4 tiles of 16)
+constexpr int SP_MAX_STAGES = 1025;   // maxK <= 65536
+constexpr int SP_BUCKETS = 128;       // stage order: counting sort on the centre distance in 32-px steps
+
+__device__ __forceinline__ int clamp_coord(float v) {  // NaN -> -2^20; only ever used for ORDERING, never for results
+    return static_cast<int>(fminf(fmaxf(v, -1048576.0f), 1048576.0f));
+}
+
+// One workgroup per frame: keypoints -> spatial order.  Writes, for sorted position p of frame f:
+//   xdesc [f][p][64] train-form expanded descriptor, sbits[f][p] compact bits, sxyi[f][p] {x, y, original index, 0},
+//   scent[f][p / 64] stage centres; positions [n, roundup(n, 64)) get a descriptor no bound lets through.
+// Without keypoints (no penalty, no coordinates) the order is the identity.
+__global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int first_frame, int first_train_frame, int min_train) {
+    __shared__ int hist[4096];
+    __shared__ int bbox[4];
+    __shared__ int wave_tot[16];
+    __shared__ int stage_sum[SP_MAX_STAGES][2];
+    const int f = first_frame + blockIdx.x;
+    const int n = mv.n_kp[f];
+    const int pred = f > 0 ? f - 1 : first_train_frame;
+    if (n < min_train && (pred < 0 || mv.n_kp[pred] < min_train)) {
+        return;  // neither a large train set nor the query frame of one (uniform)
+    }
+    const int tid = threadIdx.x;
+    const int stride = mv.width / 4;
+    const bool use_kp = mv.kps != nullptr;
+    const slamx_keypoint* kps = use_kp ? mv.kps + static_cast<size_t>(f) * mv.maxK : nullptr;
+    uint8_t* xd = mv.xdesc + static_cast<size_t>(f) * mv.maxKp * 64;
+    uint2* sb = mv.sbits + static_cast<size_t>(f) * mv.maxKp;
+    float4* sx = mv.sxyi + static_cast<size_t>(f) * mv.maxKp;
+    float2* sc = mv.scent + static_cast<size_t>(f) * (mv.maxKp / 64);
+    const int nst = (n + SP_STAGE - 1) / SP_STAGE;
+    for (int i = tid; i < 4096; i += 1024) {
+        hist[i] = 0;
+    }
+    for (int i = tid; i < nst; i += 1024) {
+        stage_sum[i][0] = 0;
+        stage_sum[i][1] = 0;
+    }
+    if (tid < 4) {
+        bbox[tid] = tid < 2 ? 0x7fffffff : -0x7fffffff;
+    }
+    __syncthreads();
+    int side = 1, ncx = 1, ncy = 1, x0 = 0, y0 = 0;
+    if (use_kp) {
+        int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff, hy = -0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            const int x = clamp_coord(kps[i].x), y = clamp_coord(kps[i].y);
+            lx = min(lx, x);
+            ly = min(ly, y);
+            hx = max(hx, x);
+            hy = max(hy, y);
+        }
+        atomicMin(&bbox[0], lx);
+        atomicMin(&bbox[1], ly);
+        atomicMax(&bbox[2], hx);
+        atomicMax(&bbox[3], hy);
+        __syncthreads();
+        x0 = bbox[0];
+        y0 = bbox[1];
+        const float w = static_cast<float>(bbox[2] - x0 + 1), h = static_cast<float>(bbox[3] - y0 + 1);
+        // cells of about one stage's worth of keypoints, at most 64 x 64 of them
+        side = max(1, static_cast<int>(sqrtf(w * h * static_cast<float>(SP_STAGE) / static_cast<float>(max(n, 1)))));
+        side = max(side, max(static_cast<int>(w) / 64 + 1, static_cast<int>(h) / 64 + 1));
+        ncx = min(64, static_cast<int>(w) / side + 1);
+        ncy = min(64, static_cast<int>(h) / side + 1);
+    }
+    auto cell_of = [&](int i) {
+        if (!use_kp) {
+            return 0;
+        }
+        const int cx = min(ncx - 1, (clamp_coord(kps[i].x) - x0) / side);
+        const int cy = min(ncy - 1, (clamp_coord(kps[i].y) - y0) / side);
+        return cy * ncx + ((cy & 1) != 0 ? ncx - 1 - cx : cx);  // boustrophedon: consecutive cells are neighbours
+    };
+    if (use_kp) {
+        for (int i = tid; i < n; i += 1024) {
+            atomicAdd(&hist[cell_of(i)], 1);
+        }
+        __syncthreads();
+        // exclusive prefix over the 4096 cells: 4 per thread, wave scan, wave totals
+        const int lane = tid & 63, wave = tid >> 6;
+        int v[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = hist[4 * tid + k];
+            s += v[k];
+        }
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) {
+                inc += o;
+            }
+        }
+        if (lane == 63) {
+            wave_tot[wave] = inc;
+        }
+        __syncthreads();
+        int base = inc - s;
+        for (int w2 = 0; w2 < wave; ++w2) {
+            base += wave_tot[w2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hist[4 * tid + k] = base;
+            base += v[k];
+        }
+        __syncthreads();
+    }
+    const uint32_t* rows = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(f) * mv.maxK * mv.width);
+    for (int i = tid; i < n; i += 1024) {
+        const int p = use_kp ? atomicAdd(&hist[cell_of(i)], 1) : i;  // (the order inside a cell is immaterial)
+        const uint32_t w0 = rows[static_cast<size_t>(i) * stride];
+        const uint32_t w1 = stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u;
+        const unsigned long long bits = static_cast<unsigned long long>(w0) | (static_cast<unsigned long long>(w1) << 32);
+        float x = 0.0f, y = 0.0f;
+        if (use_kp) {
+            x = kps[i].x;
+            y = kps[i].y;
+            atomicAdd(&stage_sum[p >> 6][0], clamp_coord(x));
+            atomicAdd(&stage_sum[p >> 6][1], clamp_coord(y));
+        }
+        sb[p] = make_uint2(w0, w1);
+        sx[p] = make_float4(x, y, __int_as_float(i), 0.0f);
+        uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
+#pragma unroll
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            const uint32_t b16 = static_cast<uint32_t>(bits >> (16 * quarter)) & 0xffffu;
+            uint4 e;
+            // four bits -> four bytes: the shifted copies of the nibble (by 0, 7, 14, 21) do not overlap
+            e.x = ((b16 & 0xfu) * 0x00204081u) & 0x01010101u;
+            e.y = (((b16 >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+            e.z = (((b16 >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+            e.w = (((b16 >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+            if (quarter == 3) {  // bits 62, 63 are never set (MM_MAX_BITS): bytes 62, 63 carry |t| and 1
+                e.w = (e.w & 0x0000ffffu) | (static_cast<uint32_t>(__popcll(bits)) << 16) | 0x01000000u;
+            }
+            o[quarter] = e;
+        }
+    }
+    // padding up to a whole stage: distance 127 + |q|, which no bound below 127 lets through (and the slow path
+    // checks the index anyway)
+    for (int p = n + tid; p < nst * SP_STAGE; p += 1024) {
+        uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
+        o[0] = o[1] = o[2] = make_uint4(0u, 0u, 0u, 0u);
+        o[3] = make_uint4(0u, 0u, 0u, 0x017f0000u);
+        sb[p] = make_uint2(0u, 0u);
+        sx[p] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+    }
+    __syncthreads();
+    for (int s2 = tid; s2 < nst; s2 += 1024) {
+        const float cnt = static_cast<float>(min(SP_STAGE, n - s2 * SP_STAGE));
+        sc[s2] = make_float2(static_cast<float>(stage_sum[s2][0]) / cnt, static_cast<float>(stage_sum[s2][1]) / cnt);
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void match_spatial_kernel(MatchView mv,
+                                                                                                     int first_query_frame,
+                                                                                                     int first_train_frame,
+                                                                                                     int npairs, int qblocks) {
+    constexpr int QW = 16 * MM_QT;                         // queries per wave
+    // ONE wave per workgroup: the waves share nothing, and a workgroup of four would hold its slot until the slowest
+    // of them is done (measured: 25 % fewer wave-cycles than the staged scan, but no less time, at four per workgroup)
+    __shared__ uint4 qtab[1][QW];                          // per query: compact bits (x, y), position (z, w as float bits)
+    __shared__ unsigned long long keys[1][QW][2];          // per query: best_key, second_key
+    __shared__ uint32_t fifo[1][MM_FIFO + 64];             // lane | first (sorted) train index of the tile << 6
+    __shared__ uint32_t pairq[1][MM_PAIRS + 64];           // query | raw distance << 8 | sorted train index << 16
+    __shared__ uint16_t order[1][SP_MAX_STAGES + 3];       // the stages, nearest first
+    __shared__ int bucket[1][SP_BUCKETS];
+    int pair, qblock, split;
+    {
+        const int id = static_cast<int>(blockIdx.x);
+        const int per_pair = qblocks * mv.nsplit;
+        if (npairs >= 8) {  // an XCD takes its pairs one after the other: a pair's sorted tables stay in its L2
+            const int k = id >> 3;
+            pair = (id & 7) + 8 * (k / per_pair);
+            const int in_pair = k - (k / per_pair) * per_pair;
+            qblock = in_pair % qblocks;
+            split = in_pair / qblocks;
+            if (pair >= npairs) {
+                return;
+            }
+        } else {
+            pair = id % npairs;
+            const int rest = id / npairs;
+            qblock = rest % qblocks;
+            split = rest / qblocks;
+        }
+    }
+    const int qf = first_query_frame + pair;
+    const int tf = qf == 0 ? first_train_frame : qf - 1;
+    const int n1 = mv.n_kp[qf];
+    const int n2 = mv.n_kp[tf];
+    const int lane = threadIdx.x;
+    constexpr int wave = 0;
+    const int wave_first = qblock * QW;  // sorted position of the wave's first query
+    if (wave_first >= n1 || n2 < mv.mfma_min_train) {
+        return;  // no queries for this wave, or a pair of match_kernel's (no barrier anywhere below: waves are independent)
+    }
+    const bool use_kp = mv.kps != nullptr;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    const uint8_t* xq = mv.xdesc + static_cast<size_t>(qf) * mv.maxKp * 64;
+    const uint8_t* xtr = mv.xdesc + static_cast<size_t>(tf) * mv.maxKp * 64;
+    const uint2* qbits = mv.sbits + static_cast<size_t>(qf) * mv.maxKp;
+    const uint2* tbits = mv.sbits + static_cast<size_t>(tf) * mv.maxKp;
+    const float4* qxyi = mv.sxyi + static_cast<size_t>(qf) * mv.maxKp;
+    const float4* txyi = mv.sxyi + static_cast<size_t>(tf) * mv.maxKp;
+    // ---- the wave's queries
+    int qorig = -1;
+    float qx = 0.0f, qy = 0.0f;
+    {
+        const int i = wave_first + lane;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n1) {
+            const uint2 b = qbits[i];
+            const float4 r = qxyi[i];
+            q = make_uint4(b.x, b.y, __float_as_uint(r.x), __float_as_uint(r.y));
+            qorig = __float_as_int(r.z);
+            qx = r.x;
+            qy = r.y;
+        }
+        qtab[wave][lane] = q;
+        keys[wave][lane][0] = MM_KEY_NONE;
+        keys[wave][lane][1] = MM_KEY_NONE;
+    }
+    constexpr int NEVER = 0x3fffffff;  // accumulator input of an absent query: distance + NEVER is never negative
+    v4i B[MM_QT];
+    v4i C[MM_QT];  // -bound of the lane's query of each tile, in all four rows
+#pragma unroll
+    for (int u = 0; u < MM_QT; ++u) {
+        const int i = wave_first + u * 16 + c;
+        const bool ok = i < n1;
+        B[u] = v4i{0, 0, 0, 0};
+        const int nb = ok ? -0x7fffffff : NEVER;
+        C[u] = v4i{nb, nb, nb, nb};
+        if (ok) {
+            const uint4 t = *reinterpret_cast<const uint4*>(xq + static_cast<size_t>(i) * 64 + 16 * g);
+            // train form -> query form: bits * -2 (= * 254 per byte, no carries), and |q| / 1 swapped
+            uint32_t w3 = t.w * 254u;
+            if (g == 3) {
+                w3 = ((t.w & 0x0101u) * 254u) | 0x00010000u | ((t.w >> 16 & 0xffu) << 24);
+            }
+            B[u] = v4i{static_cast<int>(t.x * 254u), static_cast<int>(t.y * 254u), static_cast<int>(t.z * 254u),
+                       static_cast<int>(w3)};
+        }
+    }
+    // ---- the order of the stages: nearest centre first (a counting sort on the distance in 32-px steps)
+    const int nst = (n2 + SP_STAGE - 1) / SP_STAGE;
+    uint16_t* const myorder = order[wave];
+    if (use_kp) {
+        int* const mybucket = bucket[wave];
+        // centre of the wave's queries
+        int sxq = qorig >= 0 ? clamp_coord(qx) : 0, syq = qorig >= 0 ? clamp_coord(qy) : 0, cnt = qorig >= 0 ? 1 : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            sxq += __shfl_xor(sxq, d);
+            syq += __shfl_xor(syq, d);
+            cnt += __shfl_xor(cnt, d);
+        }
+        const float cxq = static_cast<float>(sxq) / static_cast<float>(cnt), cyq = static_cast<float>(syq) / static_cast<float>(cnt);
+        const float2* cent = mv.scent + static_cast<size_t>(tf) * (mv.maxKp / 64);
+        for (int b = lane; b < SP_BUCKETS; b += 64) {
+            mybucket[b] = 0;
+        }
+        wave_lds_fence();
+        auto bucket_of = [&](int s) {
+            const float2 ctr = cent[s];
+            const float dx = ctr.x - cxq, dy = ctr.y - cyq;
+            return min(SP_BUCKETS - 1, static_cast<int>(__builtin_amdgcn_sqrtf(dx * dx + dy * dy)) >> 5);
+        };
+        for (int s = lane; s < nst; s += 64) {
+            atomicAdd(&mybucket[bucket_of(s)], 1);
+        }
+        wave_lds_fence();
+        {  // exclusive prefix over 128 buckets: two per lane
+            const int a = mybucket[2 * lane], b = mybucket[2 * lane + 1];
+            int inc = a + b;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d);
+                if (lane >= d) {
+                    inc += o;
+                }
+            }
+            wave_lds_fence();
+            mybucket[2 * lane] = inc - a - b;
+            mybucket[2 * lane + 1] = inc - b;
+        }
+        wave_lds_fence();
+        for (int s = lane; s < nst; s += 64) {
+            myorder[atomicAdd(&mybucket[bucket_of(s)], 1)] = static_cast<uint16_t>(s);
+        }
+    } else {
+        for (int s = lane; s < nst; s += 64) {
+            myorder[s] = static_cast<uint16_t>(s);
+        }
+    }
+    wave_lds_fence();
+    uint32_t* const myfifo = fifo[wave];
+    uint32_t* const mypairs = pairq[wave];
+    int tail = 0;   // tile entries waiting (wave-uniform, kept in an SGPR)
+    int ptail = 0;  // pair entries waiting
+#ifdef SLAMX_MATCH_STATS
+    unsigned long long sp_stat_1 = 0, sp_stat_2 = 0, sp_stat_3 = 0;
+#endif
+    // level 2: `count` (<= 64) pairs from the head of the pair list, one per lane: the reference's penalty
+    // arithmetic (feature_matcher.cpp:161-170) and the update of the query's two keys
+    auto settle = [&](int count) {
+        if (lane < count) {
+            const uint32_t e = mypairs[lane];
+            const int q = static_cast<int>(e & 0xffu);
+            int dist = static_cast<int>(e >> 8 & 0xffu);
+            const int t = static_cast<int>(e >> 16);
+            unsigned long long* key = keys[wave][q];
+            const int sec = static_cast<int>(key[1] >> 32);  // may have shrunk since the pair was queued
+            if (dist <= sec) {
+                const float4 tr = txyi[t];  // x, y, original index of the train keypoint
+                if (use_kp) {
+                    const uint4 qv = qtab[wave][q];
+                    dist = penalised_distance(dist, __uint_as_float(qv.z), __uint_as_float(qv.w), tr.x, tr.y);
+                }
+                SP_STAT(3, __popcll(__ballot(dist <= sec)));
+                if (dist <= sec) {
+                    const unsigned long long k = (static_cast<unsigned long long>(static_cast<uint32_t>(dist)) << 32) |
+                                                 static_cast<uint32_t>(__float_as_int(tr.z));
+                    const unsigned long long old = atomicMin(&key[0], k);
+                    atomicMin(&key[1], old > k ? old : k);
+                }
+            }
+        }
+        // move what is left to the front (reads of a step before its writes: one wave, LDS in program order)
+        for (int base = count; base < ptail; base += 64) {
+            const uint32_t v = mypairs[base + lane];
+            if (base + lane < ptail) {
+                mypairs[base - count + lane] = v;
+            }
+        }
+        ptail -= count;
+    };
+    // level 1: `count` (<= 64) entries from the head of the tile list, one per lane: entry = (lane L, tile) stands
+    // for the 16 pairs {query u * 16 + (L & 15)} x {train tile + 4 (L >> 4) + r}; their distances are recomputed
+    // with xor + popcount and the ones that still reach the query's keys go to the pair list
+    auto work = [&](int count) {
+        SP_STAT(1, count);
+        const bool valid = lane < count;
+        const uint32_t e = myfifo[lane];
+        {
+            const uint32_t v = myfifo[count + lane];  // at most 63 entries remain: moved to the front
+            if (count + lane < tail) {
+                myfifo[lane] = v;
+            }
+        }
+        tail -= count;
+        const int ec = static_cast<int>(e & 15u);
+        const int trow = valid ? static_cast<int>(e >> 6) + 4 * static_cast<int>(e >> 4 & 3u) : 0;
+        // everything the four query tiles need is requested before anything is used
+        uint2 tb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tb[r] = tbits[trow + r];  // (padding positions exist up to a whole stage: no range check on the address)
+        }
+        uint2 qb[MM_QT];
+        int limit[MM_QT];
+#pragma unroll
+        for (int u = 0; u < MM_QT; ++u) {
+            const int q = u * 16 + ec;
+            qb[u] = *reinterpret_cast<const uint2*>(&qtab[wave][q]);
+            const int bestd = static_cast<int>(keys[wave][q][0] >> 32);
+            const int sec = static_cast<int>(keys[wave][q][1] >> 32);
+            // A pair that merely TIES with `second` changes an output only if it also ties with `best` (it may have
+            // the lower index); with best < second it could at most replace the second key by an equal distance.
+            limit[u] = valid ? (bestd == sec ? sec : sec - 1) : -1;  // lanes without an entry queue nothing
+        }
+#pragma unroll
+        for (int u = 0; u < MM_QT; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = trow + r;
+                const int dist = __popc(qb[u].x ^ tb[r].x) + __popc(qb[u].y ^ tb[r].y);
+                const bool pass = dist <= limit[u] && t < n2;
+                const unsigned long long pm = __ballot(pass);
+                if (pm != 0) {  // wave-uniform
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+                    const uint32_t slot = pass ? static_cast<uint32_t>(ptail) + rank : static_cast<uint32_t>(MM_PAIRS);
+                    mypairs[slot] = static_cast<uint32_t>(u * 16 + ec) | (static_cast<uint32_t>(dist) << 8) |
+                                    (static_cast<uint32_t>(t) << 16);
+                    ptail += __popcll(pm);
+                    SP_STAT(2, __popcll(pm));
+                }
+            }
+            // after every query tile: a tile adds at most 4 x 64 pairs to the < 64 that wait (MM_PAIRS)
+#pragma unroll 1
+            while (ptail >= 64) {
+                settle(64);
+            }
+        }
+    };
+    auto refresh_bounds = [&]() {
+#pragma unroll
+        for (int u = 0; u < MM_QT; ++u) {
+            const int bestd = static_cast<int>(keys[wave][u * 16 + c][0] >> 32);
+            const int sec = static_cast<int>(keys[wave][u * 16 + c][1] >> 32);
+            // second + [best == second]: see the header (sec = INT_MAX while fewer than two pairs were seen: -INT_MAX)
+            const int nb = C[u][0] == NEVER ? NEVER : -(sec + ((bestd == sec && sec != 0x7fffffff) ? 1 : 0));
+            C[u] = v4i{nb, nb, nb, nb};
+        }
+    };
+    // this workgroup's share of the stages: every nsplit-th of the ordered list (merged by emit_kernel)
+    const int nmine = (nst - split + mv.nsplit - 1) / mv.nsplit;
+    auto stage_at = [&](int k) {  // k-th stage of this workgroup's share (wave-uniform)
+        return static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(myorder[min(split + k * mv.nsplit, nst - 1)])));
+    };
+    auto fetch = [&](int s, v4i* A) {
+        const uint8_t* base = xtr + (static_cast<size_t>(s) * SP_STAGE + c) * 64 + 16 * g;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            A[tl] = *reinterpret_cast<const v4i*>(base + tl * 16 * 64);
+        }
+    };
+    auto scan_stage = [&](int s, const v4i* A) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            v4i D[MM_QT];
+#pragma unroll
+            for (int u = 0; u < MM_QT; ++u) {
+                D[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tl], B[u], C[u], 0, 0, 0);
+            }
+            int any = 0;
+#pragma unroll
+            for (int u = 0; u < MM_QT; ++u) {
+                any |= D[u][0] | D[u][1] | D[u][2] | D[u][3];
+            }
+            const bool pass = any < 0;  // some pair is below its (stale) bound
+            const unsigned long long pm = __ballot(pass);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+            lds_u32* const wr = (lds_u32*)myfifo + tail;
+            lds_u32* const dst = pass ? wr + rank : (lds_u32*)myfifo + MM_TRASH;
+            *dst = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(s * SP_STAGE + tl * 16) << 6);
+            tail += __popcll(pm);
+            if (tail >= 64) {  // wave-uniform
+                do {
+                    work(64);
+                } while (tail >= 64);
+                refresh_bounds();
+            }
+        }
+    };
+    v4i A0[4], A1[4];
+    if (nmine > 0) {
+        fetch(stage_at(0), A0);
+    }
+    for (int k = 0; k < nmine; k += 2) {
+        const int s0 = stage_at(k);
+        const int s1 = stage_at(k + 1);
+        if (k + 1 < nmine) {
+            fetch(s1, A1);
+        }
+        scan_stage(s0, A0);
+        if (k + 1 < nmine) {
+            if (k + 2 < nmine) {
+                fetch(stage_at(k + 2), A0);
+            }
+            scan_stage(s1, A1);
+        }
+    }
+    while (tail > 0) {  // end of the scan: what is still waiting
+        work(min(64, tail));
+    }
+    while (ptail > 0) {
+        settle(min(64, ptail));
+    }
+    wave_lds_fence();
+#ifdef SLAMX_MATCH_STATS
+    if (lane == 0) {
+        atomicAdd(&sp_stats[0], 1ull);
+        atomicAdd(&sp_stats[1], sp_stat_1);
+        atomicAdd(&sp_stats[2], sp_stat_2);
+        atomicAdd(&sp_stats[3], sp_stat_3);
+        atomicAdd(&sp_stats[4], static_cast<unsigned long long>(nmine));
+    }
+#endif
+    if (qorig >= 0) {
+        const unsigned long long kb = keys[wave][lane][0], ks = keys[wave][lane][1];
+        const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + split) * mv.maxK + qorig;
+        mv.best[slot] = make_int2(static_cast<int>(kb >> 32), static_cast<int>(static_cast<uint32_t>(kb)));
+        mv.second[slot] = static_cast<int>(ks >> 32);
+    }
+}
+
 // Any descriptor width (bytes): byte-wise popcount straight from global memory.  Correctness
 // path for widths that are not 8/16/32/64 bytes.
 __global__ __launch_bounds__(256) void match_generic_kernel(MatchView mv, int first_query_frame, int first_train_frame) {
@@ -694,8 +1223,10 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
             bool good = false;
             int2 b = make_int2(0, -1);
             if (i < n1) {
-                // merge the per-chunk (best, idx, second) in ascending train order through the
-                // same update rule: the two smallest of the union, lowest index on ties
+                // merge the per-chunk summaries (best, idx, second) of disjoint parts of the train set: the best is the
+                // lexicographically smallest (distance, train index) -- the reference's strict '<' in an ascending
+                // scan (feature_matcher.cpp:132-141) -- and second = min(the losing best, both seconds).  Chunks of the
+                // popcount scan are ascending index ranges; the spatial scan's are interleaved, hence the index.
                 int best = 0x7fffffff;
                 int second = 0x7fffffff;
                 int best_idx = -1;
@@ -703,16 +1234,14 @@ __global__ __launch_bounds__(1024) void emit_kernel(MatchView mv, int first_quer
                     const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + c) * mv.maxK + i;
                     const int2 pb = mv.best[slot];
                     const int ps = mv.second[slot];
-                    if (pb.x < best) {
-                        second = best;
+                    if (pb.x < best || (pb.x == best && static_cast<uint32_t>(pb.y) < static_cast<uint32_t>(best_idx))) {
+                        second = min(second, best);
                         best = pb.x;
                         best_idx = pb.y;
-                    } else if (pb.x < second) {
-                        second = pb.x;
+                    } else {
+                        second = min(second, pb.x);
                     }
-                    if (ps < second) {
-                        second = ps;
-                    }
+                    second = min(second, ps);
                 }
                 b = make_int2(best, best_idx);
                 good = true;
@@ -764,6 +1293,15 @@ void launch_words(const MatchView& mv, int first_query_frame, int npairs, int fi
 
 }  // namespace
 
+#ifdef SLAMX_MATCH_STATS
+extern "C" void slamx_debug_match_stats(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_stats), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sp_stats), z, sizeof(z));
+}
+#endif
+
 void launch_match_consecutive(const MatchView& mv_in, int first_query_frame, int npairs, int first_train_frame,
                               hipStream_t stream, hipEvent_t ev_mid) {
     if (npairs <= 0) {
@@ -777,25 +1315,44 @@ void launch_match_consecutive(const MatchView& mv_in, int first_query_frame, int
         mv.xdesc = nullptr;  // match_kernel then takes every pair
     }
     if (mfma) {
-        // Expanded descriptors of every frame that is a query or a train set of this call, then the matrix-core scan
-        // of the pairs with large train sets; the popcount scan below takes the other pairs (the keypoint counts
-        // are only known on the device: both kernels are launched and each leaves the other's pairs alone).
+        // The matrix-core scan of the pairs with large train sets; the popcount scan below takes the other pairs (the
+        // keypoint counts are only known on the device: both kernels are launched and each leaves the other's pairs
+        // alone).  First every frame that is a query or a train set of this call is put into spatial order and
+        // expanded (spatial_order_kernel), then the scan.  SLAMX_MATCH_SPATIAL=0 (experiments): the index-order scan.
+        static const bool spatial = [] {
+            const char* e = getenv("SLAMX_MATCH_SPATIAL");
+            return e == nullptr || atoi(e) != 0;
+        }();
         const int qblocks = (mv.maxK + 64 * MM_QT - 1) / (64 * MM_QT);
         // frames in use: the queries, their predecessors, and first_train_frame when frame 0 is a query
         const int lo_frame = first_query_frame > 0 ? first_query_frame - 1 : 0;
         const int hi_frame = first_query_frame + npairs - 1;
-        dim3 gx(grid_x(mv.maxK * 4, 256, hi_frame - lo_frame + 1), hi_frame - lo_frame + 1);
-        hipLaunchKernelGGL(xdesc_kernel, gx, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc, lo_frame,
-                           first_train_frame, mv.mfma_min_train);
-        if (first_query_frame == 0 && first_train_frame >= 0 && (first_train_frame < lo_frame || first_train_frame > hi_frame)) {
-            dim3 g1(grid_x(mv.maxK * 4, 256, 1), 1);
-            hipLaunchKernelGGL(xdesc_kernel, g1, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc,
-                               first_train_frame, first_train_frame, mv.mfma_min_train);
-        }
+        const bool extra = first_query_frame == 0 && first_train_frame >= 0 && (first_train_frame < lo_frame || first_train_frame > hi_frame);
         const int pair_slots = npairs >= 8 ? 8 * ((npairs + 7) / 8) : npairs;
         dim3 grid(static_cast<unsigned>(qblocks) * pair_slots * mv.nsplit);
-        hipLaunchKernelGGL(match_mfma_kernel, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame, stride,
-                           npairs, qblocks);
+        if (spatial) {
+            hipLaunchKernelGGL(spatial_order_kernel, dim3(hi_frame - lo_frame + 1), dim3(1024), 0, stream, mv, lo_frame,
+                               first_train_frame, mv.mfma_min_train);
+            if (extra) {
+                hipLaunchKernelGGL(spatial_order_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, first_train_frame,
+                                   mv.mfma_min_train);
+            }
+            const int wblocks = (mv.maxK + 16 * MM_QT - 1) / (16 * MM_QT);  // one wave of 64 queries per workgroup
+            dim3 wgrid(static_cast<unsigned>(wblocks) * pair_slots * mv.nsplit);
+            hipLaunchKernelGGL(match_spatial_kernel, wgrid, dim3(64), 0, stream, mv, first_query_frame, first_train_frame, npairs,
+                               wblocks);
+        } else {
+            dim3 gx(grid_x(mv.maxK * 4, 256, hi_frame - lo_frame + 1), hi_frame - lo_frame + 1);
+            hipLaunchKernelGGL(xdesc_kernel, gx, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc, lo_frame,
+                               first_train_frame, mv.mfma_min_train);
+            if (extra) {
+                dim3 g1(grid_x(mv.maxK * 4, 256, 1), 1);
+                hipLaunchKernelGGL(xdesc_kernel, g1, dim3(256), 0, stream, mv.desc, mv.n_kp, mv.maxK, mv.width, mv.xdesc,
+                                   first_train_frame, first_train_frame, mv.mfma_min_train);
+            }
+            hipLaunchKernelGGL(match_mfma_kernel, grid, dim3(256), 0, stream, mv, first_query_frame, first_train_frame, stride,
+                               npairs, qblocks);
+        }
     }
     if (mv.width % 4 == 0 && stride <= 16) {
         int live = mv.live_words > 0 && mv.live_words < stride ? mv.live_words : stride;

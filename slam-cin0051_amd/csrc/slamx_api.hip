@@ -966,7 +966,7 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     // size of its train set (MatchView::mfma_min_train).
     const bool use_mfma = pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints();
     if (use_mfma && b->xdesc == nullptr) {
-        SLAMX_TRY(dev_alloc(&b->xdesc, F * b->v.maxK * 64));
+        SLAMX_TRY(dev_alloc(&b->xdesc, match_scratch_bytes(F, b->v.maxK)));
     }
     MatchView mv{};
     mv.desc = b->v.desc;
@@ -981,7 +981,7 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     // descriptors of a batch come from describe_kernel: bits >= pattern_len are never set
     mv.live_words = std::max(1, (pattern_len + 31) / 32);
     mv.live_bits = std::max(1, pattern_len);
-    mv.xdesc = use_mfma ? b->xdesc : nullptr;
+    match_scratch_carve(use_mfma ? b->xdesc : nullptr, F, b->v.maxK, &mv);
     mv.mfma_min_train = match_mfma_min_keypoints();
     // (the matrix-core path takes 256 queries per workgroup, the popcount path 512)
     mv.nsplit = match_split_for(nframes, b->v.maxK);  // one split for both scans: they share the per-chunk result slots
@@ -1581,7 +1581,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
         SLAMX_TRY(dev_alloc(&m->n_matches, 2));
         SLAMX_TRY(dev_alloc(&m->best, 2 * MATCH_MAX_SPLIT * c));
         SLAMX_TRY(dev_alloc(&m->second, 2 * MATCH_MAX_SPLIT * c));
-        SLAMX_TRY(dev_alloc(&m->xdesc, 2 * c * 64));
+        SLAMX_TRY(dev_alloc(&m->xdesc, match_scratch_bytes(2, need)));
         m->cap = need;
         m->width = width1;
     }
@@ -1649,7 +1649,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
             }
             mv.live_bits = std::max(1, 32 * (live - 1) + hb);
             if (n2 >= match_mfma_min_keypoints()) {  // see slamx_batch_match_consecutive
-                mv.xdesc = m->xdesc;
+                match_scratch_carve(m->xdesc, 2, m->cap, &mv);
                 mv.mfma_min_train = 0;  // n2 is known here: the one pair takes the matrix-core scan
                 mv.nsplit = match_split_for(1, m->cap * 2);
             }
