@@ -648,14 +648,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 // 54 % of the kernel's time at 10k keypoints, 73 % at 2k).  Both sets are therefore put into a spatial order first
 // (spatial_order_kernel: cells of ~64 keypoints, boustrophedon), a wave's 64 queries are neighbours, and the wave
 // visits the train set in STAGES of 64 neighbours, nearest stage first: the true match and the look-alikes that
-// set `second` come in the first few stages, and the far stages are scanned with the final bound (simulated on the
-// bench frames: 12-17 passes per query instead of 40-48).
+// set `second` come in the first few stages, and the far stages are scanned with the final bound.
 // Exactness does not depend on the order: the two keys (distance << 32 | ORIGINAL train index) end as the two
 // lexicographically smallest of all pairs whatever the order of the updates (see above) -- but the tile filter's
 // strict '<' relied on ascending indices.  In any order a pair of distance d may be dropped iff d > second, or
 // d == second > best (it could only replace the second key by an equal distance); a pair with d == second == best
 // may carry the lower index and passes.  The bound fed to the MFMA is therefore second + [best == second], read
 // stale (stale values only make it larger: a superset passes).
+// The geometry also gives every stage a CLASS for the wave (bounding boxes of the stage and of the wave's queries):
+//   near  -- no pair of the two boxes is farther apart than 499 px: the penalty never applies (feature_matcher.cpp:164),
+//            the slow path skips its arithmetic;
+//   far   -- every pair is at least 501 px apart: the penalised distance is at least TWICE the Hamming distance
+//            (factor 1 + d / 500 > 2, truncation after the multiply), so a pair can only matter while
+//            2 * hamming < bound: the filter runs with ceil(bound / 2), which hardly anything passes;
+//   mixed -- everything else (and every stage when a coordinate is not finite: the reference's comparison with NaN
+//            is false, i.e. no penalty -- nothing may be assumed then).
 // No LDS stage and no barrier: a wave reads its A operands straight from global memory (a tile = 16 consecutive
 // expanded descriptors = 1 KB, one dwordx4 per lane, the next stage's four tiles in flight while the current
 // stage's 16 MFMAs run); the expanded train set of a frame (0.7 MB at 10k keypoints) is L2-resident.
@@ -668,20 +675,25 @@ __device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued
 constexpr int SP_STAGE = 64;          // trains per stage (4 tiles of 16)
 constexpr int SP_MAX_STAGES = 1025;   // maxK <= 65536
 constexpr int SP_BUCKETS = 128;       // stage order: counting sort on the centre distance in 32-px steps
+constexpr int SP_STARTUP_TILES = 8;   // the first tiles are filtered one by one (the bound still moves with every tile)
+constexpr int SP_FIFO = 384;          // tile entries: < 64 waiting + the 4 x 64 pushes of a stage (+ 64 slack)
+constexpr int SP_PAIRS = 192;         // pair entries: < 64 waiting + 64 pushes (+ 64 slack)
+constexpr uint32_t SP_NEAR = 1u, SP_FAR = 2u;
 
 __device__ __forceinline__ int clamp_coord(float v) {  // NaN -> -2^20; only ever used for ORDERING, never for results
     return static_cast<int>(fminf(fmaxf(v, -1048576.0f), 1048576.0f));
 }
+__device__ __forceinline__ bool coord_ok(float v) { return fabsf(v) < 1.0e6f; }  // false for NaN and infinities
 
 // One workgroup per frame: keypoints -> spatial order.  Writes, for sorted position p of frame f:
 //   xdesc [f][p][64] train-form expanded descriptor, sbits[f][p] compact bits, sxyi[f][p] {x, y, original index, 0},
-//   scent[f][p / 64] stage centres; positions [n, roundup(n, 64)) get a descriptor no bound lets through.
+//   sbox[f][p / 64] stage bounding boxes; positions [n, roundup(n, 64)) get a descriptor no bound lets through.
 // Without keypoints (no penalty, no coordinates) the order is the identity.
 __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int first_frame, int first_train_frame, int min_train) {
     __shared__ int hist[4096];
     __shared__ int bbox[4];
     __shared__ int wave_tot[16];
-    __shared__ int stage_sum[SP_MAX_STAGES][2];
+    __shared__ int stage_box[SP_MAX_STAGES][4];  // min x, min y (floor), max x, max y (ceil); [0] = INT_MIN marks a bad stage
     const int f = first_frame + blockIdx.x;
     const int n = mv.n_kp[f];
     const int pred = f > 0 ? f - 1 : first_train_frame;
@@ -695,14 +707,16 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     uint8_t* xd = mv.xdesc + static_cast<size_t>(f) * mv.maxKp * 64;
     uint2* sb = mv.sbits + static_cast<size_t>(f) * mv.maxKp;
     float4* sx = mv.sxyi + static_cast<size_t>(f) * mv.maxKp;
-    float2* sc = mv.scent + static_cast<size_t>(f) * (mv.maxKp / 64);
+    float4* sc = mv.sbox + static_cast<size_t>(f) * (mv.maxKp / 64);
     const int nst = (n + SP_STAGE - 1) / SP_STAGE;
     for (int i = tid; i < 4096; i += 1024) {
         hist[i] = 0;
     }
     for (int i = tid; i < nst; i += 1024) {
-        stage_sum[i][0] = 0;
-        stage_sum[i][1] = 0;
+        stage_box[i][0] = 0x7fffffff;
+        stage_box[i][1] = 0x7fffffff;
+        stage_box[i][2] = -0x7fffffff;
+        stage_box[i][3] = -0x7fffffff;
     }
     if (tid < 4) {
         bbox[tid] = tid < 2 ? 0x7fffffff : -0x7fffffff;
@@ -786,8 +800,15 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         if (use_kp) {
             x = kps[i].x;
             y = kps[i].y;
-            atomicAdd(&stage_sum[p >> 6][0], clamp_coord(x));
-            atomicAdd(&stage_sum[p >> 6][1], clamp_coord(y));
+            int* box = stage_box[p >> 6];
+            if (coord_ok(x) && coord_ok(y)) {
+                atomicMin(&box[0], static_cast<int>(floorf(x)));
+                atomicMin(&box[1], static_cast<int>(floorf(y)));
+                atomicMax(&box[2], static_cast<int>(ceilf(x)));
+                atomicMax(&box[3], static_cast<int>(ceilf(y)));
+            } else {
+                atomicMin(&box[0], -0x7fffffff - 1);  // poisons the stage: it gets no class
+            }
         }
         sb[p] = make_uint2(w0, w1);
         sx[p] = make_float4(x, y, __int_as_float(i), 0.0f);
@@ -818,24 +839,27 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     }
     __syncthreads();
     for (int s2 = tid; s2 < nst; s2 += 1024) {
-        const float cnt = static_cast<float>(min(SP_STAGE, n - s2 * SP_STAGE));
-        sc[s2] = make_float2(static_cast<float>(stage_sum[s2][0]) / cnt, static_cast<float>(stage_sum[s2][1]) / cnt);
+        const int* box = stage_box[s2];
+        const bool good = use_kp && box[0] != -0x7fffffff - 1 && box[0] <= box[2];
+        sc[s2] = good ? make_float4(static_cast<float>(box[0]), static_cast<float>(box[1]), static_cast<float>(box[2]),
+                                    static_cast<float>(box[3]))
+                      : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
     }
 }
 
+// ONE wave per workgroup: the waves share nothing, and a workgroup of four would hold its slot until the slowest of
+// them is done (measured: 25 % fewer wave-cycles than the staged scan, but no less time, at four per workgroup).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void match_spatial_kernel(MatchView mv,
-                                                                                                     int first_query_frame,
-                                                                                                     int first_train_frame,
-                                                                                                     int npairs, int qblocks) {
-    constexpr int QW = 16 * MM_QT;                         // queries per wave
-    // ONE wave per workgroup: the waves share nothing, and a workgroup of four would hold its slot until the slowest
-    // of them is done (measured: 25 % fewer wave-cycles than the staged scan, but no less time, at four per workgroup)
-    __shared__ uint4 qtab[1][QW];                          // per query: compact bits (x, y), position (z, w as float bits)
-    __shared__ unsigned long long keys[1][QW][2];          // per query: best_key, second_key
-    __shared__ uint32_t fifo[1][MM_FIFO + 64];             // lane | first (sorted) train index of the tile << 6
-    __shared__ uint32_t pairq[1][MM_PAIRS + 64];           // query | raw distance << 8 | sorted train index << 16
-    __shared__ uint16_t order[1][SP_MAX_STAGES + 3];       // the stages, nearest first
-    __shared__ int bucket[1][SP_BUCKETS];
+                                                                                                    int first_query_frame,
+                                                                                                    int first_train_frame,
+                                                                                                    int npairs, int qblocks) {
+    constexpr int QW = 16 * MM_QT;                      // queries per wave
+    __shared__ uint4 qtab[QW];                          // per query: compact bits (x, y), position (z, w as float bits)
+    __shared__ unsigned long long keys[QW][2];          // per query: best_key, second_key
+    __shared__ uint32_t fifo[SP_FIFO];                  // lane | tile (sorted position / 16) << 6 | class << 30
+    __shared__ uint32_t pairq[SP_PAIRS];                // query | class << 8 | sorted train index << 16
+    __shared__ uint16_t order[SP_MAX_STAGES + 3];       // the stages, nearest first: stage | class << 14
+    __shared__ int bucket[SP_BUCKETS];
     int pair, qblock, split;
     {
         const int id = static_cast<int>(blockIdx.x);
@@ -861,10 +885,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
     const int n1 = mv.n_kp[qf];
     const int n2 = mv.n_kp[tf];
     const int lane = threadIdx.x;
-    constexpr int wave = 0;
     const int wave_first = qblock * QW;  // sorted position of the wave's first query
     if (wave_first >= n1 || n2 < mv.mfma_min_train) {
-        return;  // no queries for this wave, or a pair of match_kernel's (no barrier anywhere below: waves are independent)
+        return;  // no queries here, or a pair of match_kernel's
     }
     const bool use_kp = mv.kps != nullptr;
     const int c = lane & 15;
@@ -889,20 +912,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
             qx = r.x;
             qy = r.y;
         }
-        qtab[wave][lane] = q;
-        keys[wave][lane][0] = MM_KEY_NONE;
-        keys[wave][lane][1] = MM_KEY_NONE;
+        qtab[lane] = q;
+        keys[lane][0] = MM_KEY_NONE;
+        keys[lane][1] = MM_KEY_NONE;
     }
     constexpr int NEVER = 0x3fffffff;  // accumulator input of an absent query: distance + NEVER is never negative
     v4i B[MM_QT];
-    v4i C[MM_QT];  // -bound of the lane's query of each tile, in all four rows
+    v4i C[MM_QT];       // -bound of the lane's query of each tile (for the class of the current stage), in all four rows
+    uint32_t bnd[MM_QT];  // the bound itself: second + [best == second] (0x7fffffff while fewer than two pairs were seen)
 #pragma unroll
     for (int u = 0; u < MM_QT; ++u) {
         const int i = wave_first + u * 16 + c;
         const bool ok = i < n1;
         B[u] = v4i{0, 0, 0, 0};
-        const int nb = ok ? -0x7fffffff : NEVER;
-        C[u] = v4i{nb, nb, nb, nb};
+        bnd[u] = ok ? 0x7fffffffu : 0u;  // an absent query has bound 0: nothing is below it
         if (ok) {
             const uint4 t = *reinterpret_cast<const uint4*>(xq + static_cast<size_t>(i) * 64 + 16 * g);
             // train form -> query form: bits * -2 (= * 254 per byte, no carries), and |q| / 1 swapped
@@ -914,36 +937,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
                        static_cast<int>(w3)};
         }
     }
-    // ---- the order of the stages: nearest centre first (a counting sort on the distance in 32-px steps)
+    auto load_C = [&](bool far) {  // the MFMA's accumulator input for stages of the given kind
+#pragma unroll
+        for (int u = 0; u < MM_QT; ++u) {
+            const uint32_t b = far ? (bnd[u] + 1u) >> 1 : bnd[u];  // far: 2 * hamming < bound <=> hamming < ceil(bound / 2)
+            const int nb = bnd[u] == 0u ? NEVER : -static_cast<int>(b);
+            C[u] = v4i{nb, nb, nb, nb};
+        }
+    };
+    // ---- the order of the stages (nearest box centre first: a counting sort on the distance in 32-px steps) and
+    //      their classes
     const int nst = (n2 + SP_STAGE - 1) / SP_STAGE;
-    uint16_t* const myorder = order[wave];
+    int n_not_far = nst;  // stages [0, n_not_far) of the order are near or mixed, the rest far
     if (use_kp) {
-        int* const mybucket = bucket[wave];
-        // centre of the wave's queries
-        int sxq = qorig >= 0 ? clamp_coord(qx) : 0, syq = qorig >= 0 ? clamp_coord(qy) : 0, cnt = qorig >= 0 ? 1 : 0;
+        // box of the wave's queries; a coordinate that is not finite (or beyond +-1e6) switches the classes off
+        const bool mine = qorig >= 0;
+        float wx0 = mine ? floorf(qx) : 3.0e38f, wy0 = mine ? floorf(qy) : 3.0e38f;
+        float wx1 = mine ? ceilf(qx) : -3.0e38f, wy1 = mine ? ceilf(qy) : -3.0e38f;
+        int bad = (mine && !(coord_ok(qx) && coord_ok(qy))) ? 1 : 0;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            sxq += __shfl_xor(sxq, d);
-            syq += __shfl_xor(syq, d);
-            cnt += __shfl_xor(cnt, d);
+            wx0 = fminf(wx0, __shfl_xor(wx0, d));
+            wy0 = fminf(wy0, __shfl_xor(wy0, d));
+            wx1 = fmaxf(wx1, __shfl_xor(wx1, d));
+            wy1 = fmaxf(wy1, __shfl_xor(wy1, d));
+            bad |= __shfl_xor(bad, d);
         }
-        const float cxq = static_cast<float>(sxq) / static_cast<float>(cnt), cyq = static_cast<float>(syq) / static_cast<float>(cnt);
-        const float2* cent = mv.scent + static_cast<size_t>(tf) * (mv.maxKp / 64);
+        const float cxq = 0.5f * (wx0 + wx1), cyq = 0.5f * (wy0 + wy1);
+        const float4* boxes = mv.sbox + static_cast<size_t>(tf) * (mv.maxKp / 64);
         for (int b = lane; b < SP_BUCKETS; b += 64) {
-            mybucket[b] = 0;
+            bucket[b] = 0;
         }
         wave_lds_fence();
-        auto bucket_of = [&](int s) {
-            const float2 ctr = cent[s];
-            const float dx = ctr.x - cxq, dy = ctr.y - cyq;
-            return min(SP_BUCKETS - 1, static_cast<int>(__builtin_amdgcn_sqrtf(dx * dx + dy * dy)) >> 5);
+        // bucket = the distance of the box centres in 64-px steps; the far stages (every pair >= 501 px apart: by
+        // construction the most distant ones) in a second group of buckets behind all the others, so that the
+        // filter's bound changes kind ONCE per scan
+        auto classify = [&](int s, uint32_t* cls) {
+            const float4 bx = boxes[s];
+            *cls = 0u;
+            if (bad != 0 || !(bx.x < 3.0e38f)) {
+                return SP_BUCKETS / 2 - 1;  // no usable box: mixed, visited last among the stages that are not far
+            }
+            const float gx = fmaxf(fmaxf(bx.x - wx1, wx0 - bx.z), 0.0f), gy = fmaxf(fmaxf(bx.y - wy1, wy0 - bx.w), 0.0f);
+            const float fx = fmaxf(bx.z - wx0, wx1 - bx.x), fy = fmaxf(bx.w - wy0, wy1 - bx.y);
+            if (fx * fx + fy * fy <= 499.0f * 499.0f) {
+                *cls = SP_NEAR;
+            } else if (gx * gx + gy * gy >= 501.0f * 501.0f) {
+                *cls = SP_FAR;
+            }
+            const float dx = 0.5f * (bx.x + bx.z) - cxq, dy = 0.5f * (bx.y + bx.w) - cyq;
+            const int d = min(SP_BUCKETS / 2 - 1, static_cast<int>(__builtin_amdgcn_sqrtf(dx * dx + dy * dy)) >> 6);
+            return *cls == SP_FAR ? SP_BUCKETS / 2 + d : d;
         };
         for (int s = lane; s < nst; s += 64) {
-            atomicAdd(&mybucket[bucket_of(s)], 1);
+            uint32_t cls;
+            atomicAdd(&bucket[classify(s, &cls)], 1);
         }
         wave_lds_fence();
         {  // exclusive prefix over 128 buckets: two per lane
-            const int a = mybucket[2 * lane], b = mybucket[2 * lane + 1];
+            const int a = bucket[2 * lane], b = bucket[2 * lane + 1];
             int inc = a + b;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -953,40 +1005,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
                 }
             }
             wave_lds_fence();
-            mybucket[2 * lane] = inc - a - b;
-            mybucket[2 * lane + 1] = inc - b;
+            bucket[2 * lane] = inc - a - b;
+            bucket[2 * lane + 1] = inc - b;
         }
         wave_lds_fence();
+        n_not_far = __builtin_amdgcn_readfirstlane(bucket[SP_BUCKETS / 2]);
+        wave_lds_fence();
         for (int s = lane; s < nst; s += 64) {
-            myorder[atomicAdd(&mybucket[bucket_of(s)], 1)] = static_cast<uint16_t>(s);
+            uint32_t cls;
+            const int bk = classify(s, &cls);
+            order[atomicAdd(&bucket[bk], 1)] = static_cast<uint16_t>(static_cast<uint32_t>(s) | (cls << 14));
         }
     } else {
         for (int s = lane; s < nst; s += 64) {
-            myorder[s] = static_cast<uint16_t>(s);
+            order[s] = static_cast<uint16_t>(static_cast<uint32_t>(s) | (SP_NEAR << 14));  // no keypoints: no penalty anywhere
         }
     }
     wave_lds_fence();
-    uint32_t* const myfifo = fifo[wave];
-    uint32_t* const mypairs = pairq[wave];
     int tail = 0;   // tile entries waiting (wave-uniform, kept in an SGPR)
     int ptail = 0;  // pair entries waiting
 #ifdef SLAMX_MATCH_STATS
-    unsigned long long sp_stat_1 = 0, sp_stat_2 = 0, sp_stat_3 = 0;
+    unsigned long long sp_stat_1 = 0, sp_stat_2 = 0, sp_stat_3 = 0, sp_stat_5 = 0, sp_stat_6 = 0, sp_stat_7 = 0;
 #endif
-    // level 2: `count` (<= 64) pairs from the head of the pair list, one per lane: the reference's penalty
-    // arithmetic (feature_matcher.cpp:161-170) and the update of the query's two keys
+    // level 2: `count` (<= 64) pairs from the head of the pair list, one per lane: the Hamming distance again, the
+    // reference's penalty arithmetic (feature_matcher.cpp:161-170) unless the pair's stage is `near`, and the update
+    // of the query's two keys
     auto settle = [&](int count) {
+        SP_STAT(7, 1);
         if (lane < count) {
-            const uint32_t e = mypairs[lane];
-            const int q = static_cast<int>(e & 0xffu);
-            int dist = static_cast<int>(e >> 8 & 0xffu);
+            const uint32_t e = pairq[lane];
+            const int q = static_cast<int>(e & 63u);
             const int t = static_cast<int>(e >> 16);
-            unsigned long long* key = keys[wave][q];
+            const uint2 tb = tbits[t];
+            const float4 tr = txyi[t];  // x, y, original index of the train keypoint
+            const uint4 qv = qtab[q];
+            unsigned long long* key = keys[q];
             const int sec = static_cast<int>(key[1] >> 32);  // may have shrunk since the pair was queued
-            if (dist <= sec) {
-                const float4 tr = txyi[t];  // x, y, original index of the train keypoint
-                if (use_kp) {
-                    const uint4 qv = qtab[wave][q];
+            int dist = __popc(qv.x ^ tb.x) + __popc(qv.y ^ tb.y);
+            if (dist <= sec && t < n2) {  // (a padding row of the last stage gets here while a query has no bound yet)
+                if ((e & (SP_NEAR << 8)) == 0u) {
                     dist = penalised_distance(dist, __uint_as_float(qv.z), __uint_as_float(qv.w), tr.x, tr.y);
                 }
                 SP_STAT(3, __popcll(__ballot(dist <= sec)));
@@ -1000,145 +1057,188 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         }
         // move what is left to the front (reads of a step before its writes: one wave, LDS in program order)
         for (int base = count; base < ptail; base += 64) {
-            const uint32_t v = mypairs[base + lane];
+            const uint32_t v = pairq[base + lane];
             if (base + lane < ptail) {
-                mypairs[base - count + lane] = v;
+                pairq[base - count + lane] = v;
             }
         }
         ptail -= count;
     };
     // level 1: `count` (<= 64) entries from the head of the tile list, one per lane: entry = (lane L, tile) stands
-    // for the 16 pairs {query u * 16 + (L & 15)} x {train tile + 4 (L >> 4) + r}; their distances are recomputed
-    // with xor + popcount and the ones that still reach the query's keys go to the pair list
+    // for the 16 pairs {query u * 16 + (L & 15)} x {train 16 tile + 4 (L >> 4) + r}.  Their distances are recomputed
+    // with xor + popcount, "below the query's bound" collected as one bit per pair (the sign of distance - bound,
+    // shifted in), and the lanes then queue their set bits one per round.
     auto work = [&](int count) {
         SP_STAT(1, count);
         const bool valid = lane < count;
-        const uint32_t e = myfifo[lane];
-        {
-            const uint32_t v = myfifo[count + lane];  // at most 63 entries remain: moved to the front
-            if (count + lane < tail) {
-                myfifo[lane] = v;
+        const uint32_t e = fifo[lane];
+        for (int base = count; base < tail; base += 64) {  // what remains is moved to the front
+            const uint32_t v = fifo[base + lane];
+            if (base + lane < tail) {
+                fifo[base - count + lane] = v;
             }
         }
         tail -= count;
         const int ec = static_cast<int>(e & 15u);
-        const int trow = valid ? static_cast<int>(e >> 6) + 4 * static_cast<int>(e >> 4 & 3u) : 0;
-        // everything the four query tiles need is requested before anything is used
+        const uint32_t cls = e >> 30;
+        const int trow = valid ? static_cast<int>(e >> 6 & 0x1fffu) * 16 + 4 * static_cast<int>(e >> 4 & 3u) : 0;
+        // everything is requested before anything is used
         uint2 tb[4];
+        int rowpen[4];  // rows past the end of the train set (the last stage's padding) start their popcount at 2^20
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             tb[r] = tbits[trow + r];  // (padding positions exist up to a whole stage: no range check on the address)
+            rowpen[r] = trow + r < n2 ? 0 : (1 << 20);
         }
-        uint2 qb[MM_QT];
-        int limit[MM_QT];
+        uint32_t bits = 0u;  // bit 15 - (4 u + r): pair (u, r) is below the bound
 #pragma unroll
         for (int u = 0; u < MM_QT; ++u) {
             const int q = u * 16 + ec;
-            qb[u] = *reinterpret_cast<const uint2*>(&qtab[wave][q]);
-            const int bestd = static_cast<int>(keys[wave][q][0] >> 32);
-            const int sec = static_cast<int>(keys[wave][q][1] >> 32);
+            const uint2 qb = *reinterpret_cast<const uint2*>(&qtab[q]);
+            const uint32_t bestd = static_cast<uint32_t>(keys[q][0] >> 32);
+            const uint32_t sec = static_cast<uint32_t>(keys[q][1] >> 32);
             // A pair that merely TIES with `second` changes an output only if it also ties with `best` (it may have
             // the lower index); with best < second it could at most replace the second key by an equal distance.
-            limit[u] = valid ? (bestd == sec ? sec : sec - 1) : -1;  // lanes without an entry queue nothing
-        }
-#pragma unroll
-        for (int u = 0; u < MM_QT; ++u) {
+            uint32_t bound = sec + ((bestd == sec && sec != 0x7fffffffu) ? 1u : 0u);
+            bound = cls == SP_FAR ? (bound + 1u) >> 1 : bound;
+            bound = valid ? bound : 0u;  // lanes without an entry queue nothing
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int t = trow + r;
-                const int dist = __popc(qb[u].x ^ tb[r].x) + __popc(qb[u].y ^ tb[r].y);
-                const bool pass = dist <= limit[u] && t < n2;
-                const unsigned long long pm = __ballot(pass);
-                if (pm != 0) {  // wave-uniform
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
-                    const uint32_t slot = pass ? static_cast<uint32_t>(ptail) + rank : static_cast<uint32_t>(MM_PAIRS);
-                    mypairs[slot] = static_cast<uint32_t>(u * 16 + ec) | (static_cast<uint32_t>(dist) << 8) |
-                                    (static_cast<uint32_t>(t) << 16);
-                    ptail += __popcll(pm);
-                    SP_STAT(2, __popcll(pm));
-                }
+                const int dist = __popc(qb.x ^ tb[r].x) + (__popc(qb.y ^ tb[r].y) + rowpen[r]);
+                bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(dist - static_cast<int>(bound)), 31);
             }
-            // after every query tile: a tile adds at most 4 x 64 pairs to the < 64 that wait (MM_PAIRS)
-#pragma unroll 1
-            while (ptail >= 64) {
+        }
+        bits &= 0xffffu;
+        const uint32_t tag = (cls << 8) | static_cast<uint32_t>(ec);
+        while (true) {
+            const bool has = bits != 0u;
+            const unsigned long long pm = __ballot(has);
+            if (pm == 0) {
+                break;
+            }
+            SP_STAT(5, 1);
+            const int k = 15 - (31 - __clz(static_cast<int>(bits)));  // highest set bit first: pair index 4 u + r
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+            if (has) {
+                pairq[ptail + static_cast<int>(rank)] = tag | (static_cast<uint32_t>(k >> 2) << 4) |
+                                                        (static_cast<uint32_t>(trow + (k & 3)) << 16);
+                bits &= ~(0x8000u >> k);
+            }
+            ptail += __popcll(pm);
+            SP_STAT(2, __popcll(pm));
+            if (ptail >= 64) {
                 settle(64);
             }
         }
     };
+    bool far_now = false;  // the kind of stage C[] is loaded for
     auto refresh_bounds = [&]() {
 #pragma unroll
         for (int u = 0; u < MM_QT; ++u) {
-            const int bestd = static_cast<int>(keys[wave][u * 16 + c][0] >> 32);
-            const int sec = static_cast<int>(keys[wave][u * 16 + c][1] >> 32);
-            // second + [best == second]: see the header (sec = INT_MAX while fewer than two pairs were seen: -INT_MAX)
-            const int nb = C[u][0] == NEVER ? NEVER : -(sec + ((bestd == sec && sec != 0x7fffffff) ? 1 : 0));
-            C[u] = v4i{nb, nb, nb, nb};
+            if (bnd[u] != 0u) {
+                const uint32_t bestd = static_cast<uint32_t>(keys[u * 16 + c][0] >> 32);
+                const uint32_t sec = static_cast<uint32_t>(keys[u * 16 + c][1] >> 32);
+                bnd[u] = sec + ((bestd == sec && sec != 0x7fffffffu) ? 1u : 0u);
+                bnd[u] = bnd[u] == 0u ? 1u : bnd[u];  // (cannot happen: second == 0 implies best == 0)
+            }
         }
+        load_C(far_now);
     };
+    load_C(false);
     // this workgroup's share of the stages: every nsplit-th of the ordered list (merged by emit_kernel)
     const int nmine = (nst - split + mv.nsplit - 1) / mv.nsplit;
-    auto stage_at = [&](int k) {  // k-th stage of this workgroup's share (wave-uniform)
-        return static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(myorder[min(split + k * mv.nsplit, nst - 1)])));
+    const int nmine_not_far = min(nmine, max(0, (n_not_far - split + mv.nsplit - 1) / mv.nsplit));
+    auto stage_at = [&](int k) {  // k-th stage of this workgroup's share: stage | class << 14 (wave-uniform)
+        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(order[min(split + k * mv.nsplit, nst - 1)])));
     };
-    auto fetch = [&](int s, v4i* A) {
-        const uint8_t* base = xtr + (static_cast<size_t>(s) * SP_STAGE + c) * 64 + 16 * g;
+    auto tile_ptr = [&](uint32_t sc) {  // this lane's 16 bytes of the stage's first tile
+        return xtr + (static_cast<size_t>(sc & 0x3fffu) * SP_STAGE + c) * 64 + 16 * g;
+    };
+    // one tile: distance - bound of the lane's 4 x 4 pairs, and a list entry when any of them is negative
+    auto filter_tile = [&](const v4i& A, uint32_t tile, uint32_t cls) {
+        v4i D[MM_QT];
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            A[tl] = *reinterpret_cast<const v4i*>(base + tl * 16 * 64);
+        for (int u = 0; u < MM_QT; ++u) {
+            D[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[u], C[u], 0, 0, 0);
         }
-    };
-    auto scan_stage = [&](int s, const v4i* A) {
+        int any = 0;
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            v4i D[MM_QT];
-#pragma unroll
-            for (int u = 0; u < MM_QT; ++u) {
-                D[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tl], B[u], C[u], 0, 0, 0);
-            }
-            int any = 0;
-#pragma unroll
-            for (int u = 0; u < MM_QT; ++u) {
-                any |= D[u][0] | D[u][1] | D[u][2] | D[u][3];
-            }
-            const bool pass = any < 0;  // some pair is below its (stale) bound
-            const unsigned long long pm = __ballot(pass);
+        for (int u = 0; u < MM_QT; ++u) {
+            any |= D[u][0] | D[u][1] | D[u][2] | D[u][3];
+        }
+        const unsigned long long pm = __ballot(any < 0);  // lanes with a pair below its (stale) bound
+        if (pm != 0) {  // wave-uniform: far stages rarely have one
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
-            typedef __attribute__((address_space(3))) uint32_t lds_u32;
-            lds_u32* const wr = (lds_u32*)myfifo + tail;
-            lds_u32* const dst = pass ? wr + rank : (lds_u32*)myfifo + MM_TRASH;
-            *dst = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(s * SP_STAGE + tl * 16) << 6);
-            tail += __popcll(pm);
-            if (tail >= 64) {  // wave-uniform
-                do {
-                    work(64);
-                } while (tail >= 64);
-                refresh_bounds();
+            if (any < 0) {
+                fifo[tail + static_cast<int>(rank)] = static_cast<uint32_t>(lane) | (tile << 6) | (cls << 30);
             }
+            tail += __popcll(pm);
         }
     };
-    v4i A0[4], A1[4];
-    if (nmine > 0) {
-        fetch(stage_at(0), A0);
-    }
-    for (int k = 0; k < nmine; k += 2) {
-        const int s0 = stage_at(k);
-        const int s1 = stage_at(k + 1);
-        if (k + 1 < nmine) {
-            fetch(s1, A1);
+    auto slow_path = [&](int need) {  // works the list off while it holds at least `need` entries
+        if (tail >= need) {
+            do {
+                work(min(64, tail));
+            } while (tail >= need);
+            refresh_bounds();
         }
-        scan_stage(s0, A0);
-        if (k + 1 < nmine) {
-            if (k + 2 < nmine) {
-                fetch(stage_at(k + 2), A0);
+    };
+    // The scan: the first SP_STARTUP_TILES tiles one by one (operand straight from memory: the bound moves with every
+    // tile there), then stage by stage -- a tile's operand registers are refilled with the NEXT stage's tile as soon
+    // as its MFMAs are issued, so four tile loads are always in flight -- first the stages that are not far, then,
+    // with the halved bound, the far ones; then the list drains.
+    const int ntiles = nmine * 4;
+    const int startup = min(SP_STARTUP_TILES, ntiles);
+    const int k_steady = startup / 4;  // first stage of the steady part (SP_STARTUP_TILES is a multiple of 4)
+    for (int it = 0; it < startup; ++it) {
+        const uint32_t sc = stage_at(it >> 2);
+        const bool far = (sc >> 14) == SP_FAR;
+        if (far != far_now) {
+            far_now = far;
+            load_C(far);
+        }
+        const v4i A1 = *reinterpret_cast<const v4i*>(tile_ptr(sc) + (it & 3) * 16 * 64);
+        filter_tile(A1, (sc & 0x3fffu) * 4u + static_cast<uint32_t>(it & 3), sc >> 14);
+        slow_path(64);
+    }
+    v4i A[4];
+    if (k_steady < nmine) {
+        const uint8_t* p0 = tile_ptr(stage_at(k_steady));
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            A[tl] = *reinterpret_cast<const v4i*>(p0 + tl * 16 * 64);
+        }
+    }
+    auto steady = [&](int k0, int k1) {
+        for (int k = k0; k < k1; ++k) {
+            const uint32_t s0 = stage_at(k);
+            const uint8_t* next = tile_ptr(stage_at(min(k + 1, nmine - 1)));  // (the last stage is simply loaded again)
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                filter_tile(A[tl], (s0 & 0x3fffu) * 4u + tl, s0 >> 14);
+                A[tl] = *reinterpret_cast<const v4i*>(next + tl * 16 * 64);
             }
-            scan_stage(s1, A1);
+            slow_path(64);
         }
+    };
+    const int k_far = max(k_steady, nmine_not_far);
+    if (k_steady < k_far) {
+        if (far_now) {
+            far_now = false;
+            load_C(false);
+        }
+        steady(k_steady, k_far);
     }
-    while (tail > 0) {  // end of the scan: what is still waiting
-        work(min(64, tail));
+    if (k_far < nmine) {
+        if (!far_now) {
+            far_now = true;
+            load_C(true);
+        }
+        steady(k_far, nmine);
     }
+    slow_path(1);
     while (ptail > 0) {
         settle(min(64, ptail));
     }
@@ -1150,10 +1250,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         atomicAdd(&sp_stats[2], sp_stat_2);
         atomicAdd(&sp_stats[3], sp_stat_3);
         atomicAdd(&sp_stats[4], static_cast<unsigned long long>(nmine));
+        atomicAdd(&sp_stats[5], sp_stat_5);
+        atomicAdd(&sp_stats[6], sp_stat_6);
+        atomicAdd(&sp_stats[7], sp_stat_7);
     }
 #endif
     if (qorig >= 0) {
-        const unsigned long long kb = keys[wave][lane][0], ks = keys[wave][lane][1];
+        const unsigned long long kb = keys[lane][0], ks = keys[lane][1];
         const size_t slot = (static_cast<size_t>(qf) * mv.nsplit + split) * mv.maxK + qorig;
         mv.best[slot] = make_int2(static_cast<int>(kb >> 32), static_cast<int>(static_cast<uint32_t>(kb)));
         mv.second[slot] = static_cast<int>(ks >> 32);

@@ -214,7 +214,8 @@ struct MatchView {
                      // the tables below, carved out of the one allocation by match_scratch_carve()), or nullptr
     uint2* sbits;    // [F][maxKp]  compact bits (first two words) of the keypoint at each sorted position
     float4* sxyi;    // [F][maxKp]  {x, y, original index (int bits), 0} of the keypoint at each sorted position
-    float2* scent;   // [F][maxKp / 64]  centre of every stage (64 consecutive sorted positions)
+    float4* sbox;    // [F][maxKp / 64]  bounding box {min x, min y, max x, max y} of every stage (64 consecutive sorted
+                     // positions); min x = +inf when a coordinate of the stage is not finite or beyond +-1e6
     int maxKp;       // sorted arrays' stride: maxK rounded up to 64, plus one padding stage
     int mfma_min_train;  // with xdesc: pairs whose TRAIN set has at least this many keypoints take the matrix-core
                          // scan, the others the popcount scan (both kernels are launched, each skips the other's pairs)
@@ -227,7 +228,7 @@ struct MatchView {
 inline int match_maxKp(int maxK) { return ((maxK + 63) / 64 + 1) * 64; }
 inline size_t match_scratch_bytes(size_t frames, int maxK) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
-    return frames * kp * (64 + sizeof(uint2) + sizeof(float4)) + frames * (kp / 64) * sizeof(float2) + 256;
+    return frames * kp * (64 + sizeof(uint2) + sizeof(float4)) + frames * (kp / 64) * sizeof(float4) + 256;
 }
 inline void match_scratch_carve(uint8_t* blob, size_t frames, int maxK, MatchView* mv) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
@@ -235,7 +236,7 @@ inline void match_scratch_carve(uint8_t* blob, size_t frames, int maxK, MatchVie
     mv->xdesc = blob;
     mv->sxyi = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * 64);
     mv->sbits = blob == nullptr ? nullptr : reinterpret_cast<uint2*>(blob + frames * kp * (64 + sizeof(float4)));
-    mv->scent = blob == nullptr ? nullptr : reinterpret_cast<float2*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)));
+    mv->sbox = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)));
 }
 void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
                               hipStream_t stream, hipEvent_t ev_mid);

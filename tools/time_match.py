@@ -50,6 +50,8 @@ def main():
         w = max(out[0], 1)
         print("spatial scan: %d waves, per query: %.1f tile entries / 4, %.1f pairs queued, %.1f reached the keys; %.1f stages per wave"
               % (out[0], out[1] / w / 64 * 4, out[2] / w / 64, out[3] / w / 64, out[4] / w))
+        print("per wave: %.1f tile entries, %.1f queue rounds, %.1f stage-kind flips, %.1f settle calls" % (
+            out[1] / w, out[5] / w, out[6] / w, out[7] / w))
     print("checksum", int(nm.sum()), int(batch.download_matches(m, B - 1)["trainIdx"].astype(np.int64).sum()))
 
 
