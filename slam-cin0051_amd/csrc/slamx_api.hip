@@ -427,6 +427,8 @@ int match_mfma_min_keypoints() {
     }
     return MATCH_MFMA_MIN_KEYPOINTS;
 }
+// ... and the lower size for frames whose keypoints are spread wide (never above the general threshold)
+int match_mfma_min_keypoints_wide() { return std::min(MATCH_MFMA_MIN_KEYPOINTS_WIDE, match_mfma_min_keypoints()); }
 
 uint64_t splitmix64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -958,13 +960,11 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
         HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
     }
     const int pattern_len = static_cast<int>(b->det->pattern.size() / 4);
-    // The matrix-core scan (match.hip) wins for large train sets (3.05 vs 4.9 ms per 256 frames of 10.4k keypoints,
-    // 1.37 vs 1.63 ms per 512 frames of 4.0k) and loses for small ones (0.69 vs 0.61 ms per 512 frames of 2.1k;
-    // even at 2.8k): its slow path handles ~2 ln(n) filter passes per query, a cost per QUERY, while the scan it
-    // replaces is a cost per PAIR.  The keypoint counts are only known on the device, so when the batch's capacity
-    // allows large sets BOTH kernels are launched and every frame pair is taken by one of them according to the
-    // size of its train set (MatchView::mfma_min_train).
-    const bool use_mfma = pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints();
+    // Two all-pairs scans with identical results (match.hip): int8 matrix cores in spatial order, and xor + popcount.
+    // Which is faster depends on the size of the train set and on how far its keypoints spread (slamx_internal.h:
+    // MATCH_MFMA_MIN_KEYPOINTS); both are only known on the device, so when the batch's capacity allows BOTH kernels
+    // are launched and every frame pair is taken by one of them (MatchView::mfma_flag, set by spatial_order_kernel).
+    const bool use_mfma = pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints_wide();
     if (use_mfma && b->xdesc == nullptr) {
         SLAMX_TRY(dev_alloc(&b->xdesc, match_scratch_bytes(F, b->v.maxK)));
     }
@@ -983,7 +983,8 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     mv.live_bits = std::max(1, pattern_len);
     match_scratch_carve(use_mfma ? b->xdesc : nullptr, F, b->v.maxK, &mv);
     mv.mfma_min_train = match_mfma_min_keypoints();
-    // (the matrix-core path takes 256 queries per workgroup, the popcount path 512)
+    mv.mfma_min_wide = match_mfma_min_keypoints_wide();
+    // (the matrix-core path takes 64 queries per workgroup, the popcount path 512)
     mv.nsplit = match_split_for(nframes, b->v.maxK);  // one split for both scans: they share the per-chunk result slots
     mv.use_ratio = m->cfg.use_ratio_test;
     mv.ratio = m->cfg.ratio_test_threshold;
@@ -1648,9 +1649,10 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
                 top >>= 1;
             }
             mv.live_bits = std::max(1, 32 * (live - 1) + hb);
-            if (n2 >= match_mfma_min_keypoints()) {  // see slamx_batch_match_consecutive
+            if (n2 >= match_mfma_min_keypoints_wide()) {  // see slamx_batch_match_consecutive: the device decides
                 match_scratch_carve(m->xdesc, 2, m->cap, &mv);
-                mv.mfma_min_train = 0;  // n2 is known here: the one pair takes the matrix-core scan
+                mv.mfma_min_train = match_mfma_min_keypoints();
+                mv.mfma_min_wide = match_mfma_min_keypoints_wide();
                 mv.nsplit = match_split_for(1, m->cap * 2);
             }
         }

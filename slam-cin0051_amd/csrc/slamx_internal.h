@@ -22,7 +22,13 @@ constexpr uint8_t NMS_UNDECIDED = 0;
 constexpr uint8_t NMS_KEPT = 1;
 constexpr uint8_t NMS_SUPPRESSED = 2;
 constexpr int MATCH_MAX_SPLIT = 8;
-constexpr int MATCH_MFMA_MIN_KEYPOINTS = 3072;  // smaller train sets take the xor + popcount scan (match.hip)
+// Train sets of at least this many keypoints take the matrix-core scan (match.hip), smaller ones the xor + popcount
+// scan -- unless the frame is WIDE: when its keypoints spread over more than 1000 px, most pairs carry the jump
+// penalty, the spatial scan sees them through a halved bound, and it wins from ~800 keypoints on (1080p: 0.204 vs
+// 0.212 ms per 512 frames of 835 keypoints, 0.26 vs 0.35 at 1.3k, 0.41 vs 0.60 at 2.1k; 640x480: a tie at 1.9-2.6k).
+constexpr int MATCH_MFMA_MIN_KEYPOINTS = 3072;
+constexpr int MATCH_MFMA_MIN_KEYPOINTS_WIDE = 768;
+constexpr float MATCH_MFMA_WIDE_DIAGONAL = 1000.0f;
 constexpr int NBR_CAP = 16;            // cached earlier-ranked neighbours per candidate
 constexpr uint8_t NBR_OVERFLOW = 255;  // more than NBR_CAP: re-enumerate every round
 
@@ -217,6 +223,8 @@ struct MatchView {
     float4* sbox;    // [F][maxKp / 64]  bounding box {min x, min y, max x, max y} of every stage (64 consecutive sorted
                      // positions); min x = +inf when a coordinate of the stage is not finite or beyond +-1e6
     int maxKp;       // sorted arrays' stride: maxK rounded up to 64, plus one padding stage
+    int* mfma_flag;  // [F]  1 = pairs with this frame as TRAIN set take the matrix-core scan (spatial_order_kernel decides)
+    int mfma_min_wide;   // ... or at least this many when the frame's keypoints spread over MATCH_MFMA_WIDE_DIAGONAL px
     int mfma_min_train;  // with xdesc: pairs whose TRAIN set has at least this many keypoints take the matrix-core
                          // scan, the others the popcount scan (both kernels are launched, each skips the other's pairs)
     int use_ratio;
@@ -228,7 +236,7 @@ struct MatchView {
 inline int match_maxKp(int maxK) { return ((maxK + 63) / 64 + 1) * 64; }
 inline size_t match_scratch_bytes(size_t frames, int maxK) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
-    return frames * kp * (64 + sizeof(uint2) + sizeof(float4)) + frames * (kp / 64) * sizeof(float4) + 256;
+    return frames * kp * (64 + sizeof(uint2) + sizeof(float4)) + frames * (kp / 64) * sizeof(float4) + frames * sizeof(int) + 256;
 }
 inline void match_scratch_carve(uint8_t* blob, size_t frames, int maxK, MatchView* mv) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
@@ -237,6 +245,8 @@ inline void match_scratch_carve(uint8_t* blob, size_t frames, int maxK, MatchVie
     mv->sxyi = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * 64);
     mv->sbits = blob == nullptr ? nullptr : reinterpret_cast<uint2*>(blob + frames * kp * (64 + sizeof(float4)));
     mv->sbox = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)));
+    mv->mfma_flag = blob == nullptr ? nullptr : reinterpret_cast<int*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)) +
+                                                                       frames * (kp / 64) * sizeof(float4));
 }
 void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,
                               hipStream_t stream, hipEvent_t ev_mid);

@@ -562,7 +562,7 @@ def test_batch_matching_through_the_matrix_core_scan(slamx, oracle, mfma_scan_fo
 
 def test_batch_with_both_scans_in_one_launch(slamx, oracle, monkeypatch):
     """Frames of very different keypoint counts in one batch, threshold between them: some frame pairs are taken
-    by match_kernel, the others by match_mfma_kernel -- chosen on the device by the size of the pair's train set."""
+    by match_kernel, the others by match_spatial_kernel -- chosen on the device by the size of the pair's train set."""
     monkeypatch.setenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", "600")
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     Pp = oracle.det_params(d.cfg)
@@ -580,6 +580,75 @@ def test_batch_with_both_scans_in_one_launch(slamx, oracle, monkeypatch):
         t = (k - 1) % 5
         want = oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], mp)
         assert_records_equal(b.download_matches(m, k), want, "frame %d (%d kp) vs %d (%d kp)" % (k, sizes[k], t, sizes[t]))
+
+
+def test_batch_scan_choice_by_extent(slamx, oracle):
+    """Default thresholds: train sets of 768..3071 keypoints take the matrix-core scan only when their keypoints spread
+    over more than 1000 px (decided per frame on the device).  Wide and narrow frames with such counts alternate in one
+    batch, so both scans run in one launch and every pair sees the other kind as its partner; all results are the
+    oracle's."""
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6))
+    Pp = oracle.det_params(d.cfg)
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
+    mp = oracle.match_params(m.cfg)
+    rows, cols = 400, 1500
+    frames = []
+    for k, (n, narrow) in enumerate(((5000, False), (7000, True), (5500, False), (300, False), (6500, True))):
+        f = synth(slamx, k, rows, cols, n, rmin=3, rmax=20)
+        if narrow:
+            f[:, 600:] = 128  # corners only in the left 600 columns: diagonal of the keypoint box < 1000 px
+        frames.append(f)
+    F = len(frames)
+    b = slamx.Batch(d, rows, cols, F, 65536, 8192)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(F)
+    b.match_consecutive(m, F, use_keypoints=True, first_train_frame=F - 1)
+    ref = [oracle.detect_and_compute(f, Pp) for f in frames]
+    sizes = [len(r[0]) for r in ref]
+    assert all(768 <= sizes[k] < 3072 for k in (0, 1, 2, 4)) and sizes[3] < 768, sizes
+    assert ref[1][0]["x"].max() < 640 and ref[0][0]["x"].max() > 1400
+    for k in range(F):
+        t = (k - 1) % F
+        want = oracle.match(ref[k][1], ref[t][1], ref[k][0], ref[t][0], mp)
+        assert_records_equal(b.download_matches(m, k), want, "frame %d (%d kp) vs %d (%d kp)" % (k, sizes[k], t, sizes[t]))
+
+
+def test_match_spatial_scan_with_wild_coordinates(slamx, oracle, mfma_scan_for_all_sizes):
+    """The spatial scan orders by keypoint position and classes stages by their bounding boxes; the RESULT must not
+    depend on either: NaN coordinates (the reference's `distance > 500` is false for NaN: no penalty), coordinates of
+    +-3e9, negative ones, everything at one point, and a clean set for comparison.  (Infinite coordinates are left
+    out: the reference then converts an infinite float to int, which is undefined behaviour -- INT_MIN on x86.)"""
+    rng = np.random.default_rng(77)
+    n1, n2 = 700, 900
+    d1 = np.zeros((n1, 32), np.uint8)
+    d2 = np.zeros((n2, 32), np.uint8)
+    d1[:, :5] = rng.integers(0, 256, (n1, 5), dtype=np.uint8)
+    d2[:, :5] = rng.integers(0, 256, (n2, 5), dtype=np.uint8)
+    d2[rng.integers(0, n2, 300)] = d1[rng.integers(0, n1, 300)]
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.9))
+    mp = oracle.match_params(m.cfg)
+
+    def kps(n, kind):
+        k = np.zeros(n, slamx.KEYPOINT_DTYPE)
+        k["x"] = rng.uniform(0, 1920, n).astype(np.float32)
+        k["y"] = rng.uniform(0, 1080, n).astype(np.float32)
+        if kind == "nan":
+            k["x"][rng.integers(0, n, n // 7)] = np.nan
+            k["y"][rng.integers(0, n, n // 9)] = np.nan
+        elif kind == "huge":
+            k["x"][rng.integers(0, n, n // 5)] = 3.0e9
+            k["y"][rng.integers(0, n, n // 5)] = -3.0e9
+            k["x"][rng.integers(0, n, n // 5)] *= -1.0
+        elif kind == "point":
+            k["x"] = 7.0
+            k["y"] = 7.0
+        return k
+
+    with np.errstate(invalid="ignore", over="ignore"):
+        for kq, kt in (("nan", "clean"), ("clean", "nan"), ("nan", "nan"), ("huge", "clean"), ("clean", "huge"), ("point", "clean"),
+                       ("point", "point"), ("clean", "clean")):
+            k1, k2 = kps(n1, kq), kps(n2, kt)
+            assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, mp), "query %s, train %s" % (kq, kt))
 
 
 def test_match_penalty_fractional_keypoints(slamx, oracle):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the match stage alone on a bench workload's frames (detect + describe once, then N match calls).
-    python tools/time_match.py <workload> [batch] [reps]
+    python tools/time_match.py <workload> [batch] [reps] [n_rect]      (n_rect: another corner density for the same frame size)
 Environment switches of the matcher apply: SLAMX_MATCH_MFMA_MIN_KEYPOINTS, SLAMX_MATCH_SPATIAL."""
 import importlib.util
 import os
@@ -19,6 +19,8 @@ def main():
     wl = bench.WORKLOADS[name]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else wl["batch"]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    if len(sys.argv) > 4:
+        wl = dict(wl, n_rect=int(sys.argv[4]))
     mod = bench.load_product()
     ctx = mod.Context(0)
     det = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), ctx)
