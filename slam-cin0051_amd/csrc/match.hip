@@ -346,6 +346,43 @@ __device__ __forceinline__ int clamp_coord(float v) {  // NaN -> -2^20; only eve
 }
 __device__ __forceinline__ bool coord_ok(float v) { return fabsf(v) < 1.0e6f; }  // false for NaN and infinities
 
+// Which scan takes the pairs that have a frame as TRAIN set: large sets the matrix cores, small ones xor + popcount,
+// medium ones the matrix cores iff their keypoints spread wide (slamx_internal.h).  One WAVE per frame (the box of a
+// few thousand keypoints is a handful of loads per lane and a wave reduction).
+__global__ __launch_bounds__(1024) void scan_choice_kernel(MatchView mv, int first_frame, int nframes) {
+    const int lane = threadIdx.x & 63;
+    const int k = static_cast<int>(blockIdx.x) * 16 + static_cast<int>(threadIdx.x >> 6);
+    if (k >= nframes) {
+        return;
+    }
+    const int f = first_frame + k;
+    const int m = mv.n_kp[f];
+    int flag = m >= mv.mfma_min_train ? 1 : 0;
+    if (flag == 0 && m >= mv.mfma_min_wide && mv.kps != nullptr) {
+        const slamx_keypoint* kp = mv.kps + static_cast<size_t>(f) * mv.maxK;
+        int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff, hy = -0x7fffffff;
+        for (int i = lane; i < m; i += 64) {
+            const int x = clamp_coord(kp[i].x), y = clamp_coord(kp[i].y);
+            lx = min(lx, x);
+            ly = min(ly, y);
+            hx = max(hx, x);
+            hy = max(hy, y);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lx = min(lx, __shfl_xor(lx, d));
+            ly = min(ly, __shfl_xor(ly, d));
+            hx = max(hx, __shfl_xor(hx, d));
+            hy = max(hy, __shfl_xor(hy, d));
+        }
+        const float w = static_cast<float>(hx - lx), h = static_cast<float>(hy - ly);
+        flag = w * w + h * h >= MATCH_MFMA_WIDE_DIAGONAL * MATCH_MFMA_WIDE_DIAGONAL ? 1 : 0;
+    }
+    if (lane == 0) {
+        mv.mfma_flag[f] = flag;
+    }
+}
+
 // One workgroup per frame: keypoints -> spatial order.  Writes, for sorted position p of frame f:
 //   xdesc [f][p][64] train-form expanded descriptor, sbits[f][p] compact bits, sxyi[f][p] {x, y, original index, 0},
 //   sbox[f][p / 64] stage bounding boxes; positions [n, roundup(n, 64)) get a descriptor no bound lets through.
@@ -359,46 +396,9 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     const int n = mv.n_kp[f];
     const int pred = f > 0 ? f - 1 : first_train_frame;
     const int tid = threadIdx.x;
-    // Which scan takes the pairs that have frame `fr` as TRAIN set (workgroup-uniform): large sets the matrix cores,
-    // small ones xor + popcount, medium ones the matrix cores iff their keypoints spread wide (slamx_internal.h).
-    auto wants_mfma = [&](int fr) {
-        const int m = mv.n_kp[fr];
-        if (m >= mv.mfma_min_train) {
-            return true;
-        }
-        if (m < mv.mfma_min_wide || mv.kps == nullptr) {
-            return false;
-        }
-        __syncthreads();
-        if (tid < 4) {
-            bbox[tid] = tid < 2 ? 0x7fffffff : -0x7fffffff;
-        }
-        __syncthreads();
-        const slamx_keypoint* k = mv.kps + static_cast<size_t>(fr) * mv.maxK;
-        int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff, hy = -0x7fffffff;
-        for (int i = tid; i < m; i += 1024) {
-            const int x = clamp_coord(k[i].x), y = clamp_coord(k[i].y);
-            lx = min(lx, x);
-            ly = min(ly, y);
-            hx = max(hx, x);
-            hy = max(hy, y);
-        }
-        atomicMin(&bbox[0], lx);
-        atomicMin(&bbox[1], ly);
-        atomicMax(&bbox[2], hx);
-        atomicMax(&bbox[3], hy);
-        __syncthreads();
-        const float w = static_cast<float>(bbox[2] - bbox[0]), h = static_cast<float>(bbox[3] - bbox[1]);
-        return w * w + h * h >= MATCH_MFMA_WIDE_DIAGONAL * MATCH_MFMA_WIDE_DIAGONAL;
-    };
-    const bool as_train = wants_mfma(f);
-    if (tid == 0) {
-        mv.mfma_flag[f] = as_train ? 1 : 0;
+    if (mv.mfma_flag[f] == 0 && (pred < 0 || mv.mfma_flag[pred] == 0)) {
+        return;  // neither the train set nor the query frame of a matrix-core pair (scan_choice_kernel; uniform)
     }
-    if (!as_train && (pred < 0 || !wants_mfma(pred))) {
-        return;  // neither the train set nor the query frame of a matrix-core pair (uniform)
-    }
-    __syncthreads();
     const int stride = mv.width / 4;
     const bool use_kp = mv.kps != nullptr;
     const slamx_keypoint* kps = use_kp ? mv.kps + static_cast<size_t>(f) * mv.maxK : nullptr;
@@ -430,10 +430,19 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
             hx = max(hx, x);
             hy = max(hy, y);
         }
-        atomicMin(&bbox[0], lx);
-        atomicMin(&bbox[1], ly);
-        atomicMax(&bbox[2], hx);
-        atomicMax(&bbox[3], hy);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {  // one atomic per wave, not per thread
+            lx = min(lx, __shfl_xor(lx, d));
+            ly = min(ly, __shfl_xor(ly, d));
+            hx = max(hx, __shfl_xor(hx, d));
+            hy = max(hy, __shfl_xor(hy, d));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&bbox[0], lx);
+            atomicMin(&bbox[1], ly);
+            atomicMax(&bbox[2], hx);
+            atomicMax(&bbox[3], hy);
+        }
         __syncthreads();
         x0 = bbox[0];
         y0 = bbox[1];
@@ -1128,7 +1137,12 @@ void launch_match_consecutive(const MatchView& mv_in, int first_query_frame, int
         const int hi_frame = first_query_frame + npairs - 1;
         const bool extra = first_query_frame == 0 && first_train_frame >= 0 && (first_train_frame < lo_frame || first_train_frame > hi_frame);
         const int pair_slots = npairs >= 8 ? 8 * ((npairs + 7) / 8) : npairs;
-        hipLaunchKernelGGL(spatial_order_kernel, dim3(hi_frame - lo_frame + 1), dim3(1024), 0, stream, mv, lo_frame, first_train_frame);
+        const int nfr = hi_frame - lo_frame + 1;
+        hipLaunchKernelGGL(scan_choice_kernel, dim3((nfr + 15) / 16), dim3(1024), 0, stream, mv, lo_frame, nfr);
+        if (extra) {
+            hipLaunchKernelGGL(scan_choice_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, 1);
+        }
+        hipLaunchKernelGGL(spatial_order_kernel, dim3(nfr), dim3(1024), 0, stream, mv, lo_frame, first_train_frame);
         if (extra) {
             hipLaunchKernelGGL(spatial_order_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, first_train_frame);
         }
