@@ -420,15 +420,43 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         bbox[tid] = tid < 2 ? 0x7fffffff : -0x7fffffff;
     }
     __syncthreads();
+    // A thread owns keypoints tid, tid + 1024, ...: up to 16 of them (every set of at most 16384 keypoints) are read
+    // ONCE, all loads in flight together, and stay in registers through the three passes (box, cell counts, scatter);
+    // larger sets read their keypoints again in every pass.  With one workgroup per frame the kernel is a chain of
+    // memory round trips, not of arithmetic.
+    constexpr int CK = 16;
+    const bool cached = n <= CK * 1024;
+    float kx[CK], ky[CK];
+    if (use_kp && cached) {
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const int i = tid + 1024 * j;
+            kx[j] = i < n ? kps[i].x : 0.0f;
+            ky[j] = i < n ? kps[i].y : 0.0f;
+        }
+    }
     int side = 1, ncx = 1, ncy = 1, x0 = 0, y0 = 0;
+    float inv_side = 1.0f;
     if (use_kp) {
         int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff, hy = -0x7fffffff;
-        for (int i = tid; i < n; i += 1024) {
-            const int x = clamp_coord(kps[i].x), y = clamp_coord(kps[i].y);
+        auto grow = [&](float xf, float yf) {
+            const int x = clamp_coord(xf), y = clamp_coord(yf);
             lx = min(lx, x);
             ly = min(ly, y);
             hx = max(hx, x);
             hy = max(hy, y);
+        };
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+                if (tid + 1024 * j < n) {
+                    grow(kx[j], ky[j]);
+                }
+            }
+        } else {
+            for (int i = tid; i < n; i += 1024) {
+                grow(kps[i].x, kps[i].y);
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {  // one atomic per wave, not per thread
@@ -452,18 +480,27 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         side = max(side, max(static_cast<int>(w) / 64 + 1, static_cast<int>(h) / 64 + 1));
         ncx = min(64, static_cast<int>(w) / side + 1);
         ncy = min(64, static_cast<int>(h) / side + 1);
+        inv_side = 1.0f / static_cast<float>(side);
     }
-    auto cell_of = [&](int i) {
-        if (!use_kp) {
-            return 0;
-        }
-        const int cx = min(ncx - 1, (clamp_coord(kps[i].x) - x0) / side);
-        const int cy = min(ncy - 1, (clamp_coord(kps[i].y) - y0) / side);
+    // (a float multiply instead of the integer division: a keypoint on a cell border may land in either cell, the
+    // same one in both passes -- the order is a heuristic, the result does not depend on it)
+    auto cell_of = [&](float xf, float yf) {
+        const int cx = min(ncx - 1, static_cast<int>(static_cast<float>(clamp_coord(xf) - x0) * inv_side));
+        const int cy = min(ncy - 1, static_cast<int>(static_cast<float>(clamp_coord(yf) - y0) * inv_side));
         return cy * ncx + ((cy & 1) != 0 ? ncx - 1 - cx : cx);  // boustrophedon: consecutive cells are neighbours
     };
     if (use_kp) {
-        for (int i = tid; i < n; i += 1024) {
-            atomicAdd(&hist[cell_of(i)], 1);
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+                if (tid + 1024 * j < n) {
+                    atomicAdd(&hist[cell_of(kx[j], ky[j])], 1);
+                }
+            }
+        } else {
+            for (int i = tid; i < n; i += 1024) {
+                atomicAdd(&hist[cell_of(kps[i].x, kps[i].y)], 1);
+            }
         }
         __syncthreads();
         // exclusive prefix over the 4096 cells: 4 per thread, wave scan, wave totals
@@ -498,15 +535,11 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         __syncthreads();
     }
     const uint32_t* rows = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(f) * mv.maxK * mv.width);
-    for (int i = tid; i < n; i += 1024) {
-        const int p = use_kp ? atomicAdd(&hist[cell_of(i)], 1) : i;  // (the order inside a cell is immaterial)
-        const uint32_t w0 = rows[static_cast<size_t>(i) * stride];
-        const uint32_t w1 = stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u;
+    // one keypoint -> its sorted position: compact bits, position record, expanded descriptor, stage box
+    auto place = [&](int i, float x, float y, uint32_t w0, uint32_t w1) {
+        const int p = use_kp ? atomicAdd(&hist[cell_of(x, y)], 1) : i;  // (the order inside a cell is immaterial)
         const unsigned long long bits = static_cast<unsigned long long>(w0) | (static_cast<unsigned long long>(w1) << 32);
-        float x = 0.0f, y = 0.0f;
         if (use_kp) {
-            x = kps[i].x;
-            y = kps[i].y;
             int* box = stage_box[p >> 6];
             if (coord_ok(x) && coord_ok(y)) {
                 atomicMin(&box[0], static_cast<int>(floorf(x)));
@@ -533,6 +566,27 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
                 e.w = (e.w & 0x0000ffffu) | (static_cast<uint32_t>(__popcll(bits)) << 16) | 0x01000000u;
             }
             o[quarter] = e;
+        }
+    };
+    if (cached) {
+        uint32_t w0[CK], w1[CK];
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {  // the descriptor words of all the thread's keypoints first
+            const int i = tid + 1024 * j;
+            w0[j] = i < n ? rows[static_cast<size_t>(i) * stride] : 0u;
+            w1[j] = (i < n && stride > 1) ? rows[static_cast<size_t>(i) * stride + 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const int i = tid + 1024 * j;
+            if (i < n) {
+                place(i, use_kp ? kx[j] : 0.0f, use_kp ? ky[j] : 0.0f, w0[j], w1[j]);
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            place(i, use_kp ? kps[i].x : 0.0f, use_kp ? kps[i].y : 0.0f, rows[static_cast<size_t>(i) * stride],
+                  stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u);
         }
     }
     // padding up to a whole stage: distance 127 + |q|, which no bound below 127 lets through (and the slow path
