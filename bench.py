@@ -150,8 +150,10 @@ def pmc_traffic_bytes(kernel, batch):
     """2 x FETCH_SIZE + WRITE_SIZE of one launch of `kernel`: measured offline at 256 frames per launch
     (tools/collect_profiles.sh) and scaled to `batch` frames -- the per-frame traffic of these kernels
     does not depend on the batch."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_b256.csv")
-    if not os.path.exists(path):
+    # a STORED figure (profiles/README.md): the newest round's counter file, not a measurement of this run
+    path = next((p for p in (os.path.join(ROOT, "profiles", "r0%d_pmc_hbm_traffic_b256.csv" % r) for r in (3, 2))
+                 if os.path.exists(p)), None)
+    if path is None:
         return None
     scale = batch / 256.0
     name = kernel.split("<")[0]
@@ -710,7 +712,7 @@ def main(argv=None):
         thr = mod.load_library().slamx_matcher_mfma_threshold()
         mfma_match = wl["max_kp"] >= thr and N >= thr  # (per frame pair on the device; N is the batch average)
         if mfma_match:
-            kernel_of["match"] = "match_mfma_kernel"
+            kernel_of["match"] = "match_spatial_kernel"
         if dom == "match" and mfma_match:
             # large train sets: Hamming distances as int8 dot products on the matrix cores (match.hip): one
             # v_mfma_i32_16x16x64_i8 per 16 x 16 pairs, K = 64 of which 48 carry data (46 bits + 2 augmenting terms)

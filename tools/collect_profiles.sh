@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the measurements that profiles/ holds for a round (run on the GPU box through gpurun):
-#   1. bench.py JSON lines for every workload (with the CPU baseline for the default one, c3p and c4)
+#   1. bench.py JSON lines for every workload (with the CPU baselines: one thread and all granted cores)
 #   2. rocprofv3 --kernel-trace --stats of the default bench command, of c3 and of c4
 #   3. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the default command (HBM traffic)
 #   4. separate --pmc passes for the instruction mix (SQ_INSTS_*) and the busy counters (TA, VALU)
@@ -8,13 +8,14 @@
 #   6. tools/microbench: sustained FP64 MFMA rate, issue rates of the VALU / LDS instructions the kernels lean on
 # usage: tools/collect_profiles.sh <tag>      (writes under gpurun_out/<tag>/)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python bench.py --steps 10 --warmup 2 > "$out/bench_1080p_2k.json"
 echo "default done"
 python bench.py --batch 256 --steps 20 --warmup 3 --no-cpu-baseline --no-pcie > "$out/bench_1080p_2k_b256.json"
+python bench.py --workload c1 --steps 20 --warmup 3 --no-pcie > "$out/bench_c1.json"
 python bench.py --workload c2 --steps 20 --warmup 3 --no-pcie > "$out/bench_c2.json"
 python bench.py --workload c3 --steps 10 --warmup 2 --no-pcie > "$out/bench_c3.json"
 echo "c3 done"

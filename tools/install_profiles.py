@@ -27,7 +27,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     plain = {
         "bench_1080p_2k.json": "bench_1080p_2k.json", "bench_1080p_2k_b256.json": "bench_1080p_2k_b256.json",
-        "bench_c2.json": "bench_c2.json", "bench_c3.json": "bench_c3.json", "bench_c3p.json": "bench_c3p.json",
+        "bench_c1.json": "bench_c1.json", "bench_c2.json": "bench_c2.json", "bench_c3.json": "bench_c3.json", "bench_c3p.json": "bench_c3p.json",
         "bench_c4.json": "bench_c4.json", "bench_under_rocprof.json": "bench_under_rocprof.json",
         "bench_c3_under_rocprof.json": "bench_c3_under_rocprof.json", "bench_c4_under_rocprof.json": "bench_c4_under_rocprof.json",
         "stats_kernel_stats.csv": "bench_1080p_2k_kernel_stats.csv", "stats_c3_kernel_stats.csv": "bench_c3_kernel_stats.csv",
