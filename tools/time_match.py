@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times the match stage alone on a bench workload's frames (detect + describe once, then N match calls).
     python tools/time_match.py <workload> [batch] [reps] [n_rect]      (n_rect: another corner density for the same frame size)
-Environment switches of the matcher apply: SLAMX_MATCH_MFMA_MIN_KEYPOINTS, SLAMX_MATCH_SPATIAL."""
+The matcher's environment switch applies: SLAMX_MATCH_MFMA_MIN_KEYPOINTS (0: the matrix-core scan for every
+pair, 100000: the popcount scan).  A library built with FLAGS_match=-DSLAMX_MATCH_STATS also reports the slow-path volume."""
 import importlib.util
 import os
 import sys
@@ -38,9 +39,8 @@ def main():
         batch.match_consecutive(m, B, use_keypoints=True, first_train_frame=B - 1)
         ts.append(ctx.timer_stop_ms())
     nc, nk, nm = batch.counts(B)
-    print("%s B=%d keypoints/frame %.0f matches/frame %.0f: match stage %.3f ms (min %.3f) [MFMA_MIN=%s SPATIAL=%s]" % (
-        name, B, nk.mean(), nm.mean(), float(np.median(ts)), min(ts), os.environ.get("SLAMX_MATCH_MFMA_MIN_KEYPOINTS"),
-        os.environ.get("SLAMX_MATCH_SPATIAL")))
+    print("%s B=%d keypoints/frame %.0f matches/frame %.0f: match stage %.3f ms (min %.3f) [MFMA_MIN=%s]" % (
+        name, B, nk.mean(), nm.mean(), float(np.median(ts)), min(ts), os.environ.get("SLAMX_MATCH_MFMA_MIN_KEYPOINTS")))
     lib = mod.load_library()
     if hasattr(lib, "slamx_debug_match_stats"):  # development build (-DSLAMX_MATCH_STATS)
         import ctypes
