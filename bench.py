@@ -315,7 +315,7 @@ def cpu_baseline(mod, wl, frames, budget_s=12.0, budget_mt_s=8.0):
     out.update(host)
     if cores > 1:
         T = min(cores, len(frames), 128)
-        per_thread = max(1, len(frames) // T)
+        per_thread = max(1, min(len(frames) // T, int(budget_mt_s / t_frame)))  # (c3: 3.5 s per frame -- two per thread)
         nmt = per_thread * T
         # one frame per thread first: what a frame costs with every core busy (clocks, shared caches, a quota the
         # cgroup files did not show), then as many passes as the budget allows
