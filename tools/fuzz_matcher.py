@@ -42,8 +42,13 @@ def keypoints(rng, slamx, n, kind):
         k["x"], k["y"] = rng.integers(0, 1920, n), rng.integers(0, 1080, n)
     elif kind == 1:  # fractional, some far outside
         k["x"], k["y"] = rng.random(n) * 4000 - 1000, rng.random(n) * 3000 - 1000
-    else:  # a tight cluster: nobody is farther than the jump radius
+    elif kind == 2:  # a tight cluster: nobody is farther than the jump radius
         k["x"], k["y"] = 900 + rng.random(n) * 300, 500 + rng.random(n) * 300
+    else:  # clumps on a 4k canvas with a few NaN coordinates (no penalty in the reference: NaN > 500 is false)
+        c = rng.integers(0, 6, n)
+        k["x"], k["y"] = (c % 3) * 1500 + rng.random(n) * 200, (c // 3) * 1500 + rng.random(n) * 200
+        bad = rng.integers(0, n, max(1, n // 50))
+        k["x"][bad] = np.nan
     return k
 
 
@@ -54,16 +59,18 @@ def main():
     oracle = oracle_binding.load()
     rng = np.random.default_rng(seed)
     for case in range(cases):
-        n1 = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
-        n2 = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
+        sizes = lambda: [rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000), rng.integers(700, 3000),
+                         rng.integers(3000, 7000)]  # (the last class: the matrix-core scan by the default rule)
+        n1 = int(rng.choice(sizes()))
+        n2 = int(rng.choice(sizes()))
         width = int(rng.choice([4, 8, 12, 16, 20, 32, 33, 64]))
         bits = int(rng.choice([rng.integers(1, 16), 31, 32, 33, 46, 62, 63, 64]))
         bits = min(bits, 8 * min(width, 8))
         d1 = descriptors(rng, n1, width, bits, None)
         d2 = descriptors(rng, n2, width, bits, d1)
-        kind = int(rng.integers(0, 4))  # 3 = no keypoints
-        k1 = keypoints(rng, slamx, n1, kind) if kind < 3 else None
-        k2 = keypoints(rng, slamx, n2, kind) if kind < 3 else None
+        kind = int(rng.integers(0, 5))  # 4 = no keypoints
+        k1 = keypoints(rng, slamx, n1, kind) if kind < 4 else None
+        k2 = keypoints(rng, slamx, n2, kind) if kind < 4 else None
         filt, ratio_on = int(rng.integers(0, 2)), int(rng.integers(0, 2))
         good = int(rng.choice([1, 3, 20, 5000]))
         ratio = float(rng.choice([0.0, 0.5, 0.7, 0.9, 1.0]))
