@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     const bool use_kp = mv.kps != nullptr;
     const slamx_keypoint* kps = use_kp ? mv.kps + static_cast<size_t>(f) * mv.maxK : nullptr;
     uint8_t* xd = mv.xdesc + static_cast<size_t>(f) * mv.maxKp * 64;
-    uint2* sb = mv.sbits + static_cast<size_t>(f) * mv.maxKp;
+    uint4* sb = mv.sbits + static_cast<size_t>(f) * mv.maxKp;
     float4* sx = mv.sxyi + static_cast<size_t>(f) * mv.maxKp;
     float4* sc = mv.sbox + static_cast<size_t>(f) * (mv.maxKp / 64);
     const int nst = (n + SP_STAGE - 1) / SP_STAGE;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
                 atomicMin(&box[0], -0x7fffffff - 1);  // poisons the stage: it gets no class
             }
         }
-        sb[p] = make_uint2(w0, w1);
+        sb[p] = make_uint4(w0, w1, static_cast<uint32_t>(i), 0u);
         sx[p] = make_float4(x, y, __int_as_float(i), 0.0f);
         uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
 #pragma unroll
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
         o[0] = o[1] = o[2] = make_uint4(0u, 0u, 0u, 0u);
         o[3] = make_uint4(0u, 0u, 0u, 0x017f0000u);
-        sb[p] = make_uint2(0u, 0u);
+        sb[p] = make_uint4(0u, 0u, 0xffffffffu, 0u);
         sx[p] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
     }
     __syncthreads();
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
     const int g = lane >> 4;
     const uint8_t* xq = mv.xdesc + static_cast<size_t>(qf) * mv.maxKp * 64;
     const uint8_t* xtr = mv.xdesc + static_cast<size_t>(tf) * mv.maxKp * 64;
-    const uint2* qbits = mv.sbits + static_cast<size_t>(qf) * mv.maxKp;
-    const uint2* tbits = mv.sbits + static_cast<size_t>(tf) * mv.maxKp;
+    const uint4* qbits = mv.sbits + static_cast<size_t>(qf) * mv.maxKp;
+    const uint4* tbits = mv.sbits + static_cast<size_t>(tf) * mv.maxKp;
     const float4* qxyi = mv.sxyi + static_cast<size_t>(qf) * mv.maxKp;
     const float4* txyi = mv.sxyi + static_cast<size_t>(tf) * mv.maxKp;
     // ---- the wave's queries
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         const int i = wave_first + lane;
         uint4 q = make_uint4(0u, 0u, 0u, 0u);
         if (i < n1) {
-            const uint2 b = qbits[i];
+            const uint4 b = qbits[i];
             const float4 r = qxyi[i];
             q = make_uint4(b.x, b.y, __float_as_uint(r.x), __float_as_uint(r.y));
             qorig = __float_as_int(r.z);
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
             const uint32_t e = pairq[lane];
             const int q = static_cast<int>(e & 63u);
             const int t = static_cast<int>(e >> 16);
-            const uint2 tb = tbits[t];
+            const uint4 tb = tbits[t];
             const float4 tr = txyi[t];  // x, y, original index of the train keypoint
             const uint4 qv = qtab[q];
             unsigned long long* key = keys[q];
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         const uint32_t cls = e >> 30;
         const int trow = valid ? static_cast<int>(e >> 6 & 0x1fffu) * 16 + 4 * static_cast<int>(e >> 4 & 3u) : 0;
         // everything is requested before anything is used
-        uint2 tb[4];
+        uint4 tb[4];    // compact bits, original index
         int rowpen[4];  // rows past the end of the train set (the last stage's padding) start their popcount at 2^20
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -858,16 +858,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         for (int u = 0; u < MM_QT; ++u) {
             const int q = u * 16 + ec;
             const uint2 qb = *reinterpret_cast<const uint2*>(&qtab[q]);
-            const uint32_t bestd = static_cast<uint32_t>(keys[q][0] >> 32);
+            const unsigned long long kbest = keys[q][0];
+            const uint32_t bestd = static_cast<uint32_t>(kbest >> 32);
             const uint32_t sec = static_cast<uint32_t>(keys[q][1] >> 32);
-            // A pair that merely TIES with `second` changes an output only if it also ties with `best` (it may have
-            // the lower index); with best < second it could at most replace the second key by an equal distance.
-            uint32_t bound = sec + ((bestd == sec && sec != 0x7fffffffu) ? 1u : 0u);
-            bound = cls == SP_FAR ? (bound + 1u) >> 1 : bound;
-            bound = valid ? bound : 0u;  // lanes without an entry queue nothing
+            // A pair that merely TIES with `second` changes an output only if it also ties with `best` AND has the
+            // lower original index (then it is the new best); with best < second it could at most replace the second
+            // key by an equal distance.  Sets with the same corner at several pyramid levels sit in that tie state
+            // for most queries: without the index test every further tie went to the pair list (87 pairs per query).
+            const bool tie = bestd == sec && sec != 0x7fffffffu;
+            const uint32_t below = tie ? static_cast<uint32_t>(kbest) : 0u;  // original indices below this one may tie
+            uint32_t b0 = sec, b1 = sec + (tie ? 1u : 0u);
+            if (cls == SP_FAR) {
+                b0 = (b0 + 1u) >> 1;
+                b1 = (b1 + 1u) >> 1;
+            }
+            b0 = valid ? b0 : 0u;  // lanes without an entry queue nothing
+            b1 = valid ? b1 : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int dist = __popc(qb.x ^ tb[r].x) + (__popc(qb.y ^ tb[r].y) + rowpen[r]);
+                const uint32_t bound = tb[r].z < below ? b1 : b0;
                 bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(dist - static_cast<int>(bound)), 31);
             }
         }

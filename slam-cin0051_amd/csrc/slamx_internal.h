@@ -218,7 +218,7 @@ struct MatchView {
     int live_bits;   // highest bit that can be set in any descriptor, plus one (0 = unknown)
     uint8_t* xdesc;  // scratch of the matrix-core path (match_scratch_bytes(): expanded descriptors in SPATIAL order and
                      // the tables below, carved out of the one allocation by match_scratch_carve()), or nullptr
-    uint2* sbits;    // [F][maxKp]  compact bits (first two words) of the keypoint at each sorted position
+    uint4* sbits;    // [F][maxKp]  {compact bits (first two words), original index, 0} of the keypoint at each sorted position
     float4* sxyi;    // [F][maxKp]  {x, y, original index (int bits), 0} of the keypoint at each sorted position
     float4* sbox;    // [F][maxKp / 64]  bounding box {min x, min y, max x, max y} of every stage (64 consecutive sorted
                      // positions); min x = +inf when a coordinate of the stage is not finite or beyond +-1e6
@@ -236,16 +236,16 @@ struct MatchView {
 inline int match_maxKp(int maxK) { return ((maxK + 63) / 64 + 1) * 64; }
 inline size_t match_scratch_bytes(size_t frames, int maxK) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
-    return frames * kp * (64 + sizeof(uint2) + sizeof(float4)) + frames * (kp / 64) * sizeof(float4) + frames * sizeof(int) + 256;
+    return frames * kp * (64 + sizeof(uint4) + sizeof(float4)) + frames * (kp / 64) * sizeof(float4) + frames * sizeof(int) + 256;
 }
 inline void match_scratch_carve(uint8_t* blob, size_t frames, int maxK, MatchView* mv) {
     const size_t kp = static_cast<size_t>(match_maxKp(maxK));
     mv->maxKp = static_cast<int>(kp);
     mv->xdesc = blob;
     mv->sxyi = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * 64);
-    mv->sbits = blob == nullptr ? nullptr : reinterpret_cast<uint2*>(blob + frames * kp * (64 + sizeof(float4)));
-    mv->sbox = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)));
-    mv->mfma_flag = blob == nullptr ? nullptr : reinterpret_cast<int*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint2)) +
+    mv->sbits = blob == nullptr ? nullptr : reinterpret_cast<uint4*>(blob + frames * kp * (64 + sizeof(float4)));
+    mv->sbox = blob == nullptr ? nullptr : reinterpret_cast<float4*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint4)));
+    mv->mfma_flag = blob == nullptr ? nullptr : reinterpret_cast<int*>(blob + frames * kp * (64 + sizeof(float4) + sizeof(uint4)) +
                                                                        frames * (kp / 64) * sizeof(float4));
 }
 void launch_match_consecutive(const MatchView& mv, int first_query_frame, int npairs, int first_train_frame,

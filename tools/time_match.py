@@ -27,9 +27,15 @@ def main():
     det = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), ctx)
     m = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), ctx)
     frames = np.stack([mod.synth_frame(bench.SEED, k, wl["rows"], wl["cols"], wl["n_rect"], wl["rmin"], wl["rmax"]) for k in range(B)])
-    batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
-    batch.upload(frames)
-    batch.detect_and_compute(B)
+    if "levels" in wl:  # the pyramid workload: merged keypoints of all levels in level 0's batch
+        pyr = mod.Pyramid(det, wl["rows"], wl["cols"], B, wl["levels"], wl["scale"], wl["max_cand"], wl["max_kp"])
+        batch = pyr.level(0)
+        batch.upload(frames)
+        pyr.detect_and_compute(B)
+    else:
+        batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
+        batch.upload(frames)
+        batch.detect_and_compute(B)
     for _ in range(2):
         batch.match_consecutive(m, B, use_keypoints=True, first_train_frame=B - 1)
     ctx.synchronize()
