@@ -689,6 +689,10 @@ def main(argv=None):
         for s in mod.STAGES:
             stage[s] += ms[s] / sets
 
+    if pyr is not None:
+        # level 0's BRIEF bracket of a pyramid also holds all of levels 1.. and the merges (slamx_pyramid_detect_and_compute)
+        stage["pyramid_levels_1_up"] = stage["brief"]
+        stage["brief"] = 0.0
     if rank == 0:
         frames_total = B * K * n_gpus
         fps = frames_total / elapsed
@@ -711,7 +715,7 @@ def main(argv=None):
             "moments": 43 * 48.0 * N + 8 * N + 4 * N + 32 * N, "trig": 0.0, "brief": 0.0,
             "emit": 24.0 * N,
         }
-        dom = max(stage, key=lambda k: stage[k])
+        dom = max((k for k in stage if k != "pyramid_levels_1_up"), key=lambda k: stage[k])  # (a kernel, not a bracket)
         kernel_of = {"fast": "fast_detect_kernel", "match": "match_kernel<%d,2>" % live_words, "blur": "blur_kernel",
                      "brief": "brief_kernel", "nms_build": "nms_greedy_kernel", "sort": "sort_kernel",
                      "moments": "describe_fused_kernel", "expand": "expand_kernel", "nms_rounds": "nms_round/finish_kernel"}
@@ -755,7 +759,7 @@ def main(argv=None):
         # every other kernel against its own roofline, for the record
         others = {}
         for k in stage:
-            if stage[k] <= 0:
+            if stage[k] <= 0 or k not in hbm_bytes and k != "match":
                 continue
             if k == "match":
                 o = 2.0 * live_words * N * N * B / (stage[k] * 1e-3) / 1e9
@@ -764,7 +768,7 @@ def main(argv=None):
                 g = hbm_bytes[k] * B / (stage[k] * 1e-3) / 1e9
                 others[k] = {"ms": stage[k], "achieved": g, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}
         # the HBM-bound front-end as a whole: B_fe = 4WH + 16M + 52N bytes per frame
-        fe_ms = sum(stage[k] for k in stage if k not in ("match", "emit"))
+        fe_ms = sum(stage[k] for k in stage if k not in ("match", "emit", "pyramid_levels_1_up"))
         b_fe = (4.0 * px + 16.0 * M + 52.0 * N) * B
         out = {
             "metric": METRIC,
@@ -785,7 +789,8 @@ def main(argv=None):
         }
         if pyr is not None:
             out["config"]["pyramid"] = {"levels": wl["levels"], "scale_factor": wl["scale"], "level_shapes": pyr.shapes,
-                                        "note": "stage_ms_per_step / roofline are level 0's kernels only (candidates_per_frame too); "
+                                        "note": "stage_ms_per_step / roofline are level 0's kernels (candidates_per_frame too) plus "
+                                                "pyramid_levels_1_up = everything of the other levels and the merges; "
                                                 "keypoints_per_frame and the matcher cover all levels"}
         if n_gpus == 1 and not args.no_pcie and pyr is None:
             batch.set_profiling(0, 1)
