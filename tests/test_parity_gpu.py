@@ -613,6 +613,37 @@ def test_batch_scan_choice_by_extent(slamx, oracle):
         assert_records_equal(b.download_matches(m, k), want, "frame %d (%d kp) vs %d (%d kp)" % (k, sizes[k], t, sizes[t]))
 
 
+@pytest.mark.parametrize("n1,n2,wide", [(3300, 3500, True), (1500, 3100, False), (2500, 900, True), (900, 2500, True)])
+def test_match_default_scan_rule_through_the_host_api(slamx, oracle, n1, n2, wide):
+    """slamx_matcher_match with the DEFAULT thresholds (no environment override): train sets of >= 3072 descriptors, and
+    wide ones of >= 768, go through the matrix-core scan in spatial order, the others through xor + popcount -- decided
+    on the device.  Descriptors with the detector's 46 live bits, duplicates and near-duplicates, keypoints on a 1080p
+    canvas (wide) or in a 600 x 500 corner of it; every result is the oracle's."""
+    rng = np.random.default_rng(n1 * 7 + n2)
+
+    def make(n):
+        d = np.zeros((n, 32), np.uint8)
+        raw = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+        raw &= np.frombuffer(np.uint64((1 << 46) - 1).tobytes(), np.uint8)
+        d[:, :8] = raw
+        return d
+
+    d1, d2 = make(n1), make(n2)
+    k = rng.integers(0, n2, n2 // 2)
+    d2[k] = d1[rng.integers(0, n1, len(k))]
+    d2[k[: len(k) // 2], 1] ^= np.uint8(1) << rng.integers(0, 8, len(k) // 2).astype(np.uint8)
+    k1 = np.zeros(n1, slamx.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, slamx.KEYPOINT_DTYPE)
+    for kp in (k1, k2):
+        kp["x"] = rng.integers(0, 1920 if wide else 600, len(kp))
+        kp["y"] = rng.integers(0, 1080 if wide else 500, len(kp))
+    for cfg in ((0, 1, 1, 0.8), (1, 20, 1, 0.5), (0, 1, 0, 0.0)):
+        m = slamx.FeatureMatcher(mcfg(slamx, *cfg))
+        mp = oracle.match_params(m.cfg)
+        assert_records_equal(m.match(d1, d2, k1, k2), oracle.match(d1, d2, k1, k2, mp), "with keypoints %s" % (cfg,))
+        assert_records_equal(m.match(d1, d2), oracle.match(d1, d2, None, None, mp), "without keypoints %s" % (cfg,))
+
+
 def test_match_spatial_scan_with_wild_coordinates(slamx, oracle, mfma_scan_for_all_sizes):
     """The spatial scan orders by keypoint position and classes stages by their bounding boxes; the RESULT must not
     depend on either: NaN coordinates (the reference's `distance > 500` is false for NaN: no penalty), coordinates of
