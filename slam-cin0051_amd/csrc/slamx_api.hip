@@ -2075,7 +2075,8 @@ int slamx_pyramid_create(slamx_detector* det, const slamx_batch_shape* shape, in
         p->ytab.push_back(nullptr);
         if (l > 0) {
             const slamx_batch* prev = p->levels[static_cast<size_t>(l) - 1];
-            const std::vector<uint32_t> xt = scale_table(sh.cols, prev->shape.cols);
+            std::vector<uint32_t> xt = scale_table(sh.cols, prev->shape.cols);
+            xt.resize((xt.size() + 3) / 4 * 4 + 4, xt.back());  // downscale_kernel reads four entries at a time
             const std::vector<uint32_t> yt = scale_table(sh.rows, prev->shape.rows);
             int rc2 = dev_alloc(&p->xtab[static_cast<size_t>(l)], xt.size());
             if (rc2 == SLAMX_OK) {
