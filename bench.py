@@ -166,13 +166,15 @@ def pmc_traffic_bytes(kernel, batch):
     return None
 
 
-def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=9, n_lanes=3):
+def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=12, n_lanes=4):
     """SURVEY.md 8d's END-TO-END definition of frames/s: the same step with every frame coming from the host AND every
     result going back to it.  The batch is copied from page-locked host memory (slamx_batch_upload_async) before it
     is processed; after it, a device-side pack step gathers the VALID keypoints, descriptors and matches of all its
     frames into one buffer and ONE copy brings them to page-locked memory (slamx_batch_download_packed_async; the
     copy is sized from the previous batch of the lane plus 10 %, the tail call covers a wrong guess).  n_lanes
-    contexts (streams, batches) rotate, so the copies of one batch overlap the kernels and copies of the others.
+    contexts (streams, batches) rotate, so the copies of one batch overlap the kernels and copies of the others
+    (measured: 22.7k / 24.4k / 24.8k frames/s with 2 / 3 / 4 of them; uploads alone reach 57 GB/s on this link, beside
+    the kernels 50-51).
     Reported next to `value`, never as it (the timed region of `value` starts with the frames resident in HBM, as
     the task's measurement rule says)."""
     pin = mod.pinned_array(frames.shape)
