@@ -391,14 +391,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     __shared__ int hist[4096];
     __shared__ int bbox[4];
     __shared__ int wave_tot[16];
-    // 32 KB used one of two ways: sets that fit the register cache (n <= 16384) keep the PERMUTATION here (sorted
-    // position -> keypoint, 16 bits each) and write their tables in sorted order, coalesced; larger sets scatter
-    // their records straight from the cell counters and keep the stage boxes here:
-    // min x, min y (floor), max x, max y (ceil); [0] = INT_MIN marks a bad stage
-    __shared__ int box_or_perm[8192];
-    static_assert(SP_MAX_STAGES * 4 <= 8192, "stage boxes must fit");
-    int (*stage_box)[4] = reinterpret_cast<int (*)[4]>(box_or_perm);
-    uint16_t* perm = reinterpret_cast<uint16_t*>(box_or_perm);
+    __shared__ int stage_box[SP_MAX_STAGES][4];  // min x, min y (floor), max x, max y (ceil); [0] = INT_MIN marks a bad stage
     const int f = first_frame + blockIdx.x;
     const int n = mv.n_kp[f];
     const int pred = f > 0 ? f - 1 : first_train_frame;
@@ -417,9 +410,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     for (int i = tid; i < 4096; i += 1024) {
         hist[i] = 0;
     }
-    constexpr int CK = 16;
-    const bool cached = n <= CK * 1024;
-    for (int i = tid; i < (cached ? 0 : nst); i += 1024) {
+    for (int i = tid; i < nst; i += 1024) {
         stage_box[i][0] = 0x7fffffff;
         stage_box[i][1] = 0x7fffffff;
         stage_box[i][2] = -0x7fffffff;
@@ -433,6 +424,8 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     // ONCE, all loads in flight together, and stay in registers through the three passes (box, cell counts, scatter);
     // larger sets read their keypoints again in every pass.  With one workgroup per frame the kernel is a chain of
     // memory round trips, not of arithmetic.
+    constexpr int CK = 16;
+    const bool cached = n <= CK * 1024;
     float kx[CK], ky[CK];
     if (use_kp && cached) {
 #pragma unroll
@@ -542,9 +535,21 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         __syncthreads();
     }
     const uint32_t* rows = reinterpret_cast<const uint32_t*>(mv.desc + static_cast<size_t>(f) * mv.maxK * mv.width);
-    // the records of sorted position p: compact bits, position record, expanded descriptor
-    auto emit = [&](int p, int i, float x, float y, uint32_t w0, uint32_t w1) {
+    // one keypoint -> its sorted position: compact bits, position record, expanded descriptor, stage box
+    auto place = [&](int i, float x, float y, uint32_t w0, uint32_t w1) {
+        const int p = use_kp ? atomicAdd(&hist[cell_of(x, y)], 1) : i;  // (the order inside a cell is immaterial)
         const unsigned long long bits = static_cast<unsigned long long>(w0) | (static_cast<unsigned long long>(w1) << 32);
+        if (use_kp) {
+            int* box = stage_box[p >> 6];
+            if (coord_ok(x) && coord_ok(y)) {
+                atomicMin(&box[0], static_cast<int>(floorf(x)));
+                atomicMin(&box[1], static_cast<int>(floorf(y)));
+                atomicMax(&box[2], static_cast<int>(ceilf(x)));
+                atomicMax(&box[3], static_cast<int>(ceilf(y)));
+            } else {
+                atomicMin(&box[0], -0x7fffffff - 1);  // poisons the stage: it gets no class
+            }
+        }
         sb[p] = make_uint4(w0, w1, static_cast<uint32_t>(i), 0u);
         sx[p] = make_float4(x, y, __int_as_float(i), 0.0f);
         uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
@@ -563,91 +568,35 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
             o[quarter] = e;
         }
     };
+    if (cached) {
+        uint32_t w0[CK], w1[CK];
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {  // the descriptor words of all the thread's keypoints first
+            const int i = tid + 1024 * j;
+            w0[j] = i < n ? rows[static_cast<size_t>(i) * stride] : 0u;
+            w1[j] = (i < n && stride > 1) ? rows[static_cast<size_t>(i) * stride + 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const int i = tid + 1024 * j;
+            if (i < n) {
+                place(i, use_kp ? kx[j] : 0.0f, use_kp ? ky[j] : 0.0f, w0[j], w1[j]);
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            place(i, use_kp ? kps[i].x : 0.0f, use_kp ? kps[i].y : 0.0f, rows[static_cast<size_t>(i) * stride],
+                  stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u);
+        }
+    }
     // padding up to a whole stage: distance 127 + |q|, which no bound below 127 lets through (and the slow path
     // checks the index anyway)
-    auto emit_padding = [&](int p) {
+    for (int p = n + tid; p < nst * SP_STAGE; p += 1024) {
         uint4* o = reinterpret_cast<uint4*>(xd + static_cast<size_t>(p) * 64);
         o[0] = o[1] = o[2] = make_uint4(0u, 0u, 0u, 0u);
         o[3] = make_uint4(0u, 0u, 0u, 0x017f0000u);
         sb[p] = make_uint4(0u, 0u, 0xffffffffu, 0u);
         sx[p] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
-    };
-    const float4 no_box = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
-    if (cached) {
-        if (use_kp) {
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const int i = tid + 1024 * j;
-                if (i < n) {  // (the order inside a cell is immaterial)
-                    perm[atomicAdd(&hist[cell_of(kx[j], ky[j])], 1)] = static_cast<uint16_t>(i);
-                }
-            }
-            __syncthreads();
-        }
-        // sorted positions tid, tid + 1024, ...: a wave writes the 64 positions of ONE stage per trip -- 1 KB of
-        // compact bits, 1 KB of positions and 4 KB of expanded descriptors, each contiguous -- and reduces the
-        // stage's box in registers
-        for (int p = tid; p < nst * SP_STAGE; p += 1024) {
-            const bool valid = p < n;
-            const int i = valid ? (use_kp ? static_cast<int>(perm[p]) : p) : 0;
-            float x = 0.0f, y = 0.0f;
-            uint32_t w0 = 0u, w1 = 0u;
-            if (valid) {
-                if (use_kp) {
-                    x = kps[i].x;
-                    y = kps[i].y;
-                }
-                w0 = rows[static_cast<size_t>(i) * stride];
-                w1 = stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u;
-            }
-            if (use_kp) {
-                const bool fine = coord_ok(x) && coord_ok(y);
-                int lx = (valid && fine) ? static_cast<int>(floorf(x)) : 0x7fffffff;
-                int ly = (valid && fine) ? static_cast<int>(floorf(y)) : 0x7fffffff;
-                int hx = (valid && fine) ? static_cast<int>(ceilf(x)) : -0x7fffffff;
-                int hy = (valid && fine) ? static_cast<int>(ceilf(y)) : -0x7fffffff;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    lx = min(lx, __shfl_xor(lx, d));
-                    ly = min(ly, __shfl_xor(ly, d));
-                    hx = max(hx, __shfl_xor(hx, d));
-                    hy = max(hy, __shfl_xor(hy, d));
-                }
-                const bool poisoned = __any(valid && !fine);  // one bad coordinate: the stage gets no class
-                if ((tid & 63) == 0) {
-                    sc[p >> 6] = (!poisoned && lx <= hx) ? make_float4(static_cast<float>(lx), static_cast<float>(ly),
-                                                                      static_cast<float>(hx), static_cast<float>(hy))
-                                                         : no_box;
-                }
-            } else if ((tid & 63) == 0) {
-                sc[p >> 6] = no_box;
-            }
-            if (valid) {
-                emit(p, i, x, y, w0, w1);
-            } else {
-                emit_padding(p);
-            }
-        }
-        return;
-    }
-    for (int i = tid; i < n; i += 1024) {
-        const float x = use_kp ? kps[i].x : 0.0f, y = use_kp ? kps[i].y : 0.0f;
-        const int p = use_kp ? atomicAdd(&hist[cell_of(x, y)], 1) : i;
-        if (use_kp) {
-            int* box = stage_box[p >> 6];
-            if (coord_ok(x) && coord_ok(y)) {
-                atomicMin(&box[0], static_cast<int>(floorf(x)));
-                atomicMin(&box[1], static_cast<int>(floorf(y)));
-                atomicMax(&box[2], static_cast<int>(ceilf(x)));
-                atomicMax(&box[3], static_cast<int>(ceilf(y)));
-            } else {
-                atomicMin(&box[0], -0x7fffffff - 1);  // poisons the stage: it gets no class
-            }
-        }
-        emit(p, i, x, y, rows[static_cast<size_t>(i) * stride], stride > 1 ? rows[static_cast<size_t>(i) * stride + 1] : 0u);
-    }
-    for (int p = n + tid; p < nst * SP_STAGE; p += 1024) {
-        emit_padding(p);
     }
     __syncthreads();
     for (int s2 = tid; s2 < nst; s2 += 1024) {
@@ -655,7 +604,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         const bool good = use_kp && box[0] != -0x7fffffff - 1 && box[0] <= box[2];
         sc[s2] = good ? make_float4(static_cast<float>(box[0]), static_cast<float>(box[1]), static_cast<float>(box[2]),
                                     static_cast<float>(box[3]))
-                      : no_box;
+                      : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
     }
 }
 
