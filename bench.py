@@ -170,11 +170,12 @@ def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=12
     """SURVEY.md 8d's END-TO-END definition of frames/s: the same step with every frame coming from the host AND every
     result going back to it.  The batch is copied from page-locked host memory (slamx_batch_upload_async) before it
     is processed; after it, a device-side pack step gathers the VALID keypoints, descriptors and matches of all its
-    frames into one buffer and ONE copy brings them to page-locked memory (slamx_batch_download_packed_async; the
-    copy is sized from the previous batch of the lane plus 10 %, the tail call covers a wrong guess).  n_lanes
-    contexts (streams, batches) rotate, so the copies of one batch overlap the kernels and copies of the others
-    (measured: 22.7k / 24.4k / 24.8k frames/s with 2 / 3 / 4 of them; uploads alone reach 57 GB/s on this link, beside
-    the kernels 50-51).
+    frames and stores them into page-locked memory (slamx_batch_download_packed_async: the pack kernel's own stores
+    over PCIe, or with SLAMX_PACKED_DOWNLOAD=copy one queued copy; the host range is sized from the previous batch of
+    the lane plus 10 %, the tail call covers a wrong guess).  n_lanes contexts (streams, batches) rotate, so the copies
+    of one batch overlap the kernels and copies of the others (measured: 22.7k / 24.4k / 24.8k frames/s with 2 / 3 / 4
+    of them).  tools/e2e_breakdown.py cuts the step short stage by stage: uploads alone 57.6 GB/s (27.8k frames/s,
+    the link), + detect 53.8, + match 52.9, + the 60 MB of results 50.2 GB/s -- the same with either download form.
     Reported next to `value`, never as it (the timed region of `value` starts with the frames resident in HBM, as
     the task's measurement rule says)."""
     pin = mod.pinned_array(frames.shape)
@@ -226,7 +227,18 @@ def pcie_inclusive(mod, wl, B, frames, main, local_rank, use_keypoints, steps=12
     gb = steps * frames.nbytes / 1e9
     kp_first, m_first, status, kps, desc, matches = mod.unpack_results(outs[0])
     assert kp_first[-1] > 0 and m_first[-1] > 0 and not status.any()  # the results did arrive
+    # the same lanes with the frames left where they are: what two batches in flight (two streams) add to the
+    # HBM-resident rate of `value`, which queues its steps on one stream
+    t1 = time.perf_counter()
+    for i in range(2 * steps):
+        _, b, m = lanes[i % 2]
+        b.detect_and_compute(B)
+        b.match_consecutive(m, B, use_keypoints=use_keypoints, first_train_frame=B - 1)
+    for lane in lanes[:2]:
+        lane[0].synchronize()
+    two_in_flight = 2 * steps * B / (time.perf_counter() - t1)
     return {"value": steps * B / dt, "unit": "frames/s", "steps": steps, "contexts": len(lanes),
+            "hbm_resident_two_batches_in_flight": two_in_flight,
             "host_to_hbm_GBps": gb / dt, "hbm_to_host_GBps": total_out / 1e9 / dt,
             "result_bytes_per_frame": total_out / (steps * B), "tail_fetches": tails,
             "note": "every batch uploaded from pinned host memory before it is processed; its valid results (counts, "

@@ -231,10 +231,13 @@ int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoi
  *     int32 match_first[nframes + 1]   the same for the matches (all zero when no matcher has run on the batch)
  *     int32 status[nframes]            per-frame overflow bits (0 = complete)
  *     slamx_keypoint kps[total_keypoints]; uint8 desc[total_keypoints][width]; slamx_match matches[total_matches]
- * The total is only known on the device, so the caller chooses `bytes` (at most slamx_batch_packed_bound(), the
- * worst case; a streaming caller passes a little more than the previous batch needed).  After synchronising it
- * reads header.total_bytes: if that exceeds `bytes`, slamx_batch_download_packed_tail fetches [from, total_bytes)
- * of the same packed buffer (synchronous), valid until the next pack of this batch. */
+ * `host` is page-locked memory (slamx_host_alloc) of at least `bytes` bytes; at most `bytes` of it are written.  By
+ * default the pack kernel stores the results there itself, so only header.total_bytes cross PCIe even when `bytes`
+ * is the worst case (slamx_batch_packed_bound()); with SLAMX_PACKED_DOWNLOAD=copy the first `bytes` of the packed
+ * buffer are copied, whatever they hold, and a streaming caller passes a little more than the previous batch needed.
+ * After synchronising the caller reads header.total_bytes: if that exceeds `bytes`,
+ * slamx_batch_download_packed_tail fetches the rest of the same packed buffer (synchronous), valid until the next pack
+ * of this batch. */
 typedef struct slamx_packed_header {
     int32_t nframes, width, total_keypoints, total_matches;
     int64_t first_off, mfirst_off, status_off, kps_off, desc_off, matches_off, total_bytes;

@@ -7,7 +7,9 @@
 // bytes that are results (262 KB per 1080p frame for ~116 KB valid).  Here: a prefix over the per-frame counts
 // (one workgroup), then a copy kernel that moves every frame's valid prefix to its packed position.  HBM-bound
 // byte moving (read + write of the valid bytes, dword loads / stores, coalesced); layout in include/slamx.h
-// (slamx_packed_header).
+// (slamx_packed_header).  When the caller's buffer is page-locked memory the device can address, the copy kernel
+// writes every dword there as well -- the results then cross PCIe as the kernel's own stores, beside the uploads of
+// the next batches (a copy-engine download was measured to take its turn with them: 1.3 ms per 512 frames).
 #include "slamx_internal.h"
 
 namespace slamx {
@@ -95,17 +97,33 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restric
     }
 }
 
-__device__ __forceinline__ void copy_dwords(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n, int tid,
-                                            int nthreads) {
+// dst (HBM) always; `mirror` (the caller's page-locked buffer, written over PCIe by the kernel itself) where it is given
+// and the dword lies inside its first mirror_bytes
+__device__ __forceinline__ void copy_dwords(const uint32_t* __restrict__ src, uint8_t* __restrict__ pack, long long off, int n,
+                                            int tid, int nthreads, uint8_t* __restrict__ mirror, long long mirror_bytes) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(pack + off);
+    if (mirror == nullptr) {
+        for (int i = tid; i < n; i += nthreads) {
+            dst[i] = src[i];
+        }
+        return;
+    }
+    uint32_t* far = reinterpret_cast<uint32_t*>(mirror + off);
+    const long long room = (mirror_bytes - off) / 4;  // whole dwords of the mirror from `off` on (may be <= 0)
     for (int i = tid; i < n; i += nthreads) {
-        dst[i] = src[i];
+        const uint32_t v = src[i];
+        dst[i] = v;
+        if (i < room) {
+            far[i] = v;
+        }
     }
 }
 
 // grid (blocks per frame, frames): a frame's valid keypoints, descriptors and matches to their packed positions
 __global__ __launch_bounds__(256) void pack_copy_kernel(const slamx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                         const slamx_match* __restrict__ matches, int maxK, int width,
-                                                        uint8_t* __restrict__ pack) {
+                                                        uint8_t* __restrict__ pack, uint8_t* __restrict__ mirror,
+                                                        long long mirror_bytes) {
     const slamx_packed_header* h = reinterpret_cast<const slamx_packed_header*>(pack);
     const int f = blockIdx.y;
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -114,23 +132,46 @@ __global__ __launch_bounds__(256) void pack_copy_kernel(const slamx_keypoint* __
     const int* m_first = reinterpret_cast<const int*>(pack + h->mfirst_off);
     const int k0 = kp_first[f], nk = kp_first[f + 1] - k0;
     const int m0 = m_first[f], nm = m_first[f + 1] - m0;
+    if (mirror != nullptr && f == 0) {  // the header and the per-frame tables (written by pack_offsets_kernel): [0, kps_off)
+        const long long head = min(h->kps_off, mirror_bytes) / 4;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(pack);
+        uint32_t* far = reinterpret_cast<uint32_t*>(mirror);
+        for (long long i = tid; i < head; i += nthreads) {
+            far[i] = src[i];
+        }
+    }
+    if (f == 0 && tid < 48) {  // the (< 16-byte) gaps behind the three sections: zero, so that the buffer is a function of the results
+        const int g = tid >> 4;
+        const long long tk = kp_first[gridDim.y], tm = m_first[gridDim.y];
+        const long long from = g == 0 ? h->kps_off + 20LL * tk : g == 1 ? h->desc_off + width * tk : h->matches_off + 12LL * tm;
+        const long long to = g == 0 ? h->desc_off : g == 1 ? h->matches_off : h->total_bytes;
+        const long long at = from + (tid & 15);
+        if (at < to) {
+            pack[at] = 0;
+            if (mirror != nullptr && at < mirror_bytes) {
+                mirror[at] = 0;
+            }
+        }
+    }
     // keypoint records are 5 dwords, matches 3: whole dwords, aligned on both sides (sections start 16-byte aligned)
-    copy_dwords(reinterpret_cast<const uint32_t*>(kps + static_cast<size_t>(f) * maxK),
-                reinterpret_cast<uint32_t*>(pack + h->kps_off) + 5LL * k0, 5 * nk, tid, nthreads);
+    copy_dwords(reinterpret_cast<const uint32_t*>(kps + static_cast<size_t>(f) * maxK), pack, h->kps_off + 20LL * k0, 5 * nk, tid,
+                nthreads, mirror, mirror_bytes);
     if ((width & 3) == 0) {
-        copy_dwords(reinterpret_cast<const uint32_t*>(desc + static_cast<size_t>(f) * maxK * width),
-                    reinterpret_cast<uint32_t*>(pack + h->desc_off) + static_cast<long long>(width / 4) * k0, (width / 4) * nk,
-                    tid, nthreads);
+        copy_dwords(reinterpret_cast<const uint32_t*>(desc + static_cast<size_t>(f) * maxK * width), pack,
+                    h->desc_off + static_cast<long long>(width) * k0, (width / 4) * nk, tid, nthreads, mirror, mirror_bytes);
     } else {
         const uint8_t* s = desc + static_cast<size_t>(f) * maxK * width;
-        uint8_t* d = pack + h->desc_off + static_cast<long long>(width) * k0;
+        const long long off = h->desc_off + static_cast<long long>(width) * k0;
         for (int i = tid; i < nk * width; i += nthreads) {
-            d[i] = s[i];
+            pack[off + i] = s[i];
+            if (mirror != nullptr && off + i < mirror_bytes) {
+                mirror[off + i] = s[i];
+            }
         }
     }
     if (matches != nullptr && nm > 0) {
-        copy_dwords(reinterpret_cast<const uint32_t*>(matches + static_cast<size_t>(f) * maxK),
-                    reinterpret_cast<uint32_t*>(pack + h->matches_off) + 3LL * m0, 3 * nm, tid, nthreads);
+        copy_dwords(reinterpret_cast<const uint32_t*>(matches + static_cast<size_t>(f) * maxK), pack, h->matches_off + 12LL * m0,
+                    3 * nm, tid, nthreads, mirror, mirror_bytes);
     }
 }
 
@@ -148,9 +189,10 @@ size_t packed_bound_bytes(int nframes, int maxK, int width, bool with_matches) {
 }
 
 void launch_pack_results(const BatchView& v, const slamx_match* matches, const int* n_matches, int nframes, uint8_t* pack,
-                         hipStream_t stream) {
+                         hipStream_t stream, uint8_t* mirror, size_t mirror_bytes) {
     hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, stream, v.n_kp, n_matches, v.status, nframes, v.width, pack);
-    hipLaunchKernelGGL(pack_copy_kernel, dim3(4, nframes), dim3(256), 0, stream, v.kps, v.desc, matches, v.maxK, v.width, pack);
+    hipLaunchKernelGGL(pack_copy_kernel, dim3(4, nframes), dim3(256), 0, stream, v.kps, v.desc, matches, v.maxK, v.width, pack,
+                       mirror, static_cast<long long>(mirror_bytes));
 }
 
 }  // namespace slamx

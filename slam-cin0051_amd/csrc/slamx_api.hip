@@ -1129,6 +1129,22 @@ int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, s
         b->pack_bytes = cap;
     }
     hipStream_t s = b->det->ctx->stream;
+    // Page-locked memory the device can address (slamx_host_alloc's always is): the pack kernel stores the results
+    // there itself, beside its HBM copy -- no copy-engine transfer, which takes its turn with the uploads of the
+    // batches behind.  SLAMX_PACKED_DOWNLOAD=copy keeps the pack + hipMemcpyAsync form.
+    const char* mode = std::getenv("SLAMX_PACKED_DOWNLOAD");
+    void* mapped = nullptr;
+    if ((mode == nullptr || std::strcmp(mode, "copy") != 0) &&
+        (hipHostGetDevicePointer(&mapped, host, 0) != hipSuccess || mapped == nullptr)) {
+        (void)hipGetLastError();
+        mapped = nullptr;
+    }
+    if (mapped != nullptr) {
+        launch_pack_results(b->v, b->matches, b->n_matches, nframes, b->pack, s, static_cast<uint8_t*>(mapped),
+                            std::min(bytes, bound));
+        HIP_TRY(hipGetLastError());
+        return SLAMX_OK;
+    }
     launch_pack_results(b->v, b->matches, b->n_matches, nframes, b->pack, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, b->pack, std::min(bytes, bound), hipMemcpyDeviceToHost, s));
@@ -1147,6 +1163,7 @@ int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, si
     if (total > b->pack_bytes || total > host_capacity) {
         return fail(SLAMX_ERR_CAPACITY, "download_packed_tail: the host buffer is smaller than header.total_bytes");
     }
+    from &= ~static_cast<size_t>(15);  // (the kernel-written form leaves a cut dword out: start at the section grain)
     if (from < total) {
         HIP_TRY(hipMemcpy(static_cast<uint8_t*>(host) + from, b->pack + from, total - from, hipMemcpyDeviceToHost));
     }

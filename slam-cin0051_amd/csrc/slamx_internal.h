@@ -270,7 +270,7 @@ void launch_downscale(const BatchView& src, const BatchView& dst, const uint32_t
                       hipStream_t stream);
 size_t packed_bound_bytes(int nframes, int maxK, int width, bool with_matches);
 void launch_pack_results(const BatchView& v, const slamx_match* matches, const int* n_matches, int nframes, uint8_t* pack,
-                         hipStream_t stream);
+                         hipStream_t stream, uint8_t* mirror = nullptr, size_t mirror_bytes = 0);
 void launch_merge_level(const BatchView& src, const BatchView& dst, float scale, int nframes, hipStream_t stream);
 
 // sliding-window Gauss-Newton (gn.hip): device pointers of a batch of windows

@@ -878,11 +878,17 @@ def test_batch_download_results_async(slamx, oracle):
         b.download_results_async(3, (np.empty((3, 1024), slamx.KEYPOINT_DTYPE),) + bufs[1:])
 
 
-def test_batch_download_packed_async(slamx, oracle):
+@pytest.mark.parametrize("mode", ["", "copy"])
+def test_batch_download_packed_async(slamx, oracle, monkeypatch, mode):
     """The packed streaming download: a device-side pack step gathers the valid keypoints / descriptors / matches of
-    all frames into one buffer (prefix of the counts + copy kernel), ONE queued copy brings it to page-locked
-    memory; frames with different counts, an empty frame in the middle, the tail call when the first copy was cut
-    short, and a batch no matcher has run on."""
+    all frames into one buffer (prefix of the counts + copy kernel) and brings it to page-locked memory -- the copy
+    kernel's own stores over PCIe (default) or one queued copy (SLAMX_PACKED_DOWNLOAD=copy); frames with different
+    counts, an empty frame in the middle, the tail call when the host buffer was cut short, and a batch no matcher
+    has run on."""
+    if mode:
+        monkeypatch.setenv("SLAMX_PACKED_DOWNLOAD", mode)
+    else:
+        monkeypatch.delenv("SLAMX_PACKED_DOWNLOAD", raising=False)
     d = slamx.FeatureDetector(cfg_of(slamx, window=8))
     Pp = oracle.det_params(d.cfg)
     m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.8))
@@ -925,6 +931,7 @@ def test_batch_download_packed_async(slamx, oracle):
     have = b.download_packed_async(F, short, total // 3)
     d.ctx.synchronize()
     assert slamx.packed_header(short)["total_bytes"] == total and have < total
+    assert not short[have:].any()  # nothing beyond what the caller allowed
     b.fetch_packed_tail(short, have)
     assert np.array_equal(short[:total], buf[:total])
     with pytest.raises(ValueError):  # pageable memory is refused
