@@ -327,6 +327,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // No LDS stage and no barrier: a wave reads its A operands straight from global memory (a tile = 16 consecutive
 // expanded descriptors = 1 KB, one dwordx4 per lane, the next stage's four tiles in flight while the current
 // stage's 16 MFMAs run); the expanded train set of a frame (0.7 MB at 10k keypoints) is L2-resident.
+#ifdef SLAMX_MATCH_CLOCKS  // development build only (make FLAGS_match=-DSLAMX_MATCH_CLOCKS): where a wave of the spatial scan spends its time
+__device__ unsigned long long sp_clocks[8];  // waves, then s_memtime ticks (100 MHz): setup, stage order, startup tiles, steady scan, of it slow path, drain
+#define SP_CLK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define SP_CLK(v) ((void)0)
+#endif
 #ifdef SLAMX_MATCH_STATS  // development build only (make FLAGS_match=-DSLAMX_MATCH_STATS): slow-path volume of the spatial scan
 __device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued, pairs that reached the keys, stages
 #define SP_STAT(i, v) sp_stat_##i += (v)
@@ -336,6 +342,7 @@ __device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued
 constexpr int SP_STAGE = 64;          // trains per stage (4 tiles of 16)
 constexpr int SP_MAX_STAGES = 1025;   // maxK <= 65536
 constexpr int SP_BUCKETS = 128;       // stage order: counting sort on the centre distance in 32-px steps
+constexpr int SP_SEED_STAGES = 2;      // leading near stages scanned densely, a query per lane, before the filter has a bound
 constexpr int SP_STARTUP_TILES = 8;   // the first tiles are filtered one by one (the bound still moves with every tile)
 constexpr int SP_FIFO = 384;          // tile entries: < 64 waiting + the 4 x 64 pushes of a stage (+ 64 slack)
 constexpr int SP_PAIRS = 192;         // pair entries: < 64 waiting + 64 pushes (+ 64 slack)
@@ -624,6 +631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
     // (A resident set of workgroups looping over the work items instead of one workgroup per item was tried: the outer
     // loop cost 33 registers and spilled scalars into the scan -- 4.3 vs 2.2 ms at 10k keypoints.)
     const int lane = threadIdx.x;
+    SP_CLK(clk_begin);
     int pair, qblock, split;
     {
         const int id = static_cast<int>(blockIdx.x);
@@ -708,6 +716,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
             C[u] = v4i{nb, nb, nb, nb};
         }
     };
+    SP_CLK(clk_setup);
     // ---- the order of the stages (nearest box centre first: a counting sort on the distance in 32-px steps) and
     //      their classes
     const int nst = (n2 + SP_STAGE - 1) / SP_STAGE;
@@ -785,6 +794,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         }
     }
     wave_lds_fence();
+    SP_CLK(clk_order);
+#ifdef SLAMX_MATCH_CLOCKS
+    unsigned long long clk_slow = 0;
+#endif
     int tail = 0;   // tile entries waiting (wave-uniform, kept in an SGPR)
     int ptail = 0;  // pair entries waiting
 #ifdef SLAMX_MATCH_STATS
@@ -952,19 +965,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
     };
     auto slow_path = [&](int need) {  // works the list off while it holds at least `need` entries
         if (tail >= need) {
+            SP_CLK(c0);
             do {
                 work(min(64, tail));
             } while (tail >= need);
             refresh_bounds();
+#ifdef SLAMX_MATCH_CLOCKS
+            clk_slow += __builtin_amdgcn_s_memtime() - c0;
+#endif
         }
     };
     // The scan: the first SP_STARTUP_TILES tiles one by one (operand straight from memory: the bound moves with every
     // tile there), then stage by stage -- a tile's operand registers are refilled with the NEXT stage's tile as soon
     // as its MFMAs are issued, so four tile loads are always in flight -- first the stages that are not far, then,
     // with the halved bound, the far ones; then the list drains.
+    // ---- seed: the leading NEAR stages of the share (at most SP_SEED_STAGES: the 128 nearest trains), a query per
+    //      lane against every train of the stage, both keys in registers.  No penalty in a near stage, so a distance is
+    //      at most 64 and (distance << 16 | original index) orders like the 64-bit key: best = min, second = median of
+    //      (best, second, new) -- 7 vector instructions per train (the rows come through scalar loads), where the same
+    //      trains through the filter cost three times that: nothing is below a bound that does not exist yet, so every
+    //      pair went through both lists.  A padding row carries original index 0xffffffff: its key is "none" by itself.
+    int k_seed = 0;
+    {
+        uint32_t kb = 0xffffffffu, ks = 0xffffffffu;
+        const uint2 qown = *reinterpret_cast<const uint2*>(&qtab[lane]);
+        while (k_seed < min(SP_SEED_STAGES, nmine)) {
+            const uint32_t sc = stage_at(k_seed);
+            if ((sc >> 14) != SP_NEAR) {
+                break;
+            }
+            const uint4* rows = tbits + static_cast<size_t>(sc & 0x3fffu) * SP_STAGE;
+            for (int j0 = 0; j0 < SP_STAGE; j0 += 8) {
+                uint4 tb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    tb[u] = rows[j0 + u];  // (wave-uniform address)
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t dist = static_cast<uint32_t>(__popc(qown.x ^ tb[u].x) + __popc(qown.y ^ tb[u].y));
+                    const uint32_t k = (dist << 16) | tb[u].z;
+                    const uint32_t lo = min(kb, k);
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(ks) : "v"(kb), "v"(ks), "v"(k));
+                    kb = lo;
+                }
+            }
+            ++k_seed;
+        }
+        if (k_seed > 0) {
+            if (qorig >= 0) {
+                auto wide = [](uint32_t k) {
+                    return k == 0xffffffffu ? MM_KEY_NONE
+                                            : (static_cast<unsigned long long>(k >> 16) << 32) | static_cast<unsigned long long>(k & 0xffffu);
+                };
+                keys[lane][0] = wide(kb);
+                keys[lane][1] = wide(ks);
+            }
+            wave_lds_fence();
+            refresh_bounds();
+        }
+    }
+    // without a seed (the nearest stage is not near: sparse or spread-out sets) the first SP_STARTUP_TILES tiles go
+    // through the filter one by one
     const int ntiles = nmine * 4;
-    const int startup = min(SP_STARTUP_TILES, ntiles);
-    const int k_steady = startup / 4;  // first stage of the steady part (SP_STARTUP_TILES is a multiple of 4)
+    const int startup = k_seed > 0 ? 0 : min(SP_STARTUP_TILES, ntiles);
+    const int k_steady = k_seed > 0 ? k_seed : startup / 4;  // first stage of the steady part (SP_STARTUP_TILES is a multiple of 4)
     for (int it = 0; it < startup; ++it) {
         const uint32_t sc = stage_at(it >> 2);
         const bool far = (sc >> 14) == SP_FAR;
@@ -976,6 +1041,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         filter_tile(A1, (sc & 0x3fffu) * 4u + static_cast<uint32_t>(it & 3), sc >> 14);
         slow_path(64);
     }
+    SP_CLK(clk_startup);
+#ifdef SLAMX_MATCH_CLOCKS
+    const unsigned long long clk_slow_startup = clk_slow;
+#endif
     v4i A[4];
     if (k_steady < nmine) {
         const uint8_t* p0 = tile_ptr(stage_at(k_steady));
@@ -1011,11 +1080,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ma
         }
         steady(k_far, nmine);
     }
+    SP_CLK(clk_steady);
     slow_path(1);
     while (ptail > 0) {
         settle(min(64, ptail));
     }
     wave_lds_fence();
+#ifdef SLAMX_MATCH_CLOCKS
+    if (lane == 0) {
+        const unsigned long long clk_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(&sp_clocks[0], 1ull);
+        atomicAdd(&sp_clocks[1], clk_setup - clk_begin);
+        atomicAdd(&sp_clocks[2], clk_order - clk_setup);
+        atomicAdd(&sp_clocks[3], clk_startup - clk_order);
+        atomicAdd(&sp_clocks[4], clk_steady - clk_startup);
+        atomicAdd(&sp_clocks[5], clk_slow - clk_slow_startup);
+        atomicAdd(&sp_clocks[6], clk_end - clk_steady);
+        atomicAdd(&sp_clocks[7], clk_slow_startup);
+    }
+#endif
 #ifdef SLAMX_MATCH_STATS
     if (lane == 0) {
         atomicAdd(&sp_stats[0], 1ull);
@@ -1169,6 +1252,14 @@ void launch_words(const MatchView& mv, int first_query_frame, int npairs, int fi
 
 }  // namespace
 
+#ifdef SLAMX_MATCH_CLOCKS
+extern "C" void slamx_debug_match_clocks(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_clocks), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sp_clocks), z, sizeof(z));
+}
+#endif
 #ifdef SLAMX_MATCH_STATS
 extern "C" void slamx_debug_match_stats(unsigned long long* out) {
     (void)hipDeviceSynchronize();

@@ -2,7 +2,8 @@
 """Times the match stage alone on a bench workload's frames (detect + describe once, then N match calls).
     python tools/time_match.py <workload> [batch] [reps] [n_rect]      (n_rect: another corner density for the same frame size)
 The matcher's environment switch applies: SLAMX_MATCH_MFMA_MIN_KEYPOINTS (0: the matrix-core scan for every
-pair, 100000: the popcount scan).  A library built with FLAGS_match=-DSLAMX_MATCH_STATS also reports the slow-path volume."""
+pair, 100000: the popcount scan).  A library built with FLAGS_match=-DSLAMX_MATCH_STATS also reports the slow-path volume,
+one built with FLAGS_match=-DSLAMX_MATCH_CLOCKS where a wave spends its time."""
 import importlib.util
 import os
 import sys
@@ -60,6 +61,17 @@ def main():
               % (out[0], out[1] / w / 64 * 4, out[2] / w / 64, out[3] / w / 64, out[4] / w))
         print("per wave: %.1f tile entries, %.1f queue rounds, %.1f stage-kind flips, %.1f settle calls" % (
             out[1] / w, out[5] / w, out[6] / w, out[7] / w))
+    if hasattr(lib, "slamx_debug_match_clocks"):  # development build (-DSLAMX_MATCH_CLOCKS)
+        import ctypes
+
+        out = (ctypes.c_ulonglong * 8)()
+        lib.slamx_debug_match_clocks(out)
+        batch.match_consecutive(m, B, use_keypoints=True, first_train_frame=B - 1)
+        lib.slamx_debug_match_clocks(out)
+        w = max(out[0], 1)
+        us = [out[i] / w / 100.0 for i in range(8)]  # s_memtime: 100 MHz
+        print("spatial scan, per wave (%d waves): setup %.1f us, stage order %.1f, startup tiles %.1f (slow path %.1f), steady scan %.1f "
+              "(slow path %.1f), drain %.1f" % (out[0], us[1], us[2], us[3], us[7], us[4], us[5], us[6]))
     print("checksum", int(nm.sum()), int(batch.download_matches(m, B - 1)["trainIdx"].astype(np.int64).sum()))
 
 
