@@ -340,6 +340,10 @@ __device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued
 #define SP_STAT(i, v) ((void)0)
 #endif
 constexpr int SP_STAGE = 64;          // trains per stage (4 tiles of 16)
+#ifndef SLAMX_SP_CELL
+#define SLAMX_SP_CELL 32
+#endif
+constexpr int SP_CELL = SLAMX_SP_CELL;  // keypoints per cell of the spatial order, on average
 constexpr int SP_MAX_STAGES = 1025;   // maxK <= 65536
 constexpr int SP_BUCKETS = 128;       // stage order: counting sort on the centre distance in 32-px steps
 constexpr int SP_SEED_STAGES = 2;      // leading near stages scanned densely, a query per lane, before the filter has a bound
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
         y0 = bbox[1];
         const float w = static_cast<float>(bbox[2] - x0 + 1), h = static_cast<float>(bbox[3] - y0 + 1);
         // cells of about one stage's worth of keypoints, at most 64 x 64 of them
-        side = max(1, static_cast<int>(sqrtf(w * h * static_cast<float>(SP_STAGE) / static_cast<float>(max(n, 1)))));
+        side = max(1, static_cast<int>(sqrtf(w * h * static_cast<float>(SP_CELL) / static_cast<float>(max(n, 1)))));
         side = max(side, max(static_cast<int>(w) / 64 + 1, static_cast<int>(h) / 64 + 1));
         ncx = min(64, static_cast<int>(w) / side + 1);
         ncy = min(64, static_cast<int>(h) / side + 1);

@@ -207,6 +207,41 @@ def test_detect_dense_candidates(slamx, oracle, window, arc, t):
     assert_records_equal(d.detect(img), oracle.detect(img, Pp), "dense detect window=%d arc=%d t=%d" % (window, arc, t))
 
 
+def test_detect_filter_wave_count_follows_the_frame(slamx, oracle):
+    """Batches with a candidate capacity of >= 65536 run the greedy NMS with 1 + 7 waves; a frame with >= 32768
+    candidates uses all seven filter waves, the others three (nms.hip, NMS_DENSE_CANDIDATES).  One batch with
+    frames on both sides of that count, heavily tied noise; the same frames through a small-capacity batch (the
+    1 + 3 instantiation) where they fit."""
+    rng = np.random.default_rng(20251)
+    rows, cols = 420, 640
+    noise = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    d = slamx.FeatureDetector(cfg_of(slamx, t=30, arc=9, window=5))
+    Pp = oracle.det_params(d.cfg)
+    frames = []
+    for keep_rows in (rows, 300, 150, 330):  # the rest of the frame is flat: no corners there
+        f = np.full((rows, cols), 128, np.uint8)
+        f[:keep_rows] = noise[:keep_rows]
+        frames.append(f)
+    counts = [len(oracle.fast_candidates(f, Pp)) for f in frames]
+    b = slamx.Batch(d, rows, cols, len(frames), max_candidates=131072, max_keypoints=16384)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(len(frames))
+    nc, nk, _ = b.counts(len(frames))
+    assert nc.tolist() == counts and max(counts) >= 32768 > min(counts)
+    for k, f in enumerate(frames):
+        want_k, want_d = oracle.detect_and_compute(f, Pp)
+        got_k, got_d = b.download(k)
+        assert_records_equal(got_k, want_k, "frame %d (%d candidates)" % (k, counts[k]))
+        assert np.array_equal(got_d, want_d)
+    small = [k for k, c in enumerate(counts) if c <= 30000]
+    if small:
+        b2 = slamx.Batch(d, rows, cols, len(small), max_candidates=30000, max_keypoints=16384)
+        b2.upload(np.stack([frames[k] for k in small]))
+        b2.detect_and_compute(len(small))
+        for j, k in enumerate(small):
+            assert_records_equal(b2.download(j)[0], b.download(k)[0], "frame %d through the small instantiation" % k)
+
+
 def test_detect_without_nms(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, nms=0))
     img = synth(slamx, 1, 300, 400, 1500, rmin=3, rmax=20)
