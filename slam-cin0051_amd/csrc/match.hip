@@ -341,9 +341,11 @@ __device__ unsigned long long sp_stats[8];  // waves, tile entries, pairs queued
 #endif
 constexpr int SP_STAGE = 64;          // trains per stage (4 tiles of 16)
 #ifndef SLAMX_SP_CELL
-#define SLAMX_SP_CELL 32
+#define SLAMX_SP_CELL 64
 #endif
-constexpr int SP_CELL = SLAMX_SP_CELL;  // keypoints per cell of the spatial order, on average
+// keypoints per cell of the spatial order, on average (match stage per 512 frames of 2.1k keypoints with 16 / 32 / 48 / 64 /
+// 96 / 128: 0.43 / 0.47 / 0.40 / 0.42 / 0.42 / 0.45 ms -- how the cell grid happens to cut the frame, not a trend; c3 2.03-2.09)
+constexpr int SP_CELL = SLAMX_SP_CELL;
 constexpr int SP_MAX_STAGES = 1025;   // maxK <= 65536
 constexpr int SP_BUCKETS = 128;       // stage order: counting sort on the centre distance in 32-px steps
 constexpr int SP_SEED_STAGES = 2;      // leading near stages scanned densely, a query per lane, before the filter has a bound
