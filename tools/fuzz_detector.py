@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the detector against the CPU restatement (oracle/): random shapes, thresholds, arc
-lengths and image statistics through FAST candidates, and detect + compute on the smaller ones.
+lengths and image statistics through FAST candidates, and detect + compute on the smaller ones (every third of those
+also through a batch with a large candidate capacity: the other instantiation of the greedy NMS).
 Test infrastructure (uses oracle/ as the checker).  usage: tools/fuzz_detector.py [cases] [seed]"""
 import os
 import sys
@@ -61,6 +62,15 @@ def main():
             k_got, d_got = det.detectAndCompute(img)
             assert len(k_got) == len(k_ref) and np.array_equal(k_got, k_ref), "keypoints differ, " + tag
             assert np.array_equal(d_got, d_ref), "descriptors differ, " + tag
+            if case % 3 == 0:  # the same frame twice through a batch whose capacity selects the 1 + 7-wave greedy NMS
+                b = slamx.Batch(det, rows, cols, 2, max_candidates=65536, max_keypoints=max(16, len(k_ref) + 8))
+                b.upload(np.stack([img, img]))
+                b.detect_and_compute(2)
+                for f in range(2):
+                    k_b, d_b = b.download(f)
+                    assert len(k_b) == len(k_ref) and np.array_equal(k_b, k_ref), "batch keypoints differ, " + tag
+                    assert len(k_ref) == 0 or np.array_equal(d_b, d_ref), "batch descriptors differ, " + tag
+                del b
         det.close() if hasattr(det, "close") else None
     print("fuzz_detector: %d cases identical (seed %d)" % (cases, seed))
 
