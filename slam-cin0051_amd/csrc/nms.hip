@@ -709,22 +709,50 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                 xy_a = xy_b;
                 xy_b = xy_c;
             } else if (wave == 0 && g >= 0) {
-                for (int h = 0; h < L; ++h) {
-                    if (g * L + h >= nchunks) {
-                        break;
+                if constexpr (LMAX > LOOKAHEAD) {
+                    // (dense instantiation) the group's masks and entries are all requested before the first is used: one
+                    // LDS round trip for the group instead of two per chunk -- c3 0.77 -> 0.70 ms; with three chunks a
+                    // group, most of them without a survivor, the same form costs 3 %: the small instantiation keeps the loop
+                    unsigned long long am[LMAX];
+                    uint2 ent[LMAX];
+#pragma unroll
+                    for (int h = 0; h < LMAX; ++h) {
+                        const bool there = h < L && g * L + h < nchunks;
+                        am[h] = there ? look_mask[g & 1][h] : 0ull;
+                        ent[h] = look[g & 1][h][lane];
                     }
-                    const unsigned long long am = look_mask[g & 1][h];
-                    const int na = __popcll(am);
-                    if (na == 0) {
-                        continue;
+#pragma unroll
+                    for (int h = 0; h < LMAX; ++h) {
+                        const int na = __popcll(am[h]);
+                        if (na == 0) {
+                            continue;
+                        }
+                        if (pend > FLUSH_AT || pend + na > 64) {
+                            flush();
+                        }
+                        if ((am[h] >> lane) & 1ull) {
+                            stage[pend + rank_below_mask(am[h])] = ent[h];
+                        }
+                        pend += na;
                     }
-                    if (pend > FLUSH_AT || pend + na > 64) {
-                        flush();
+                } else {
+                    for (int h = 0; h < L; ++h) {
+                        if (g * L + h >= nchunks) {
+                            break;
+                        }
+                        const unsigned long long am = look_mask[g & 1][h];
+                        const int na = __popcll(am);
+                        if (na == 0) {
+                            continue;
+                        }
+                        if (pend > FLUSH_AT || pend + na > 64) {
+                            flush();
+                        }
+                        if ((am >> lane) & 1ull) {
+                            stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
+                        }
+                        pend += na;
                     }
-                    if ((am >> lane) & 1ull) {
-                        stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
-                    }
-                    pend += na;
                 }
             }
             __threadfence_block();
