@@ -686,8 +686,11 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
         uint32_t key_b = chunk_load(sorted, hc0 + L);
         uint32_t xy_b = chunk_load(sorted_xy, hc0 + L);
         const int ngroups = (nchunks + L - 1) / L;
-        for (int g = -1; g < ngroups; ++g) {
-            if (filters) {
+        // One loop per role, the same number of barriers in each.  (In one shared loop the wait for the filter waves'
+        // prefetched chunk -- s_waitcnt vmcnt(0) at the loop head -- also made wave 0 wait, every group, until the
+        // keypoint records of its last batch had reached memory: stores count in vmcnt too.)
+        if (filters) {
+            for (int g = -1; g < ngroups; ++g) {
                 // group g + 1 into look[(g + 1) & 1]
                 const int c = (g + 1) * L + hc0;
                 const uint32_t key_c = chunk_load(sorted, c + 2 * L);
@@ -708,55 +711,68 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                 key_b = key_c;
                 xy_a = xy_b;
                 xy_b = xy_c;
-            } else if (wave == 0 && g >= 0) {
-                if constexpr (LMAX > LOOKAHEAD) {
-                    // (dense instantiation) the group's masks and entries are all requested before the first is used: one
-                    // LDS round trip for the group instead of two per chunk -- c3 0.77 -> 0.70 ms; with three chunks a
-                    // group, most of them without a survivor, the same form costs 3 %: the small instantiation keeps the loop
-                    unsigned long long am[LMAX];
-                    uint2 ent[LMAX];
-#pragma unroll
-                    for (int h = 0; h < LMAX; ++h) {
-                        const bool there = h < L && g * L + h < nchunks;
-                        am[h] = there ? look_mask[g & 1][h] : 0ull;
-                        ent[h] = look[g & 1][h][lane];
-                    }
-#pragma unroll
-                    for (int h = 0; h < LMAX; ++h) {
-                        const int na = __popcll(am[h]);
-                        if (na == 0) {
-                            continue;
-                        }
-                        if (pend > FLUSH_AT || pend + na > 64) {
-                            flush();
-                        }
-                        if ((am[h] >> lane) & 1ull) {
-                            stage[pend + rank_below_mask(am[h])] = ent[h];
-                        }
-                        pend += na;
-                    }
-                } else {
-                    for (int h = 0; h < L; ++h) {
-                        if (g * L + h >= nchunks) {
-                            break;
-                        }
-                        const unsigned long long am = look_mask[g & 1][h];
-                        const int na = __popcll(am);
-                        if (na == 0) {
-                            continue;
-                        }
-                        if (pend > FLUSH_AT || pend + na > 64) {
-                            flush();
-                        }
-                        if ((am >> lane) & 1ull) {
-                            stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
-                        }
-                        pend += na;
-                    }
-                }
+                __threadfence_block();
+                __syncthreads();
             }
-            __threadfence_block();
-            __syncthreads();
+        } else if (wave == 0) {
+            for (int g = -1; g < ngroups; ++g) {
+                if (g >= 0) {
+                    if constexpr (LMAX > LOOKAHEAD) {
+                        // (dense instantiation) the group's masks and entries are all requested before the first is
+                        // used: one LDS round trip for the group instead of two per chunk -- c3 0.77 -> 0.70 ms; with
+                        // three chunks a group, most of them without a survivor, the same form costs 3 %: the small
+                        // instantiation keeps the loop
+                        unsigned long long am[LMAX];
+                        uint2 ent[LMAX];
+#pragma unroll
+                        for (int h = 0; h < LMAX; ++h) {
+                            const bool there = h < L && g * L + h < nchunks;
+                            am[h] = there ? look_mask[g & 1][h] : 0ull;
+                            ent[h] = look[g & 1][h][lane];
+                        }
+#pragma unroll
+                        for (int h = 0; h < LMAX; ++h) {
+                            const int na = __popcll(am[h]);
+                            if (na == 0) {
+                                continue;
+                            }
+                            if (pend > FLUSH_AT || pend + na > 64) {
+                                flush();
+                            }
+                            if ((am[h] >> lane) & 1ull) {
+                                stage[pend + rank_below_mask(am[h])] = ent[h];
+                            }
+                            pend += na;
+                        }
+                    } else {
+                        for (int h = 0; h < L; ++h) {
+                            if (g * L + h >= nchunks) {
+                                break;
+                            }
+                            const unsigned long long am = look_mask[g & 1][h];
+                            const int na = __popcll(am);
+                            if (na == 0) {
+                                continue;
+                            }
+                            if (pend > FLUSH_AT || pend + na > 64) {
+                                flush();
+                            }
+                            if ((am >> lane) & 1ull) {
+                                stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
+                            }
+                            pend += na;
+                        }
+                    }
+                
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        } else {
+            for (int g = -1; g < ngroups; ++g) {
+                __threadfence_block();
+                __syncthreads();
+            }
         }
         if (wave == 0) {
             flush();
