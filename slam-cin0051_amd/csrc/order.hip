@@ -566,8 +566,19 @@ __device__ int SORT_BLOCK_MIN = 3072;  // segments at least this long are partit
 // sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
 // seq == t + 1).  Queued segments are disjoint ranges of more than SORT_LEAF keys, so at most
 // len / 17 of them exist at any time: with SORT_QCAP >= lds_keys / 17 + 32 the ring never fills.
-constexpr int SORT_QCAP = 1024;
-constexpr int SORT_LDS_KEYS_MAX = 16384;
+#ifndef SLAMX_SORT_QCAP
+#define SLAMX_SORT_QCAP 2048
+#endif
+constexpr int SORT_QCAP = SLAMX_SORT_QCAP;
+#ifndef SLAMX_SORT_LDS_KEYS
+#define SLAMX_SORT_LDS_KEYS 28672
+#endif
+// Keys of one LDS-resident piece: 112 KB of keys + 3.5 KB of leaf flags + the 24 KB ring.  The 16-bit position lists of
+// the partitions sit in the unused tail of the key region while a piece leaves room for them (len * 1.5 <= capacity:
+// 19k keys) and in the piece's range of the OUTPUT array in global memory otherwise (idle until the leaf pass; 2-3 %
+// slower than LDS at 13-14.5k keys) -- until round 3 they had 32 KB of LDS of their own and a piece was at most 16384
+// keys, so the 20-24k candidates of a pyramid level paid a workgroup-wide partition level in global memory first.
+constexpr int SORT_LDS_KEYS_MAX = SLAMX_SORT_LDS_KEYS;
 static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
 
 struct SegQueue {
@@ -646,8 +657,12 @@ __device__ bool seg_pop(const SegQueue& q, SortShared& sh, int2* item) {
 // 64 keys), keeps the larger child for itself and queues the other one.  No level barriers: the
 // duration is the longest parent-child chain, not the sum of the slowest segment of every level.
 // Leaf boundaries are recorded in segbits at bit (bit_base + position).
-__device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q, int len, int depth, uint32_t* segbits,
-                                 int bit_base, SortShared& sh) {
+// Position lists of the partitions (len 16-bit entries): scr16 (global memory) for the workgroup-wide levels; for a
+// wave's own partitions behind the keys in LDS when scr_lds_word >= 0 (the word offset of that area in `a`), else
+// scr16 as well.  Two call sites, so that each form keeps its address space.  (The same for block_partition made it
+// a called function: 74 registers and a stack; inlined three times the kernel grew from 55 to 74 KB.)
+__device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, int scr_lds_word, const SegQueue& q, int len, int depth,
+                                 uint32_t* segbits, int bit_base, SortShared& sh) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -698,7 +713,7 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q
                 }
                 continue;
             }
-            const int cut = block_partition(a, scr16 + seg.x, seg.x, seg.y, sh);
+            const int cut = block_partition(a, scr16 + seg.x, seg.x, seg.y, sh);  // (workgroup-wide: lists in global memory)
             if (tid == 0) {
                 mark_leaf_boundary(cut);
                 const int2 child[2] = {make_int2(cut, seg.y), make_int2(seg.x, cut)};
@@ -757,7 +772,9 @@ __device__ void introsort_levels(uint32_t* a, uint16_t* scr16, const SegQueue& q
         } else if (last - first <= 64) {
             wave_small_introsort(a, first, last, dep, lane, sh.sel[wave], segbits, bit_base);
         } else {
-            const int cut = wave_partition_cf(a, scr16 + first, first, last, lane);
+            const int cut = scr_lds_word >= 0
+                                ? wave_partition_cf(a, reinterpret_cast<uint16_t*>(a + scr_lds_word) + first, first, last, lane)
+                                : wave_partition_cf(a, scr16 + first, first, last, lane);
             const int size_l = cut - first;
             const int size_r = last - cut;
             if (lane == 0) {
@@ -813,9 +830,8 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
     const int tid = threadIdx.x;
     const int nwords = (n + 32) / 32;  // bits 0..n
     uint32_t* segbits = nwords <= lds_keys / 32 + 2 ? lds + lds_keys : gsegbits;
-    uint16_t* scr16 = reinterpret_cast<uint16_t*>(lds + lds_keys + lds_keys / 32 + 2);  // lds_keys entries
     SegQueue queue;
-    queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2 + (lds_keys + 3) / 2 + 1);
+    queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
     queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
     queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
     for (int i = tid; i < nwords; i += blockDim.x) {
@@ -927,7 +943,11 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
             lds[i] = gkeys[first + i];
         }
         __syncthreads();
-        introsort_levels(lds, scr16, queue, len, depth, segbits, first, sh);
+        // 16-bit position lists of this piece's partitions (len entries): behind its keys while there is room (19k
+        // keys), else the piece's range of the output array
+        const int len4 = (len + 3) & ~3;
+        const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
+        introsort_levels(lds, reinterpret_cast<uint16_t*>(out + first), scr_lds_word, queue, len, depth, segbits, first, sh);
         if (!all_in_lds) {
             for (int i = tid; i < len; i += blockDim.x) {
                 gkeys[first + i] = lds[i];
@@ -1047,16 +1067,15 @@ __global__ __launch_bounds__(SORT_THREADS) void debug_sort_kernel(uint32_t* keys
 
 
 int lds_keys_for(int maxM) {
-    // keys kept in LDS while they fit 64 KiB; longer arrays are first split in global memory by
-    // the workgroup-wide partition until every piece fits
+    // keys kept in LDS while they fit; longer arrays are first split in global memory by the workgroup-wide
+    // partition until every piece fits
     const int cap = SORT_LDS_KEYS_MAX;
     return maxM < cap ? (maxM < 64 ? 64 : maxM) : cap;
 }
 
 size_t sort_lds_bytes(int lds_keys) {
-    // keys + leaf-flag words + 16-bit partition scratch + segment queue (data, sequence numbers)
-    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + static_cast<size_t>(lds_keys) * 2 + 32 +
-           static_cast<size_t>(SORT_QCAP) * 12;
+    // keys + leaf-flag words + segment queue (data, sequence numbers)
+    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + 32 + static_cast<size_t>(SORT_QCAP) * 12;
 }
 void allow_big_lds(const void* fn) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(SORT_LDS_KEYS_MAX)));
