@@ -28,6 +28,8 @@ namespace {
 // dword that holds its first one (scale factors up to 2.5: 3 + 3 * 2.5 + 1 < 12), so the two source rows are read as
 // ONE 12-byte load each and the taps are cut out of registers (v_alignbyte); the first version issued 16 byte loads
 // and 4 table loads per lane and ran at a quarter of the HBM rate (3.2 of the pyramid workload's 15.6 ms).
+constexpr int DS_ROWS = 4;  // destination rows per thread: the column table is decoded once for all of them
+
 __global__ __launch_bounds__(256) void downscale_kernel(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
                                                         int src_cols, uint8_t* __restrict__ dst, size_t dst_frame_stride,
                                                         int dst_pitch, int dst_rows, int dst_cols,
@@ -37,63 +39,94 @@ __global__ __launch_bounds__(256) void downscale_kernel(const uint8_t* __restric
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
         return;
     }
-    const int y = bx / segs;  // (scalar)
-    const int xd = (bx - y * segs) * 256 + static_cast<int>(threadIdx.x);
-    if (y >= dst_rows || xd * 4 >= dst_pitch) {
+    const int yb = (bx / segs) * DS_ROWS;  // (scalar) first of this block's destination rows
+    const int xd = (bx - (bx / segs) * segs) * 256 + static_cast<int>(threadIdx.x);
+    if (yb >= dst_rows || xd * 4 >= dst_pitch) {
         return;
     }
     const uint8_t* s = src + static_cast<size_t>(f) * src_frame_stride;
-    uint32_t* out = reinterpret_cast<uint32_t*>(dst + static_cast<size_t>(f) * dst_frame_stride + static_cast<size_t>(y) * dst_pitch) + xd;
+    uint32_t* out = reinterpret_cast<uint32_t*>(dst + static_cast<size_t>(f) * dst_frame_stride + static_cast<size_t>(yb) * dst_pitch) + xd;
+    const int out_step = dst_pitch / 4;  // (the pitch is a multiple of 64)
+    const int nrows = min(DS_ROWS, dst_rows - yb);
     const int x4 = xd * 4;
     if (x4 >= dst_cols) {
-        *out = 0u;  // pitch padding gets zeros
+        for (int r = 0; r < nrows; ++r) {
+            out[r * out_step] = 0u;  // pitch padding gets zeros
+        }
         return;
     }
-    const uint32_t ye = ytab[y];
-    const int y0 = static_cast<int>(ye & 0xffffu);
-    const int fy = static_cast<int>(ye >> 16);
-    const uint8_t* r0 = s + static_cast<size_t>(y0) * src_pitch;
-    const uint8_t* r1 = s + static_cast<size_t>(fy != 0 ? y0 + 1 : y0) * src_pitch;  // f != 0 => y0 + 1 exists
     const uint4 xe4 = *reinterpret_cast<const uint4*>(xtab + x4);  // (the table is padded to a multiple of 4 entries)
     const uint32_t xe[4] = {xe4.x, xe4.y, xe4.z, xe4.w};
     const int base = static_cast<int>(xe[0] & 0xfffcu);
-    uint32_t result = 0;
+    uint32_t ye[DS_ROWS];
+#pragma unroll
+    for (int r = 0; r < DS_ROWS; ++r) {
+        ye[r] = ytab[min(yb + r, dst_rows - 1)];
+    }
     if (static_cast<int>(xe[3] & 0xffffu) - base <= 10) {
+        // all row pairs are requested before the first is used
         // (frames end with 64 bytes of slack: the 12 bytes may reach past the last row's pitch)
-        const uint3 a3 = *reinterpret_cast<const uint3*>(r0 + base);
-        const uint3 b3 = *reinterpret_cast<const uint3*>(r1 + base);
+        uint3 a3[DS_ROWS], b3[DS_ROWS];
+#pragma unroll
+        for (int r = 0; r < DS_ROWS; ++r) {
+            const int y0 = static_cast<int>(ye[r] & 0xffffu);
+            const int fy = static_cast<int>(ye[r] >> 16);
+            a3[r] = *reinterpret_cast<const uint3*>(s + static_cast<size_t>(y0) * src_pitch + base);
+            b3[r] = *reinterpret_cast<const uint3*>(s + static_cast<size_t>(fy != 0 ? y0 + 1 : y0) * src_pitch + base);  // f != 0 => y0 + 1 exists
+        }
+        uint32_t result[DS_ROWS] = {};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int o = static_cast<int>(xe[k] & 0xffffu) - base;  // 0 .. 10: this tap and its right neighbour are bytes o, o + 1
             const int fx = static_cast<int>(xe[k] >> 16);
             const bool hi = o >= 4;
             const bool hi2 = o >= 8;
-            // the 8 bytes that hold byte o and o + 1, then the 4 bytes from byte o on
-            const uint32_t ta = __builtin_amdgcn_alignbyte(hi2 ? 0u : (hi ? a3.z : a3.y), hi2 ? a3.z : (hi ? a3.y : a3.x), static_cast<uint32_t>(o));
-            const uint32_t tb = __builtin_amdgcn_alignbyte(hi2 ? 0u : (hi ? b3.z : b3.y), hi2 ? b3.z : (hi ? b3.y : b3.x), static_cast<uint32_t>(o));
-            const int a = static_cast<int>(ta & 0xffu), b = static_cast<int>(ta >> 8 & 0xffu);
-            const int c = static_cast<int>(tb & 0xffu), d = static_cast<int>(tb >> 8 & 0xffu);
-            // a (2048 - fx) + b fx == 2048 a + (b - a) fx: the same integers as the defining formula (fx == 0: b is not
-            // used, whatever byte it is)
-            const int top = (a << 11) + (b - a) * fx;
-            const int bot = (c << 11) + (d - c) * fx;
-            const int v = ((top << 11) + (bot - top) * fy + (1 << 21)) >> 22;
-            result |= (x4 + k < dst_cols ? static_cast<uint32_t>(v) : 0u) << (8 * k);
+            const bool inside = x4 + k < dst_cols;
+#pragma unroll
+            for (int r = 0; r < DS_ROWS; ++r) {
+                const int fy = static_cast<int>(ye[r] >> 16);
+                // the 8 bytes that hold byte o and o + 1, then the 4 bytes from byte o on
+                const uint32_t ta = __builtin_amdgcn_alignbyte(hi2 ? 0u : (hi ? a3[r].z : a3[r].y), hi2 ? a3[r].z : (hi ? a3[r].y : a3[r].x),
+                                                               static_cast<uint32_t>(o));
+                const uint32_t tb = __builtin_amdgcn_alignbyte(hi2 ? 0u : (hi ? b3[r].z : b3[r].y), hi2 ? b3[r].z : (hi ? b3[r].y : b3[r].x),
+                                                               static_cast<uint32_t>(o));
+                const int a = static_cast<int>(ta & 0xffu), b = static_cast<int>(ta >> 8 & 0xffu);
+                const int c = static_cast<int>(tb & 0xffu), d = static_cast<int>(tb >> 8 & 0xffu);
+                // a (2048 - fx) + b fx == 2048 a + (b - a) fx: the same integers as the defining formula (fx == 0: b is
+                // not used, whatever byte it is)
+                const int top = (a << 11) + (b - a) * fx;
+                const int bot = (c << 11) + (d - c) * fx;
+                const int v = ((top << 11) + (bot - top) * fy + (1 << 21)) >> 22;
+                result[r] |= (inside ? static_cast<uint32_t>(v) : 0u) << (8 * k);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DS_ROWS; ++r) {
+            if (r < nrows) {
+                out[r * out_step] = result[r];
+            }
         }
     } else {  // very large scale factors: the taps are read one by one
+        for (int r = 0; r < nrows; ++r) {
+            const int y0 = static_cast<int>(ye[r] & 0xffffu);
+            const int fy = static_cast<int>(ye[r] >> 16);
+            const uint8_t* r0 = s + static_cast<size_t>(y0) * src_pitch;
+            const uint8_t* r1 = s + static_cast<size_t>(fy != 0 ? y0 + 1 : y0) * src_pitch;
+            uint32_t result = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x0 = static_cast<int>(xe[k] & 0xffffu);
-            const int fx = static_cast<int>(xe[k] >> 16);
-            const int x1 = fx != 0 ? x0 + 1 : x0;  // f != 0 => x0 + 1 < src_cols
-            const int a = r0[x0], b = r0[x1], c = r1[x0], d = r1[x1];
-            const int top = (a << 11) + (b - a) * fx;
-            const int bot = (c << 11) + (d - c) * fx;
-            const int v = ((top << 11) + (bot - top) * fy + (1 << 21)) >> 22;
-            result |= (x4 + k < dst_cols ? static_cast<uint32_t>(v) : 0u) << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                const int x0 = static_cast<int>(xe[k] & 0xffffu);
+                const int fx = static_cast<int>(xe[k] >> 16);
+                const int x1 = fx != 0 ? x0 + 1 : x0;  // f != 0 => x0 + 1 < src_cols
+                const int a = r0[x0], b = r0[x1], c = r1[x0], d = r1[x1];
+                const int top = (a << 11) + (b - a) * fx;
+                const int bot = (c << 11) + (d - c) * fx;
+                const int v = ((top << 11) + (bot - top) * fy + (1 << 21)) >> 22;
+                result |= (x4 + k < dst_cols ? static_cast<uint32_t>(v) : 0u) << (8 * k);
+            }
+            out[r * out_step] = result;
         }
     }
-    *out = result;
     (void)src_cols;
 }
 
@@ -150,8 +183,8 @@ __global__ __launch_bounds__(256) void merge_level_kernel(const slamx_keypoint* 
 
 void launch_downscale(const BatchView& src, const BatchView& dst, const uint32_t* xtab, const uint32_t* ytab, int nframes,
                       hipStream_t stream) {
-    const int segs = (dst.pitch / 4 + 255) / 256;  // workgroups per destination row
-    const int bpf = dst.rows * segs;
+    const int segs = (dst.pitch / 4 + 255) / 256;  // workgroups per group of DS_ROWS destination rows
+    const int bpf = (dst.rows + DS_ROWS - 1) / DS_ROWS * segs;
     hipLaunchKernelGGL(downscale_kernel, dim3(frame_grid(nframes, bpf)), dim3(256), 0, stream, src.frames, src.frame_stride,
                        src.pitch, src.cols, const_cast<uint8_t*>(dst.frames), dst.frame_stride, dst.pitch, dst.rows, dst.cols,
                        xtab, ytab, nframes, bpf, segs);
