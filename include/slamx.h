@@ -96,7 +96,7 @@ const char* slamx_version(void);
 /* Train-set size from which the matcher computes the all-pairs Hamming distances of a frame pair on the
  * int8 matrix cores instead of with xor + popcount (descriptors with <= 62 live bits only; results are
  * identical either way; in a batch the choice is made per frame pair on the device, a batch whose keypoint
- * capacity is below the value never takes the matrix-core scan).  Built-in 3072, overridden by the
+ * capacity is below the value never takes the matrix-core scan).  Built-in 1024, overridden by the
  * environment variable SLAMX_MATCH_MFMA_MIN_KEYPOINTS. */
 int slamx_matcher_mfma_threshold(void);
 

@@ -23,10 +23,12 @@ constexpr uint8_t NMS_KEPT = 1;
 constexpr uint8_t NMS_SUPPRESSED = 2;
 constexpr int MATCH_MAX_SPLIT = 8;
 // Train sets of at least this many keypoints take the matrix-core scan (match.hip), smaller ones the xor + popcount
-// scan -- unless the frame is WIDE: when its keypoints spread over more than 1000 px, most pairs carry the jump
-// penalty, the spatial scan sees them through a halved bound, and it wins from ~800 keypoints on (1080p: 0.204 vs
-// 0.212 ms per 512 frames of 835 keypoints, 0.26 vs 0.35 at 1.3k, 0.41 vs 0.60 at 2.1k; 640x480: a tie at 1.9-2.6k).
-constexpr int MATCH_MFMA_MIN_KEYPOINTS = 3072;
+// scan (640x480, per 1024 frames: 0.258 vs 0.269 ms at 844 keypoints, 0.467 vs 0.397 at 1.3k, 0.81 vs 0.66 at 1.9k,
+// 1.13 vs 0.85 at 2.4k; until the end of round 3 the value was 3072 -- the scan's start-up and slow path were heavier
+// then and narrow frames tied up to 2.6k) -- and from fewer when the frame is WIDE: when its keypoints spread over
+// more than 1000 px, most pairs carry the jump penalty, the spatial scan sees them through a halved bound, and it wins
+// from ~800 keypoints on (1080p: 0.204 vs 0.212 ms per 512 frames of 835 keypoints, 0.26 vs 0.35 at 1.3k).
+constexpr int MATCH_MFMA_MIN_KEYPOINTS = 1024;
 constexpr int MATCH_MFMA_MIN_KEYPOINTS_WIDE = 768;
 constexpr float MATCH_MFMA_WIDE_DIAGONAL = 1000.0f;
 constexpr int NBR_CAP = 16;            // cached earlier-ranked neighbours per candidate

@@ -460,8 +460,8 @@ def test_match_random_descriptors(slamx, oracle, width, n1, n2):
 
 @pytest.fixture
 def mfma_scan_for_all_sizes(monkeypatch):
-    """The matrix-core scan is only taken for train sets of >= 3072 keypoints (smaller ones are faster on
-    the popcount scan); the override sends every size through it."""
+    """The matrix-core scan is only taken for train sets of >= 1024 keypoints (>= 768 when they spread over more than
+    1000 px; smaller ones are faster on the popcount scan); the override sends every size through it."""
     monkeypatch.setenv("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", "0")
 
 
@@ -530,7 +530,7 @@ def test_match_matrix_core_scan_descriptor_widths(slamx, oracle, width, bits, mf
 
 
 def test_match_large_train_set_takes_the_matrix_core_scan(slamx, oracle):
-    """7000 train descriptors with 46 live bits: above the built-in threshold (3072), no override."""
+    """7000 train descriptors with 46 live bits: above the built-in threshold (1024), no override."""
     rng = np.random.default_rng(77)
     n1, n2 = 900, 7000
     d1 = np.zeros((n1, 32), np.uint8)
@@ -618,17 +618,17 @@ def test_batch_with_both_scans_in_one_launch(slamx, oracle, monkeypatch):
 
 
 def test_batch_scan_choice_by_extent(slamx, oracle):
-    """Default thresholds: train sets of 768..3071 keypoints take the matrix-core scan only when their keypoints spread
-    over more than 1000 px (decided per frame on the device).  Wide and narrow frames with such counts alternate in one
-    batch, so both scans run in one launch and every pair sees the other kind as its partner; all results are the
-    oracle's."""
+    """Default thresholds: train sets of 1024 keypoints or more take the matrix-core scan, those of 768..1023 only when
+    their keypoints spread over more than 1000 px (decided per frame on the device).  Wide and narrow frames on both
+    sides of those counts alternate in one batch, so both scans run in one launch and every pair sees the other kind
+    as its partner; all results are the oracle's."""
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     Pp = oracle.det_params(d.cfg)
     m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.7))
     mp = oracle.match_params(m.cfg)
     rows, cols = 400, 1500
     frames = []
-    for k, (n, narrow) in enumerate(((5000, False), (7000, True), (5500, False), (300, False), (6500, True))):
+    for k, (n, narrow) in enumerate(((2200, False), (5200, True), (5500, False), (300, False), (5400, True), (7000, True))):
         f = synth(slamx, k, rows, cols, n, rmin=3, rmax=20)
         if narrow:
             f[:, 600:] = 128  # corners only in the left 600 columns: diagonal of the keypoint box < 1000 px
@@ -640,7 +640,7 @@ def test_batch_scan_choice_by_extent(slamx, oracle):
     b.match_consecutive(m, F, use_keypoints=True, first_train_frame=F - 1)
     ref = [oracle.detect_and_compute(f, Pp) for f in frames]
     sizes = [len(r[0]) for r in ref]
-    assert all(768 <= sizes[k] < 3072 for k in (0, 1, 2, 4)) and sizes[3] < 768, sizes
+    assert all(768 <= sizes[k] < 1024 for k in (0, 1, 4)) and sizes[3] < 768 and sizes[2] >= 1024 and sizes[5] >= 1024, sizes
     assert ref[1][0]["x"].max() < 640 and ref[0][0]["x"].max() > 1400
     for k in range(F):
         t = (k - 1) % F
@@ -648,9 +648,10 @@ def test_batch_scan_choice_by_extent(slamx, oracle):
         assert_records_equal(b.download_matches(m, k), want, "frame %d (%d kp) vs %d (%d kp)" % (k, sizes[k], t, sizes[t]))
 
 
-@pytest.mark.parametrize("n1,n2,wide", [(3300, 3500, True), (1500, 3100, False), (2500, 900, True), (900, 2500, True)])
+@pytest.mark.parametrize("n1,n2,wide", [(3300, 3500, True), (1500, 3100, False), (2500, 900, True), (900, 2500, True),
+                                         (1200, 1000, False), (1000, 1030, False)])
 def test_match_default_scan_rule_through_the_host_api(slamx, oracle, n1, n2, wide):
-    """slamx_matcher_match with the DEFAULT thresholds (no environment override): train sets of >= 3072 descriptors, and
+    """slamx_matcher_match with the DEFAULT thresholds (no environment override): train sets of >= 1024 descriptors, and
     wide ones of >= 768, go through the matrix-core scan in spatial order, the others through xor + popcount -- decided
     on the device.  Descriptors with the detector's 46 live bits, duplicates and near-duplicates, keypoints on a 1080p
     canvas (wide) or in a 600 x 500 corner of it; every result is the oracle's."""
