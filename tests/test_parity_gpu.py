@@ -143,14 +143,17 @@ def _check_sort(gpu_ctx, oracle, scores):
 
 
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 18, 31, 32, 33, 63, 64, 65, 66, 100, 127, 128, 129, 130, 200, 255, 256,
-                               257, 500, 1000, 1023, 1024, 1025, 4097, 11329, 24576, 24577, 40000, 70000])
+                               257, 500, 1000, 1023, 1024, 1025, 4097, 11329, 16384, 16385, 19112, 19116, 19120, 24576, 24577,
+                               28671, 28672, 28673, 40000, 57345, 70000])
 def test_sort_random_with_ties(gpu_ctx, oracle, n):
+    """(sizes around 19114 and 28672: where the partition lists move from LDS to global memory, and where an array stops
+    fitting LDS in one piece -- order.hip, SORT_LDS_KEYS_MAX)"""
     rng = np.random.default_rng(n)
     for spread in (3, 40, 1600, 4081):
         _check_sort(gpu_ctx, oracle, rng.integers(0, spread, n))
 
 
-@pytest.mark.parametrize("n", [17, 64, 65, 129, 1000, 5000, 30000])
+@pytest.mark.parametrize("n", [17, 64, 65, 129, 1000, 5000, 19500, 28672, 30000])
 def test_sort_structured(gpu_ctx, oracle, n):
     i = np.arange(n)
     cases = [
