@@ -579,6 +579,7 @@ constexpr int SORT_QCAP = SLAMX_SORT_QCAP;
 // slower than LDS at 13-14.5k keys) -- until round 3 they had 32 KB of LDS of their own and a piece was at most 16384
 // keys, so the 20-24k candidates of a pyramid level paid a workgroup-wide partition level in global memory first.
 constexpr int SORT_LDS_KEYS_MAX = SLAMX_SORT_LDS_KEYS;
+constexpr int PIECE_NO_LEVELS = 0x7f;  // depth field of a piece that is a single leaf: it only takes the leaf pass
 static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
 
 struct SegQueue {
@@ -855,8 +856,8 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
     }
     int2* ready = lists + 2 * maxSeg;  // {first, last | depth << 24}
     if (n <= lds_keys) {
-        if (tid == 0 && n > SORT_LEAF) {
-            ready[0] = make_int2(0, n | (depth0 << 24));
+        if (tid == 0) {
+            ready[0] = make_int2(0, n | ((n > SORT_LEAF ? depth0 : PIECE_NO_LEVELS) << 24));
             sh.counters[3] = 1;
         }
     } else {
@@ -887,6 +888,15 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
                     __syncthreads();
                     for (int i = seg.x + tid; i < seg.y; i += blockDim.x) {
                         atomicOr(&segbits[i >> 5], 1u << (i & 31));
+                        // sorted already, every element its own leaf, and no piece will hold it: straight to the output
+                        const uint32_t key = gkeys[i];
+                        out[i] = key;
+                        if (rank_of != nullptr) {
+                            rank_of[key & INDEX_MASK] = static_cast<uint32_t>(i);
+                        }
+                        if (xy != nullptr) {
+                            gkeys[i] = xy[key & INDEX_MASK];
+                        }
                     }
                     continue;
                 }
@@ -896,13 +906,13 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
                     const int2 child[2] = {make_int2(cut, seg.y), make_int2(seg.x, cut)};
                     for (int c = 0; c < 2; ++c) {
                         const int size = child[c].y - child[c].x;
-                        if (size <= SORT_LEAF) {
+                        if (size <= 0) {
                             continue;
                         }
-                        if (size <= lds_keys) {
+                        if (size <= lds_keys) {  // (a child that is a leaf already becomes a piece without levels)
                             const int slot = sh.counters[3]++;
                             if (slot < maxSeg) {
-                                ready[slot] = make_int2(child[c].x, child[c].y | ((depth - 1) << 24));
+                                ready[slot] = make_int2(child[c].x, child[c].y | ((size > SORT_LEAF ? depth - 1 : PIECE_NO_LEVELS) << 24));
                             } else {
                                 sh.counters[2] = 1;
                             }
@@ -931,7 +941,15 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
     }
     __threadfence_block();
     __syncthreads();
-    // phase B: every LDS-sized segment: load, introsort levels in LDS, store back
+    // phase B: every piece (an LDS-sized segment; the whole array when it fits): load, introsort levels in LDS, and
+    // __final_insertion_sort straight from LDS into the output -- a stable sort inside each leaf: rank counting, one
+    // lane per element.  (Until late in round 3 the pieces of a long array went back to global memory and ONE leaf pass
+    // read them again from there: 0.23 ms of c3's 1.73.)  (x,y) in sorted order is written over the piece's dead unsorted
+    // keys for the greedy NMS, which then streams its input (the gather is cheaper here, spread over 16 waves, than in
+    // that single-wave kernel).  rank_of (optional): the inverse permutation, a
+    // divergent scatter.
+    (void)all_in_lds;
+    const bool sorted_xy = xy != nullptr;  // a loaded piece's keys in gkeys are dead: (x,y) in sorted order go there
     const int n_ready = min(sh.counters[3], maxSeg);
     for (int r = 0; r < n_ready; ++r) {
         const int2 seg = ready[r];
@@ -943,80 +961,64 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
             lds[i] = gkeys[first + i];
         }
         __syncthreads();
-        // 16-bit position lists of this piece's partitions (len entries): behind its keys while there is room (19k
-        // keys), else the piece's range of the output array
-        const int len4 = (len + 3) & ~3;
-        const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
-        introsort_levels(lds, reinterpret_cast<uint16_t*>(out + first), scr_lds_word, queue, len, depth, segbits, first, sh);
-        if (!all_in_lds) {
-            for (int i = tid; i < len; i += blockDim.x) {
-                gkeys[first + i] = lds[i];
+        if (depth != PIECE_NO_LEVELS) {
+            // 16-bit position lists of this piece's partitions (len entries): behind its keys while there is room (19k
+            // keys), else the piece's range of the output array
+            const int len4 = (len + 3) & ~3;
+            const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
+            introsort_levels(lds, reinterpret_cast<uint16_t*>(out + first), scr_lds_word, queue, len, depth, segbits, first, sh);
+        }
+        constexpr int LU = 4;  // elements per thread and step: their gathers are in flight together
+        for (int i0 = first + tid; i0 < last; i0 += LU * blockDim.x) {
+            uint32_t me[LU], pxy[LU];
+            int lo_[LU], hi_[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = min(i0 + u * static_cast<int>(blockDim.x), last - 1);
+                me[u] = lds[i - first];
+                // A leaf has at most SORT_LEAF = 16 elements, so its start flag lies in (i-16, i] and its
+                // end flag in (i, i+16]: both inside the 64 flag bits that start at word (i-16)/32
+                // (flags 0 and n are always set, and so are those at a piece's ends).
+                const int w0 = max(i - 16, 0) >> 5;
+                const unsigned long long x = static_cast<unsigned long long>(segbits[w0]) |
+                                             (static_cast<unsigned long long>(segbits[min(w0 + 1, nwords - 1)]) << 32);
+                const int rel = i - w0 * 32;  // <= 47
+                const unsigned long long upto = x & low_mask(rel + 1);
+                const unsigned long long above = x & ~low_mask(rel + 1);
+                lo_[u] = w0 * 32 + (63 - __clzll(static_cast<long long>(upto)));
+                hi_[u] = w0 * 32 + (__ffsll(static_cast<long long>(above)) - 1);
+            }
+            if (sorted_xy) {
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    pxy[u] = xy[me[u] & INDEX_MASK];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * static_cast<int>(blockDim.x);
+                if (i >= last) {
+                    break;
+                }
+                const uint32_t sc = score_of(me[u]);
+                int pos = lo_[u];
+                for (int j = lo_[u]; j < hi_[u]; ++j) {
+                    const uint32_t o = score_of(lds[j - first]);
+                    pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
+                }
+                out[pos] = me[u];
+                if (rank_of != nullptr) {
+                    rank_of[me[u] & INDEX_MASK] = static_cast<uint32_t>(pos);
+                }
+                if (sorted_xy) {
+                    gkeys[pos] = pxy[u];
+                }
             }
         }
         __threadfence_block();
         __syncthreads();
     }
-    if (all_in_lds && n_ready == 0) {  // n <= 16: a single leaf, no level ran
-        for (int i = tid; i < n; i += blockDim.x) {
-            lds[i] = gkeys[i];
-        }
-    }
     const int overflow = sh.counters[2];
-    __syncthreads();
-    // __final_insertion_sort == stable sort inside each leaf: rank counting, one lane per element.
-    // When the whole array sat in LDS the keys are read from there, and (x,y) in sorted order is
-    // written over the dead unsorted keys for the greedy NMS, which then streams its input (the
-    // gather is cheaper here, spread over 16 waves, than in that single-wave kernel).  rank_of
-    // (optional): the inverse permutation, a divergent scatter.
-    const uint32_t* a = all_in_lds ? lds : gkeys;
-    const bool sorted_xy = all_in_lds && xy != nullptr;  // the unsorted keys in gkeys are dead: (x,y) in sorted order go there
-    constexpr int LU = 4;  // elements per thread and step: their gathers are in flight together
-    for (int i0 = tid; i0 < n; i0 += LU * blockDim.x) {
-        uint32_t me[LU], pxy[LU];
-        int lo_[LU], hi_[LU];
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int i = min(i0 + u * static_cast<int>(blockDim.x), n - 1);
-            me[u] = a[i];
-            // A leaf has at most SORT_LEAF = 16 elements, so its start flag lies in (i-16, i] and its
-            // end flag in (i, i+16]: both inside the 64 flag bits that start at word (i-16)/32
-            // (flags 0 and n are always set).
-            const int w0 = max(i - 16, 0) >> 5;
-            const unsigned long long x = static_cast<unsigned long long>(segbits[w0]) |
-                                         (static_cast<unsigned long long>(segbits[min(w0 + 1, nwords - 1)]) << 32);
-            const int rel = i - w0 * 32;  // <= 47
-            const unsigned long long upto = x & low_mask(rel + 1);
-            const unsigned long long above = x & ~low_mask(rel + 1);
-            lo_[u] = w0 * 32 + (63 - __clzll(static_cast<long long>(upto)));
-            hi_[u] = w0 * 32 + (__ffsll(static_cast<long long>(above)) - 1);
-        }
-        if (sorted_xy) {
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                pxy[u] = xy[me[u] & INDEX_MASK];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int i = i0 + u * static_cast<int>(blockDim.x);
-            if (i >= n) {
-                break;
-            }
-            const uint32_t sc = score_of(me[u]);
-            int pos = lo_[u];
-            for (int j = lo_[u]; j < hi_[u]; ++j) {
-                const uint32_t o = score_of(a[j]);
-                pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
-            }
-            out[pos] = me[u];
-            if (rank_of != nullptr) {
-                rank_of[me[u] & INDEX_MASK] = static_cast<uint32_t>(pos);
-            }
-            if (sorted_xy) {
-                gkeys[pos] = pxy[u];
-            }
-        }
-    }
     __threadfence_block();
     __syncthreads();
     return overflow != 0 ? STATUS_SEG_OVERFLOW : 0;
@@ -1042,13 +1044,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds
     uint32_t* rank_of = need_rank_of != 0 ? v.rank_of + static_cast<size_t>(f) * v.maxM : nullptr;
     const uint32_t* xy = need_rank_of != 0 ? nullptr : v.cand_xy + static_cast<size_t>(f) * v.maxM;
     const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, rank_of, xy);
-    if (xy != nullptr && n > lds_keys) {
-        // the array did not fit LDS: the keys were sorted in place in gkeys, gather in a separate pass
-        __syncthreads();
-        for (int r = threadIdx.x; r < n; r += blockDim.x) {
-            gkeys[r] = xy[out[r] & INDEX_MASK];
-        }
-    }
     if (threadIdx.x == 0 && st != 0) {
         atomicOr(&v.status[f], st);
     }
