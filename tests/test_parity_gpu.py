@@ -175,6 +175,16 @@ def test_sort_depth_limit_heapsort(gpu_ctx, oracle):
         _check_sort(gpu_ctx, oracle, ((n - 1) - vals) // 3)  # with ties
 
 
+def test_sort_depth_limit_in_the_global_levels(gpu_ctx, oracle):
+    """The same adversary on an array that does not fit LDS (order.hip: 28672 keys): every partition peels off a few
+    keys, so the depth limit runs out while the segment is still in global memory and one lane heap-sorts ~30k keys
+    there; the sorted segment goes straight to the output, the peeled-off leaves arrive as pieces without levels."""
+    for n in (30000, 70000):
+        vals = np.minimum(oracle.antiqsort(n), 4095)  # scores have 12 bits; the first ~30 pivots are the smallest values,
+        _check_sort(gpu_ctx, oracle, 4095 - vals)      # everything above them compares the same clamped or not
+        _check_sort(gpu_ctx, oracle, vals)
+
+
 def test_sort_kitti_scores(gpu_ctx, oracle, det, P, ref_data):
     img = load_gray(os.path.join(ref_data, "images/0000000000.png"))
     cand = oracle.fast_candidates(img, P)
