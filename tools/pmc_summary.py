@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for r in rows:
-    k = r["Kernel_Name"].replace("slamx::(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(", ", ",")
+    k = r["Kernel_Name"].replace("slamx::(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(", ", ",").replace(",", ";")  # template arguments: no commas in a CSV field
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[k].add(r["Dispatch_Id"])
 names = sorted({r["Counter_Name"] for r in rows})
