@@ -8,6 +8,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <exception>
 #include <functional>
@@ -68,7 +69,8 @@ public:
             std::rethrow_exception(e);
         }
     }
-    // true iff the last pass ended in an error that join() has reported or will report
+    // true iff the last pass ended in an error that join() has reported or will report (callable while the pass runs:
+    // the flag is atomic; join() itself belongs to ONE thread)
     bool failed() const { return m_failed; }
     // sum of squared reprojection residuals before the first and after the last step of the last pass
     double initialCost() const { return m_cost0; }
@@ -164,7 +166,7 @@ private:
     Options m_options;
     double m_cost0 = 0.0, m_cost1 = 0.0;
     std::exception_ptr m_error;  // written by the backend thread, read after it has been joined
-    bool m_failed = false;
+    std::atomic<bool> m_failed{false};  // written by the backend thread, read by failed() from any thread
 };
 
 }  // namespace slam

@@ -400,7 +400,11 @@ __global__ __launch_bounds__(1024) void scan_choice_kernel(MatchView mv, int fir
 //   xdesc [f][p][64] train-form expanded descriptor, sbits[f][p] compact bits, sxyi[f][p] {x, y, original index, 0},
 //   sbox[f][p / 64] stage bounding boxes; positions [n, roundup(n, 64)) get a descriptor no bound lets through.
 // Without keypoints (no penalty, no coordinates) the order is the identity.
-__global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int first_frame, int first_train_frame) {
+// [first_query, last_query]: the frames of this launch that are QUERY frames of a pair of the call (the frame before the
+// first query and a far-away first_train_frame are train sets only: their own predecessor's flag was not written by this
+// call's scan_choice_kernel and is not looked at).
+__global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int first_frame, int first_train_frame, int first_query,
+                                                             int last_query) {
     __shared__ int hist[4096];
     __shared__ int bbox[4];
     __shared__ int wave_tot[16];
@@ -409,7 +413,8 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(MatchView mv, int f
     const int n = mv.n_kp[f];
     const int pred = f > 0 ? f - 1 : first_train_frame;
     const int tid = threadIdx.x;
-    if (mv.mfma_flag[f] == 0 && (pred < 0 || mv.mfma_flag[pred] == 0)) {
+    const bool is_query = f >= first_query && f <= last_query && pred >= 0;
+    if (mv.mfma_flag[f] == 0 && (!is_query || mv.mfma_flag[pred] == 0)) {
         return;  // neither the train set nor the query frame of a matrix-core pair (scan_choice_kernel; uniform)
     }
     const int stride = mv.width / 4;
@@ -1303,9 +1308,11 @@ void launch_match_consecutive(const MatchView& mv_in, int first_query_frame, int
         if (extra) {
             hipLaunchKernelGGL(scan_choice_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, 1);
         }
-        hipLaunchKernelGGL(spatial_order_kernel, dim3(nfr), dim3(1024), 0, stream, mv, lo_frame, first_train_frame);
+        hipLaunchKernelGGL(spatial_order_kernel, dim3(nfr), dim3(1024), 0, stream, mv, lo_frame, first_train_frame,
+                           first_query_frame, hi_frame);
         if (extra) {
-            hipLaunchKernelGGL(spatial_order_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, first_train_frame);
+            hipLaunchKernelGGL(spatial_order_kernel, dim3(1), dim3(1024), 0, stream, mv, first_train_frame, first_train_frame,
+                               0x7fffffff, -1);  // a train set only
         }
         const int wblocks = (mv.maxK + 16 * MM_QT - 1) / (16 * MM_QT);  // one wave of 64 queries per workgroup
         dim3 wgrid(static_cast<unsigned>(wblocks) * pair_slots * mv.nsplit);

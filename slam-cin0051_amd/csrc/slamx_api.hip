@@ -963,7 +963,7 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     // Two all-pairs scans with identical results (match.hip): int8 matrix cores in spatial order, and xor + popcount.
     // Which is faster depends on the size of the train set and on how far its keypoints spread (slamx_internal.h:
     // MATCH_MFMA_MIN_KEYPOINTS); both are only known on the device, so when the batch's capacity allows BOTH kernels
-    // are launched and every frame pair is taken by one of them (MatchView::mfma_flag, set by spatial_order_kernel).
+    // are launched and every frame pair is taken by one of them (MatchView::mfma_flag, set by scan_choice_kernel).
     const bool use_mfma = pattern_len <= 62 && b->v.width % 4 == 0 && b->v.maxK >= match_mfma_min_keypoints_wide();
     if (use_mfma && b->xdesc == nullptr) {
         SLAMX_TRY(dev_alloc(&b->xdesc, match_scratch_bytes(F, b->v.maxK)));
@@ -2662,14 +2662,26 @@ struct RcclApi {
 RcclApi& rccl() {
     static RcclApi api = [] {
         RcclApi a;
-        const char* names[] = {std::getenv("SLAMX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // SLAMX_RCCL_NO_FALLBACK=1: only $SLAMX_RCCL_LIBRARY is tried (the missing-library path has a test)
+        const char* nf = std::getenv("SLAMX_RCCL_NO_FALLBACK");
+        const bool fallback = nf == nullptr || *nf == '\0' || *nf == '0';
+        const char* names[] = {std::getenv("SLAMX_RCCL_LIBRARY"), fallback ? "librccl.so.1" : nullptr,
+                               fallback ? "librccl.so" : nullptr, fallback ? "/opt/rocm/lib/librccl.so.1" : nullptr};
+        std::string why = "?";
         for (const char* n : names) {
-            if (n != nullptr && *n != '\0' && (a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) {
+            if (n == nullptr || *n == '\0') {
+                continue;
+            }
+            if ((a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) {
                 break;
+            }
+            const char* e = dlerror();  // ONE call: dlerror() clears the state it returns
+            if (e != nullptr) {
+                why = e;
             }
         }
         if (a.lib == nullptr) {
-            a.error = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set SLAMX_RCCL_LIBRARY";
+            a.error = "librccl not found (" + why + "); set SLAMX_RCCL_LIBRARY";
             return a;
         }
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
@@ -2697,11 +2709,12 @@ struct slamx_mapgather {
     slamx_ctx* ctx = nullptr;
     void* comm = nullptr;
     int rank = 0, world = 1;
-    int32_t* d_counts = nullptr;  // [world + 1]: the gathered counts, then this rank's own
+    int32_t* d_counts = nullptr;  // [3 world + 3]: layout in slamx_mapgather_create
     double* d_send = nullptr;     // [cap][3]
     double* d_recv = nullptr;     // [world][cap][3]
     int cap = 0;
     std::vector<double> h_recv;
+    std::vector<int32_t> h_counts;
 };
 
 extern "C" {
@@ -2734,8 +2747,20 @@ int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_B
     g->world = world;
     RcclId u{};
     std::memcpy(u.internal, id, SLAMX_MAPGATHER_ID_BYTES);
-    RCCL_TRY(rccl().CommInitRank(&g->comm, world, u, rank));  // blocks until all `world` ranks have called it
-    SLAMX_TRY(dev_alloc(&g->d_counts, static_cast<size_t>(world) + 1));
+    // Everything that can fail locally comes BEFORE the rendezvous: a rank that returned early from here would leave
+    // the others waiting in ncclCommInitRank for ever.
+    // d_counts: [0, 2 world) the gathered {count, status} pairs, [2 world, 2 world + 2) this rank's own pair,
+    // [2 world + 2, 3 world + 2) the gathered "buffers ready" flags, [3 world + 2] this rank's flag
+    const int rc_alloc = dev_alloc(&g->d_counts, 3 * static_cast<size_t>(world) + 3);
+    if (rc_alloc != SLAMX_OK) {
+        return rc_alloc;
+    }
+    g->h_counts.assign(3 * static_cast<size_t>(world) + 3, 0);
+    const int r_init = rccl().CommInitRank(&g->comm, world, u, rank);  // blocks until all `world` ranks have called it
+    if (r_init != 0) {
+        dev_free(g->d_counts);
+        return fail(SLAMX_ERR_RUNTIME, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r_init));
+    }
     *out = g.release();
     return SLAMX_OK;
 }
@@ -2760,40 +2785,101 @@ int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_point
     if (g == nullptr || n_points < 0 || (xyz == nullptr && n_points > 0) || counts == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_allgather: bad arguments");
     }
-    HIP_TRY(hipSetDevice(g->ctx->device));
+    // No rank may leave between the collectives: the others would wait in the next one for ever.  A LOCAL failure (a HIP
+    // call, an allocation) is therefore remembered, the rank goes on through every collective -- the first carries its
+    // status beside its count, the second tells whether every rank has its buffers, and only when all have does the
+    // payload travel -- and the error is reported at the end, on every rank.  (A failing ncclAllGather itself means the
+    // communicator is gone: nothing this rank does can release the others then.)
+    int local_rc = SLAMX_OK;
+    std::string local_msg;
+    auto soft = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && local_rc == SLAMX_OK) {
+            local_rc = SLAMX_ERR_HIP;
+            local_msg = std::string(what) + ": " + hipGetErrorString(e);
+        }
+    };
+    soft(hipSetDevice(g->ctx->device), "hipSetDevice");
     hipStream_t s = g->ctx->stream;
     constexpr int kInt32 = 2, kFloat64 = 8;  // ncclInt32, ncclFloat64
-    // 1. the counts
-    const int32_t mine = n_points;
-    HIP_TRY(hipMemcpyAsync(g->d_counts + g->world, &mine, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    RCCL_TRY(rccl().AllGather(g->d_counts + g->world, g->d_counts, 1, kInt32, g->comm, s));
-    HIP_TRY(hipMemcpyAsync(counts, g->d_counts, sizeof(int32_t) * g->world, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    int cap = 0, tot = 0;
-    SLAMX_TRY(slamx_mapgather_plan(counts, g->world, &cap, &tot));
+    const size_t W = static_cast<size_t>(g->world);
+    int32_t* d_pairs = g->d_counts;
+    int32_t* d_mine = g->d_counts + 2 * W;
+    int32_t* d_ready = g->d_counts + 2 * W + 2;
+    int32_t* d_myready = g->d_counts + 3 * W + 2;
+    // 1. the counts, each with the rank's status so far
+    const int32_t mine[2] = {n_points, local_rc};
+    soft(hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, s), "hipMemcpyAsync(count)");
+    RCCL_TRY(rccl().AllGather(d_mine, d_pairs, 2, kInt32, g->comm, s));
+    soft(hipMemcpyAsync(g->h_counts.data(), d_pairs, sizeof(int32_t) * 2 * W, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(counts)");
+    soft(hipStreamSynchronize(s), "hipStreamSynchronize");
+    bool peers_ok = true;
+    for (size_t r = 0; r < W; ++r) {
+        counts[r] = local_rc == SLAMX_OK ? g->h_counts[2 * r] : 0;
+        peers_ok = peers_ok && g->h_counts[2 * r + 1] == 0;
+    }
+    int cap = 1, tot = 0;
+    if (local_rc == SLAMX_OK) {
+        const int rc_plan = slamx_mapgather_plan(counts, g->world, &cap, &tot);
+        if (rc_plan != SLAMX_OK) {
+            local_rc = rc_plan;
+            local_msg = slamx_last_error();
+        }
+    }
     if (total != nullptr) {
         *total = tot;
     }
-    // 2. the payload, padded to the largest count (every rank computes the same `cap` from the same counts)
-    if (cap > g->cap) {
+    // 2. buffers for the payload, padded to the largest count (every rank computes the same `cap` from the same counts)
+    if (local_rc == SLAMX_OK && cap > g->cap) {
+        const int grown = std::max(cap, 2 * g->cap);
         dev_free(g->d_send);
         dev_free(g->d_recv);
-        g->d_send = nullptr;
-        g->d_recv = nullptr;
-        const int grown = std::max(cap, 2 * g->cap);
-        SLAMX_TRY(dev_alloc(&g->d_send, static_cast<size_t>(grown) * 3));
-        SLAMX_TRY(dev_alloc(&g->d_recv, static_cast<size_t>(g->world) * grown * 3));
-        g->cap = grown;
+        g->cap = 0;
+        int rc_a = dev_alloc(&g->d_send, static_cast<size_t>(grown) * 3);
+        if (rc_a == SLAMX_OK) {
+            rc_a = dev_alloc(&g->d_recv, W * grown * 3);
+        }
+        if (rc_a == SLAMX_OK) {
+            g->cap = grown;
+        } else {
+            local_rc = rc_a;
+            local_msg = slamx_last_error();
+            dev_free(g->d_send);
+            dev_free(g->d_recv);
+        }
     }
-    HIP_TRY(hipMemsetAsync(g->d_send, 0, static_cast<size_t>(cap) * 3 * sizeof(double), s));
-    if (n_points > 0) {
-        HIP_TRY(hipMemcpyAsync(g->d_send, xyz, static_cast<size_t>(n_points) * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (local_rc == SLAMX_OK) {
+        soft(hipMemsetAsync(g->d_send, 0, static_cast<size_t>(cap) * 3 * sizeof(double), s), "hipMemsetAsync(send)");
+        if (n_points > 0) {
+            soft(hipMemcpyAsync(g->d_send, xyz, static_cast<size_t>(n_points) * 3 * sizeof(double), hipMemcpyHostToDevice, s),
+                 "hipMemcpyAsync(points)");
+        }
     }
+    const int32_t ready = local_rc == SLAMX_OK && peers_ok ? 1 : 0;
+    soft(hipMemcpyAsync(d_myready, &ready, sizeof(ready), hipMemcpyHostToDevice, s), "hipMemcpyAsync(ready)");
+    RCCL_TRY(rccl().AllGather(d_myready, d_ready, 1, kInt32, g->comm, s));
+    soft(hipMemcpyAsync(g->h_counts.data() + 2 * W + 2, d_ready, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s),
+         "hipMemcpyAsync(ready flags)");
+    soft(hipStreamSynchronize(s), "hipStreamSynchronize");
+    int first_not_ready = -1;
+    for (size_t r = 0; r < W && first_not_ready < 0; ++r) {
+        if (g->h_counts[2 * W + 2 + r] == 0) {
+            first_not_ready = static_cast<int>(r);
+        }
+    }
+    if (local_rc != SLAMX_OK) {
+        return fail(local_rc, "mapgather_allgather: " + local_msg + " (the collectives were entered; no payload travelled)");
+    }
+    if (first_not_ready >= 0) {
+        // every rank sees the same flags and skips the payload collective together
+        return fail(SLAMX_ERR_RUNTIME, "mapgather_allgather: rank " + std::to_string(first_not_ready) +
+                                           " reported a local failure; no payload travelled");
+    }
+    // 3. the payload
     RCCL_TRY(rccl().AllGather(g->d_send, g->d_recv, static_cast<size_t>(cap) * 3, kFloat64, g->comm, s));
-    g->h_recv.resize(static_cast<size_t>(g->world) * cap * 3);
+    g->h_recv.resize(W * cap * 3);
     HIP_TRY(hipMemcpyAsync(g->h_recv.data(), g->d_recv, g->h_recv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    // 3. unpack (reports a too small `out` only now: no rank may leave before the collectives)
+    // 4. unpack (reports a too small `out` only now: no rank may leave before the collectives)
     return slamx_mapgather_unpack(g->h_recv.data(), counts, g->world, cap, out, cap_points);
 }
 

@@ -225,7 +225,7 @@ struct MatchView {
     float4* sbox;    // [F][maxKp / 64]  bounding box {min x, min y, max x, max y} of every stage (64 consecutive sorted
                      // positions); min x = +inf when a coordinate of the stage is not finite or beyond +-1e6
     int maxKp;       // sorted arrays' stride: maxK rounded up to 64, plus one padding stage
-    int* mfma_flag;  // [F]  1 = pairs with this frame as TRAIN set take the matrix-core scan (spatial_order_kernel decides)
+    int* mfma_flag;  // [F]  1 = pairs with this frame as TRAIN set take the matrix-core scan (scan_choice_kernel decides)
     int mfma_min_wide;   // ... or at least this many when the frame's keypoints spread over MATCH_MFMA_WIDE_DIAGONAL px
     int mfma_min_train;  // with xdesc: pairs whose TRAIN set has at least this many keypoints take the matrix-core
                          // scan, the others the popcount scan (both kernels are launched, each skips the other's pairs)

@@ -384,3 +384,22 @@ def test_handle_cells_close_children_first_whoever_goes_first(slamx):
     for h in (b2, det, ctx, lvl, b1):
         h.close()  # late finalisers find nothing left to do
     assert log == ["b1", "b2", "det", "ctx"]
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(tmp_path):
+    """with no loadable librccl the map-gather entry points return SLAMX_ERR_RUNTIME with a message (the
+    not-found path once built its message from a second dlerror() call, i.e. from NULL).  The library handle is bound
+    once per process, so this runs in a child; SLAMX_RCCL_NO_FALLBACK keeps the built-in names out."""
+    code = (
+        "import ctypes, sys\n"
+        "lib = ctypes.CDLL(%r)\n"
+        "lib.slamx_last_error.restype = ctypes.c_char_p\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = lib.slamx_mapgather_unique_id(buf)\n"
+        "msg = lib.slamx_last_error().decode()\n"
+        "print(rc, msg)\n"
+        "sys.exit(0 if rc == 2 and 'librccl not found' in msg and 'no_such_librccl' in msg else 1)\n"
+    ) % os.path.join(ROOT, "slam-cin0051_amd", "libslamx.so")
+    env = dict(os.environ, SLAMX_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"), SLAMX_RCCL_NO_FALLBACK="1")
+    p = subprocess.run([os.sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0, p.stdout.decode()

@@ -186,6 +186,13 @@ int main(int argc, char** argv) {
             throw std::runtime_error("-g " + std::to_string(gpus) + ": only " + std::to_string(slamx_device_count()) +
                                      " GPU(s) visible");
         }
+        if (world > 1) {
+            // ... and every rank's context is created HERE, so that a GPU that cannot be opened fails the run before a
+            // thread waits for it in ncclCommInitRank (the threads find these contexts through slam::useDevice)
+            for (int r = 0; r < world; ++r) {
+                (void)slam::detail::context_of_device(r);
+            }
+        }
         std::vector<uint8_t> id(SLAMX_MAPGATHER_ID_BYTES, 0);
         if (gpusGiven) {
             slam::detail::check(slamx_mapgather_unique_id(id.data()));  // handed to every rank's thread
