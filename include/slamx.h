@@ -313,6 +313,95 @@ int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const
 int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
                       float* x4, double* xyz);
 
+/* The same two RANSAC loops with the sample table given by the caller instead of drawn from a seed: idx holds
+ * `iterations` rows of 8 (essential) / 6 (PnP) indices into the correspondences.  slamx_essential_ransac and
+ * slamx_pnp_ransac are exactly these calls on the table their std::mt19937 produces; the batched stage below draws its
+ * tables on the device (slamx_pose_download_samples) and must give the same result as these calls fed with them. */
+int slamx_essential_from_samples(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K,
+                                 const int32_t* idx, int iterations, double threshold_px, double* E, int32_t* n_inliers,
+                                 uint8_t* inlier_mask);
+int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, const int32_t* idx,
+                           int iterations, double threshold, double* R, double* t, int32_t* max_inliers);
+
+/* ---- the pose stage of a device-resident batch (BASELINE.json configs[2]: "+ 2-view essential-matrix / PnP pose") ----
+ * For every frame f of the batch whose matches against its predecessor are on the device (slamx_batch_match_consecutive:
+ * query = f, train = f - 1, or first_train_frame for f = 0), in a fixed number of launches over ALL frames and with no
+ * host round trip, allocation or synchronisation:
+ *   1. PoseEstimator::estimate (src/frontend/pose_estimator.cpp:18-67) with (keypoints1, keypoints2) = (train frame,
+ *      query frame): the correspondences are gathered from the keypoint and match arrays where they are, normalised by
+ *      K^-1; the essential matrix comes from this build's own RANSAC (cv::findEssentialMat is third-party: normalised
+ *      8-point hypotheses, Sampson scoring, first maximum, refit on the inliers -- the algorithm of slamx_essential_ransac,
+ *      same kernels); then simpleRecoverPose (src/frontend/simple_pose_recover.cpp:35-98) on all correspondences.
+ *      Fewer than 8 matches: no pose (pose_estimator.cpp:21-25), SLAMX_POSE_TOO_FEW_MATCHES, R = I, t = 0.
+ *   2. PoseEstimator::triangulatePoints (pose_estimator.cpp:69-104) with K [I|0], K [R|t]: one map point per match.
+ *   3. if pnp_iterations > 0: the RANSAC of LoopClosure::verifyGeometricConsistency (src/backend/loop_closure.cpp:
+ *      173-222) for frame f against the map points of its train frame (those triangulated in step 2 of the pair whose
+ *      QUERY frame the train frame is): 3D point of match.trainIdx, 2D keypoint of match.queryIdx, for every match whose
+ *      train keypoint has a map point; 6-point DLT solvePnP hypotheses (loop_closure.cpp:238-274), reprojection inlier
+ *      count, first maximum from maxInliers = 0 (identity / zero when nothing scores).  Fewer than
+ *      max(6, pnp_min_correspondences) correspondences: SLAMX_POSE_PNP_SKIPPED.
+ * Samples are drawn on the device by a counter-based generator (splitmix64 of (seed, frame slot, hypothesis, draw),
+ * indices redrawn until distinct as loop_closure.cpp:185-193 does); slamx_pose_download_samples returns the tables.
+ * The match lists are taken as slamx_batch_match_consecutive left them (query order, before filterAndSortMatches). */
+typedef struct slamx_pose_config {
+    double K[9];               /* intrinsics, row-major                                                     */
+    int32_t iterations;        /* essential-matrix hypotheses per frame pair, 1..65536                       */
+    double threshold_px;       /* Sampson threshold in pixels (divided by the mean focal length)             */
+    uint32_t seed;
+    int32_t pnp_iterations;    /* RansacMaxIterations (loop_closure.yml); 0 = no PnP step                    */
+    double pnp_threshold;      /* RansacReprojectionThreshold                                                */
+    int32_t pnp_min_correspondences; /* MinMatchesForPnP; values below 6 mean 6                              */
+    int32_t max_matches;       /* capacity per frame pair; 0 = the batch's max_keypoints                     */
+} slamx_pose_config;
+#define SLAMX_POSE_TOO_FEW_MATCHES 1 /* fewer than 8 matches: no essential matrix, no map points             */
+#define SLAMX_POSE_PNP_SKIPPED 2     /* fewer correspondences than the PnP step needs                        */
+#define SLAMX_POSE_MATCH_OVERFLOW 4  /* more matches than max_matches: the first max_matches were used        */
+#define SLAMX_POSE_NO_TRAIN_FRAME 8  /* frame 0 with first_train_frame < 0: nothing to estimate               */
+typedef struct slamx_pose_result {
+    double E[9], R[9], t[3];   /* essential matrix (singular values 1,1,0), pose of the query frame's camera  */
+    double pnp_R[9], pnp_t[3];
+    int32_t n_matches, n_inliers, front[4], pnp_correspondences, pnp_inliers, status, best_hypothesis;
+} slamx_pose_result;
+typedef struct slamx_pose slamx_pose;
+int slamx_pose_create(slamx_batch* b, const slamx_pose_config* cfg, slamx_pose** out);
+void slamx_pose_destroy(slamx_pose* p);
+/* Enqueue the stage for frames [0, nframes) on the context stream (async; no allocation, no synchronisation). */
+int slamx_batch_pose(slamx_pose* p, int nframes, int first_train_frame);
+/* Synchronise and copy out: one result per frame. */
+int slamx_pose_download(slamx_pose* p, int nframes, slamx_pose_result* out);
+/* Map points of one frame's pair, parallel to its match list (n = n_matches): xyz n x 3 doubles, inlier_mask (optional)
+ * n bytes = the essential matrix's inlier flags. */
+int slamx_pose_download_points(slamx_pose* p, int frame, double* xyz, uint8_t* inlier_mask, int cap, int* n);
+/* The sample tables the device drew for one frame: idx [iterations][8], pnp_idx [pnp_iterations][6] (either may be NULL). */
+int slamx_pose_download_samples(slamx_pose* p, int frame, int32_t* idx, int32_t* pnp_idx);
+/* Intermediate products of step 1 for the parity tests: the essential matrix of every hypothesis of one frame
+ * (E_all [iterations][9]) and its Sampson inlier count (counts [iterations]); either may be NULL. */
+int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int32_t* counts);
+/* The 3D-2D correspondences step 3 formed for one frame (for tests): p3d n x 3, p2d n x 2 doubles. */
+int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, double* p2d, int cap, int* n);
+/* Per-kernel device time of the stage (hipEvents on the context stream around every launch of the calls since
+ * profiling was switched on; on = n > 1 records every n-th call only). */
+#define SLAMX_POSE_STAGE_GATHER 0      /* pose_gather_kernel                                                 */
+#define SLAMX_POSE_STAGE_HYPOTHESES 1  /* essential_hyp_kernel (sampling + 8-point solve, lane per hypothesis) */
+#define SLAMX_POSE_STAGE_SCORE 2       /* sampson_score_kernel: every hypothesis x every correspondence       */
+#define SLAMX_POSE_STAGE_SELECT 3      /* pose_select_kernel (first maximum, inlier flags of the winner)      */
+#define SLAMX_POSE_STAGE_REFIT 4       /* essential_refit_kernel (normal matrix of the inliers on FP64 MFMA)  */
+#define SLAMX_POSE_STAGE_FINAL 5       /* pose_final_kernel (refit accepted or not, decomposeEssential)       */
+#define SLAMX_POSE_STAGE_CHEIRALITY 6  /* cheirality_kernel (4 candidates x every correspondence)             */
+#define SLAMX_POSE_STAGE_TRIANGULATE 7 /* triangulate_pairs_kernel                                            */
+#define SLAMX_POSE_STAGE_PNP_GATHER 8  /* pnp_gather_kernel                                                   */
+#define SLAMX_POSE_STAGE_PNP_SOLVE 9   /* pnp_hyp_kernel (sampling + DLT on FP64 MFMA, wave per hypothesis)   */
+#define SLAMX_POSE_STAGE_PNP_SCORE 10  /* pnp_score_kernel + pnp_select_kernel                                */
+#define SLAMX_POSE_STAGE_COUNT 11
+int slamx_pose_set_profiling(slamx_pose* p, int on);
+int slamx_pose_stage_ms(slamx_pose* p, float* avg_ms /* SLAMX_POSE_STAGE_COUNT */, int32_t* launches /* same, optional */);
+/* Keypoints and matches of one frame slot written from the host (a caller that has them from elsewhere -- the keyframe
+ * database of LoopClosure::addKeyframe, loop_closure.cpp:96-109 -- and the parity tests of the pose stage): kps n_kp
+ * keypoints, matches n_matches rows (queryIdx ascending, as the matcher leaves them) against the slot's train frame.
+ * Descriptors of the slot are left as they are. */
+int slamx_batch_upload_results(slamx_batch* b, int frame, const slamx_keypoint* kps, int n_kp, const slamx_match* matches,
+                               int n_matches);
+
 /* ---- image pyramid (BASELINE.json north_star / configs[2]; NO reference counterpart) ----
  * The reference detects on the full-resolution image only (feature_detector.cpp:8-18, Keypoint::size
  * is the constant 6.0, feature_detector.hpp:18,35).  A pyramid is a stack of batches: level 0 has the

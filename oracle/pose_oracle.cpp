@@ -364,9 +364,11 @@ void oracle_triangulate(const double* P1, const double* P2, const float* pts1, c
 // runs -- same sampling, same conditioning, null vector by the one-sided Jacobi SVD, same Sampson
 // test -- used to check the GPU implementation, not to pin it against OpenCV.
 // pts: n x 2 float pixel coordinates.  E_all (optional): iterations x 9, counts_all (optional).
-int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const double* K, int iterations,
-                            double threshold_px, unsigned seed, double* E, int* n_inliers, unsigned char* mask,
-                            double* E_all, int* counts_all) {
+// The loop with the sample table GIVEN (idx: iterations x 8 indices): what oracle_essential_ransac runs after drawing
+// its table, and what the batched GPU stage -- which draws its tables on the device -- is compared with.
+int oracle_essential_from_samples(const float* pts1, const float* pts2, int n, const double* K, const int* table, int iterations,
+                                  double threshold_px, double* E, int* n_inliers, unsigned char* mask, double* E_all,
+                                  int* counts_all) {
     if (n < 8 || iterations <= 0) {
         return -1;
     }
@@ -378,8 +380,6 @@ int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const d
         x2[2 * i] = (static_cast<double>(pts2[2 * i]) - cx) / fx;
         x2[2 * i + 1] = (static_cast<double>(pts2[2 * i + 1]) - cy) / fy;
     }
-    std::mt19937 rng(seed);
-    std::uniform_int_distribution<int> dist(0, n - 1);
     const double thr = threshold_px / (0.5 * (fx + fy));
     const double thr2 = thr * thr;
     int best = -1, best_count = -1;
@@ -404,14 +404,7 @@ int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const d
         return c;
     };
     for (int it = 0; it < iterations; ++it) {
-        int idx[8];
-        int have = 0;
-        while (have < 8) {
-            const int c = dist(rng);
-            if (std::find(idx, idx + have, c) == idx + have) {
-                idx[have++] = c;
-            }
-        }
+        const int* idx = table + static_cast<size_t>(it) * 8;
         double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
         for (int i = 0; i < 8; ++i) {
             c1x += x1[2 * idx[i]];
@@ -553,6 +546,30 @@ int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const d
         std::copy(use_fit ? flags2.begin() : flags.begin(), use_fit ? flags2.end() : flags.end(), mask);
     }
     return best;
+}
+
+int oracle_essential_ransac(const float* pts1, const float* pts2, int n, const double* K, int iterations,
+                            double threshold_px, unsigned seed, double* E, int* n_inliers, unsigned char* mask,
+                            double* E_all, int* counts_all) {
+    if (n < 8 || iterations <= 0) {
+        return -1;
+    }
+    // the sampling rule of the reference's own RANSAC (loop_closure.cpp:177-193) with an explicit seed
+    std::mt19937 rng(seed);
+    std::uniform_int_distribution<int> dist(0, n - 1);
+    std::vector<int> table(static_cast<size_t>(iterations) * 8);
+    for (int it = 0; it < iterations; ++it) {
+        int* idx = &table[static_cast<size_t>(it) * 8];
+        int have = 0;
+        while (have < 8) {
+            const int c = dist(rng);
+            if (std::find(idx, idx + have, c) == idx + have) {
+                idx[have++] = c;
+            }
+        }
+    }
+    return oracle_essential_from_samples(pts1, pts2, n, K, table.data(), iterations, threshold_px, E, n_inliers, mask, E_all,
+                                         counts_all);
 }
 
 }  // extern "C"

@@ -74,6 +74,22 @@ class Camera(C.Structure):
                 ("height", C.c_int32), ("K", C.c_double * 9)]
 
 
+class PoseConfig(C.Structure):
+    """slamx_pose_config (include/slamx.h): the pose stage of a batch."""
+    _fields_ = [("K", C.c_double * 9), ("iterations", C.c_int32), ("threshold_px", C.c_double), ("seed", C.c_uint32),
+                ("pnp_iterations", C.c_int32), ("pnp_threshold", C.c_double), ("pnp_min_correspondences", C.c_int32),
+                ("max_matches", C.c_int32)]
+
+
+POSE_RESULT_DTYPE = np.dtype([("E", "<f8", (3, 3)), ("R", "<f8", (3, 3)), ("t", "<f8", (3,)), ("pnp_R", "<f8", (3, 3)),
+                              ("pnp_t", "<f8", (3,)), ("n_matches", "<i4"), ("n_inliers", "<i4"), ("front", "<i4", (4,)),
+                              ("pnp_correspondences", "<i4"), ("pnp_inliers", "<i4"), ("status", "<i4"),
+                              ("best_hypothesis", "<i4")], align=True)
+POSE_STAGES = ("gather", "hypotheses", "score", "select", "refit", "final", "cheirality", "triangulate", "pnp_gather",
+               "pnp_solve", "pnp_score")
+POSE_TOO_FEW_MATCHES, POSE_PNP_SKIPPED, POSE_MATCH_OVERFLOW, POSE_NO_TRAIN_FRAME = 1, 2, 4, 8
+
+
 class BatchShape(C.Structure):
     _fields_ = [
         ("rows", C.c_int32),
@@ -98,6 +114,9 @@ EXPORTS = [
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_packed_bound", "slamx_batch_download_packed_async",
     "slamx_batch_download_packed_tail", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
+    "slamx_essential_from_samples", "slamx_pnp_from_samples", "slamx_pose_create", "slamx_pose_destroy", "slamx_batch_pose",
+    "slamx_pose_download", "slamx_pose_download_points", "slamx_pose_download_samples", "slamx_pose_download_correspondences", "slamx_pose_download_hypotheses",
+    "slamx_pose_set_profiling", "slamx_pose_stage_ms", "slamx_batch_upload_results",
     "slamx_undistort",
     "slamx_pyramid_create", "slamx_pyramid_destroy", "slamx_pyramid_batch", "slamx_pyramid_level_shape",
     "slamx_pyramid_detect_and_compute",
@@ -184,6 +203,20 @@ def load_library():
     lib.slamx_count_inliers_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, vp]
     lib.slamx_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, C.POINTER(C.c_int32)]
     lib.slamx_essential_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp]
+    lib.slamx_essential_from_samples.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp, vp]
+    lib.slamx_pnp_from_samples.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp, C.POINTER(C.c_int32)]
+    lib.slamx_pose_create.argtypes = [vp, C.POINTER(PoseConfig), C.POINTER(vp)]
+    lib.slamx_pose_destroy.argtypes = [vp]
+    lib.slamx_pose_destroy.restype = None
+    lib.slamx_batch_pose.argtypes = [vp, C.c_int, C.c_int]
+    lib.slamx_pose_download.argtypes = [vp, C.c_int, vp]
+    lib.slamx_pose_download_points.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_pose_download_samples.argtypes = [vp, C.c_int, vp, vp]
+    lib.slamx_pose_download_correspondences.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_pose_download_hypotheses.argtypes = [vp, C.c_int, vp, vp]
+    lib.slamx_pose_set_profiling.argtypes = [vp, C.c_int]
+    lib.slamx_pose_stage_ms.argtypes = [vp, vp, vp]
+    lib.slamx_batch_upload_results.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
     lib.slamx_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.slamx_triangulate.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.slamx_camera_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(Camera)]
@@ -442,6 +475,31 @@ class Context(_Owner):
         _check(self.lib.slamx_essential_ransac(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), iterations,
                                                float(threshold_px), seed, _ptr(E), C.byref(cnt), _ptr(mask)))
         return E, cnt.value, mask
+
+    def essential_from_samples(self, pts1, pts2, K, table, threshold_px=1.0):
+        """slamx_essential_from_samples: the RANSAC loop on a GIVEN sample table (iterations x 8 indices)."""
+        a = np.ascontiguousarray(pts1, dtype=np.float32)
+        b = np.ascontiguousarray(pts2, dtype=np.float32)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        tb = np.ascontiguousarray(table, dtype=np.int32)
+        E = np.empty((3, 3))
+        cnt = C.c_int32()
+        mask = np.zeros(a.shape[0], np.uint8)
+        _check(self.lib.slamx_essential_from_samples(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(tb), tb.shape[0],
+                                                     float(threshold_px), _ptr(E), C.byref(cnt), _ptr(mask)))
+        return E, cnt.value, mask
+
+    def pnp_from_samples(self, p3d, p2d, K, table, threshold):
+        a = np.ascontiguousarray(p3d, dtype=np.float64)
+        b = np.ascontiguousarray(p2d, dtype=np.float64)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        tb = np.ascontiguousarray(table, dtype=np.int32)
+        R = np.empty((3, 3))
+        t = np.empty(3)
+        best = C.c_int32()
+        _check(self.lib.slamx_pnp_from_samples(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(tb), tb.shape[0],
+                                               float(threshold), _ptr(R), _ptr(t), C.byref(best)))
+        return R, t, best.value
 
     def recover_pose(self, E, pts1, pts2, K):
         Ec = np.ascontiguousarray(E, dtype=np.float64)
@@ -714,6 +772,12 @@ class Batch(_Owner):
     def fetch_packed_tail(self, buf, have):
         _check(self.lib.slamx_batch_download_packed_tail(self.h, buf.ctypes.data, int(have), buf.nbytes))
 
+    def upload_results(self, frame, keypoints, matches):
+        """slamx_batch_upload_results: keypoints and matches (queryIdx ascending) of one frame slot from the host."""
+        k = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        _check(self.lib.slamx_batch_upload_results(self.h, frame, _ptr(k), k.shape[0], _ptr(m), m.shape[0]))
+
     def set_profiling(self, n_sets=1, every=1):
         _check(self.lib.slamx_batch_set_profiling_every(self.h, n_sets, every))
 
@@ -721,6 +785,79 @@ class Batch(_Owner):
         ms = (C.c_float * len(STAGES))()
         _check(self.lib.slamx_batch_stage_ms(self.h, set_index, ms))
         return dict(zip(STAGES, [float(x) for x in ms]))
+
+
+class PoseStage(_Owner):
+    """slamx_pose_* (include/slamx.h): essential-matrix RANSAC -> simpleRecoverPose -> triangulatePoints -> PnP RANSAC for
+    every frame pair of a batch, device-resident, a fixed number of launches per call."""
+
+    def __init__(self, batch, K, iterations=256, threshold_px=1.0, seed=0, pnp_iterations=0, pnp_threshold=2.0,
+                 pnp_min_correspondences=6, max_matches=0):
+        self.batch = batch
+        self.lib = batch.lib
+        cfg = PoseConfig()
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        for i in range(9):
+            cfg.K[i] = float(Kc[i])
+        cfg.iterations, cfg.threshold_px, cfg.seed = int(iterations), float(threshold_px), int(seed)
+        cfg.pnp_iterations, cfg.pnp_threshold = int(pnp_iterations), float(pnp_threshold)
+        cfg.pnp_min_correspondences, cfg.max_matches = int(pnp_min_correspondences), int(max_matches)
+        self.cfg = cfg
+        self._hd = _Handle(self.lib.slamx_pose_destroy, batch._hd)
+        _check(self.lib.slamx_pose_create(batch.h, C.byref(cfg), C.byref(self._hd.value)))
+
+    def run(self, nframes, first_train_frame=-1):
+        _check(self.lib.slamx_batch_pose(self.h, nframes, first_train_frame))
+
+    def download(self, nframes):
+        out = np.zeros(nframes, POSE_RESULT_DTYPE)
+        _check(self.lib.slamx_pose_download(self.h, nframes, _ptr(out)))
+        return out
+
+    def points(self, frame):
+        """-> (xyz [n, 3], inlier mask [n]) of one frame's pair, parallel to its match list"""
+        n = C.c_int()
+        try:
+            _check(self.lib.slamx_pose_download_points(self.h, frame, None, None, 0, C.byref(n)))
+        except CapacityError:
+            pass
+        xyz = np.empty((n.value, 3))
+        mask = np.zeros(n.value, np.uint8)
+        _check(self.lib.slamx_pose_download_points(self.h, frame, _ptr(xyz), _ptr(mask), n.value, C.byref(n)))
+        return xyz, mask
+
+    def samples(self, frame):
+        """-> (idx [iterations, 8], pnp_idx [pnp_iterations, 6]) as the device drew them"""
+        idx = np.zeros((self.cfg.iterations, 8), np.int32)
+        pidx = np.zeros((max(self.cfg.pnp_iterations, 0), 6), np.int32)
+        _check(self.lib.slamx_pose_download_samples(self.h, frame, _ptr(idx), _ptr(pidx) if pidx.size else None))
+        return idx, pidx
+
+    def hypotheses(self, frame):
+        """-> (E_all [iterations, 3, 3], counts [iterations]) of one frame's pair"""
+        E = np.empty((self.cfg.iterations, 3, 3))
+        c = np.zeros(self.cfg.iterations, np.int32)
+        _check(self.lib.slamx_pose_download_hypotheses(self.h, frame, _ptr(E), _ptr(c)))
+        return E, c
+
+    def correspondences(self, frame):
+        n = C.c_int()
+        try:
+            _check(self.lib.slamx_pose_download_correspondences(self.h, frame, None, None, 0, C.byref(n)))
+        except CapacityError:
+            pass
+        p3, p2 = np.empty((n.value, 3)), np.empty((n.value, 2))
+        _check(self.lib.slamx_pose_download_correspondences(self.h, frame, _ptr(p3), _ptr(p2), n.value, C.byref(n)))
+        return p3, p2
+
+    def set_profiling(self, every=1):
+        _check(self.lib.slamx_pose_set_profiling(self.h, int(every)))
+
+    def stage_ms(self):
+        ms = np.zeros(len(POSE_STAGES), np.float32)
+        n = np.zeros(len(POSE_STAGES), np.int32)
+        _check(self.lib.slamx_pose_stage_ms(self.h, _ptr(ms), _ptr(n)))
+        return dict(zip(POSE_STAGES, [float(x) for x in ms])), int(n[0])
 
 
 PACKED_HEADER_DTYPE = np.dtype([("nframes", "<i4"), ("width", "<i4"), ("total_keypoints", "<i4"), ("total_matches", "<i4"),

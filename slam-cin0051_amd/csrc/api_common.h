@@ -1,0 +1,142 @@
+// api_common.h -- shared by the host-side translation units of the C ABI (slamx_api.hip, pose_api.hip): the
+// thread-local error slot, the status macros, device allocation helpers and the handle structs.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "slamx_internal.h"
+
+struct slamx_ctx;
+namespace slamx {
+std::string& last_error_slot();  // thread-local, defined in slamx_api.hip (what slamx_last_error() returns)
+void pose_release_context(slamx_ctx* ctx);  // pose_api.hip: frees what the pose entry points keep on a context
+}
+
+namespace {
+
+inline int fail(int code, const std::string& msg) {
+    slamx::last_error_slot() = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            return fail(SLAMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+        }                                                                                                  \
+    } while (0)
+
+#define SLAMX_TRY(expr)       \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_ != SLAMX_OK) { \
+            return rc_;       \
+        }                     \
+    } while (0)
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) {
+        count = 1;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return SLAMX_OK;
+}
+template <typename T>
+void dev_free(T*& p) {
+    if (p != nullptr) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+
+// Scoped device buffer (one-off calls outside the hot path: parity helpers, undistort).
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p != nullptr) {
+            (void)hipFree(p);
+        }
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 1); }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+}  // namespace
+
+struct slamx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string name;
+    int n_cus = 0;
+    // second queue of the context: the blur of a batch beside its sort + NMS (blur_beside_sort), created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
+    // grow-only device scratch of the host-pointer pose entry points (pose_api.hip): carved per call, re-allocated only
+    // when a call needs more than any call before it
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    struct slamx_pose* single_pose = nullptr;  // one-pair workspace behind slamx_essential_ransac / slamx_pnp_ransac
+};
+
+struct slamx_detector {
+    slamx_ctx* ctx = nullptr;
+    slamx_detector_config cfg{};
+    std::vector<int32_t> pattern;  // x1,y1,x2,y2 per surviving pair
+    int8_t* pattern_dev = nullptr;
+    uint2* moment_weights_dev = nullptr;  // moment_weight_table() for PatchSize / 2 <= 15
+    double* weights_dev = nullptr;
+    slamx_batch* single = nullptr;  // lazily created 1-frame batch behind the host-buffer API
+};
+
+struct slamx_matcher {
+    slamx_ctx* ctx = nullptr;
+    slamx_matcher_config cfg{};
+    // scratch behind slamx_matcher_match: a 2-"frame" layout, frame 0 = train, frame 1 = query
+    int cap = 0, width = 0;
+    uint8_t* desc = nullptr;
+    slamx_keypoint* kps = nullptr;
+    int* n_kp = nullptr;
+    slamx_match* matches = nullptr;
+    int* n_matches = nullptr;
+    int2* best = nullptr;
+    int* second = nullptr;
+    uint8_t* xdesc = nullptr;  // [2][cap][64]
+};
+
+struct slamx_batch {
+    slamx_detector* det = nullptr;
+    slamx_batch_shape shape{};
+    slamx::BatchView v{};
+    uint8_t* frames = nullptr;
+    // matcher outputs (allocated on first use)
+    slamx_match* matches = nullptr;
+    int* n_matches = nullptr;
+    int2* best = nullptr;
+    int* second = nullptr;
+    uint8_t* xdesc = nullptr;  // [F][maxK][64] expanded descriptors of the matrix-core matcher
+    uint8_t* pack = nullptr;   // packed results of slamx_batch_download_packed_async (worst-case size, on first use)
+    size_t pack_bytes = 0;
+    // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
+    // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS_BUILD|5|NMS_ROUNDS|6|BLUR|7|MOMENTS|8|TRIG|9|BRIEF|10|MATCH|11|EMIT|12
+    static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
+    int n_sets = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<char> ev_valid;
+    long long calls = 0;  // detect_and_compute calls since profiling was switched on
+    int cur_set = 0;
+    int every = 1;        // only every `every`-th call records events (an event between two kernels keeps
+                          // the second from ramping up while the first drains: ~9 % on the bench step)
+    bool active = false;  // the current call records
+    int last_frames = 0;
+    int last_status = 0;  // per-frame status bits seen by the most recent slamx_batch_download
+};
+

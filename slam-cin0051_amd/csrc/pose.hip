@@ -22,6 +22,8 @@
 // to the singular vectors with SVD-level accuracy while every O(n * 12^2) contraction stays on MFMA.
 // The 3x3 and 4x4 problems (orthonormalisation, essential-matrix decomposition, triangulation) are
 // one-sided Jacobi SVDs in registers, one per lane.
+#include <algorithm>
+
 #include "slamx_internal.h"
 
 #pragma clang fp contract(off)
@@ -179,13 +181,17 @@ __device__ void triangulate_dlt(const double* P1, const double* P2, float x1, fl
 constexpr int PNP_MAX_ROWS = 64;  // 2n <= 64
 constexpr int LD = 16;            // all LDS matrices are padded to 16 columns
 
-struct PnpWork {
-    double A[PNP_MAX_ROWS * LD];
+// LDS work area of one wave's preconditioned Jacobi SVD: A holds up to ROWS rows
+template <int ROWS>
+struct JacobiWork {
+    double A[ROWS * LD];
     double G[LD * LD];
     double Vp[LD * LD];
     double Vt[LD * LD];  // accumulated V
-    double T[PNP_MAX_ROWS * LD];
+    double T[(ROWS > LD ? ROWS : LD) * LD];
 };
+typedef JacobiWork<PNP_MAX_ROWS> PnpWork;  // solvePnP with up to 32 points (slamx_pnp_dlt_batch)
+typedef JacobiWork<16> PnpWork6;           // the RANSAC's 6-point samples: 12 rows
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -289,7 +295,8 @@ __device__ void jacobi_sym(double* G, double* Vp, int n, int lane) {
 // Right singular vector of the smallest singular value of w.A (rows x ncols, ncols <= 12, zero padded
 // to 16 columns): three passes of {G = A^T A on MFMA; cyclic Jacobi on G; A <- A Vp, Vt <- Vt Vp}.
 // Returns the column of w.Vt that holds it (wave-uniform).
-__device__ int wave_null_column(PnpWork& w, int rows, int ncols, int lane) {
+template <typename Work>
+__device__ int wave_null_column(Work& w, int rows, int ncols, int lane) {
     for (int e = lane; e < LD * LD; e += 64) {
         w.Vt[e] = (e / LD == e % LD) ? 1.0 : 0.0;
     }
@@ -328,6 +335,76 @@ __device__ int wave_null_column(PnpWork& w, int rows, int ncols, int lane) {
     return jmin;
 }
 
+// One hypothesis, one wave: build A (loop_closure.cpp:249-255) from n_points correspondences, zero padded to 16 columns;
+// pt3(i) / pt2(i) return pointers to the i-th 3-D point and pixel.  Lane 0 writes R (9), t (3) and optionally the DLT
+// null vector (12).
+template <typename Work, typename P3, typename P2>
+__device__ void wave_solve_pnp(Work& w, int n_points, P3 pt3, P2 pt2, int lane, double* R_out, double* t_out, double* null_out) {
+    const int rows = 2 * n_points;
+    for (int e = lane; e < rows * LD; e += 64) {
+        const int r = e / LD;
+        const int c = e - r * LD;
+        const int i = r >> 1;
+        const double* P3p = pt3(i);
+        const double* P2p = pt2(i);
+        const double X = P3p[0], Y = P3p[1], Z = P3p[2];
+        const double uv = (r & 1) ? P2p[1] : P2p[0];
+        double val = 0.0;
+        const int cc = (r & 1) ? c - 4 : c;  // second row of the pair shifts the [X Y Z 1] block by 4
+        if (cc >= 0 && cc < 4) {
+            val = cc == 0 ? X : cc == 1 ? Y : cc == 2 ? Z : 1.0;
+        } else if (c >= 8 && c < 12) {
+            const double base = c == 8 ? X : c == 9 ? Y : c == 10 ? Z : 1.0;
+            val = -uv * base;
+        }
+        w.A[e] = val;
+    }
+    const int jmin = wave_null_column(w, rows, 12, lane);
+    if (lane == 0) {
+        double p[12];
+        for (int k = 0; k < 12; ++k) {
+            p[k] = w.Vt[k * LD + jmin];
+            if (null_out != nullptr) {
+                null_out[k] = p[k];
+            }
+        }
+        // :260 column-major 3x4 map of the row-major DLT vector (reference behaviour, kept)
+        double R0[9], t0[3];
+        for (int c = 0; c < 3; ++c) {
+            for (int r = 0; r < 3; ++r) {
+                R0[r * 3 + c] = p[c * 3 + r];
+            }
+        }
+        for (int r = 0; r < 3; ++r) {
+            t0[r] = p[9 + r];
+        }
+        double Ur[9], Sr[3], Vr[9], Vrt[9], UVt[9], UD[9], Rm[9];
+        svd3(R0, Ur, Sr, Vr);
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                Vrt[i * 3 + j] = Vr[j * 3 + i];
+            }
+        }
+        mul3(Ur, Vrt, UVt);
+        const double det = det3(UVt);
+        const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, det};
+        mul3(Ur, D, UD);
+        mul3(UD, Vrt, Rm);
+        double fro = 0.0;
+        for (int k = 0; k < 9; ++k) {
+            fro += R0[k] * R0[k];
+        }
+        fro = sqrt(fro);
+        for (int k = 0; k < 9; ++k) {
+            R_out[k] = Rm[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            t_out[k] = t0[k] / fro;
+        }
+    }
+    wave_sync();
+}
+
 __global__ __launch_bounds__(256) void pnp_dlt_kernel(const double* __restrict__ p3d, const double* __restrict__ p2d,
                                                       int n_points, int n_hyp, double* __restrict__ R_out,
                                                       double* __restrict__ t_out, double* __restrict__ null_out) {
@@ -335,71 +412,13 @@ __global__ __launch_bounds__(256) void pnp_dlt_kernel(const double* __restrict__
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork) / sizeof(double)));
-    const int rows = 2 * n_points;
     for (int h = blockIdx.x * 4 + wave; h < n_hyp; h += gridDim.x * 4) {  // wave-uniform
-        // build A (loop_closure.cpp:249-255), zero padded to 16 columns
-        for (int e = lane; e < rows * LD; e += 64) {
-            const int r = e / LD;
-            const int c = e - r * LD;
-            const int i = r >> 1;
-            const double* P3 = p3d + (static_cast<size_t>(h) * n_points + i) * 3;
-            const double* P2 = p2d + (static_cast<size_t>(h) * n_points + i) * 2;
-            const double X = P3[0], Y = P3[1], Z = P3[2];
-            const double uv = (r & 1) ? P2[1] : P2[0];
-            double val = 0.0;
-            const int cc = (r & 1) ? c - 4 : c;  // second row of the pair shifts the [X Y Z 1] block by 4
-            if (cc >= 0 && cc < 4) {
-                val = cc == 0 ? X : cc == 1 ? Y : cc == 2 ? Z : 1.0;
-            } else if (c >= 8 && c < 12) {
-                const double base = c == 8 ? X : c == 9 ? Y : c == 10 ? Z : 1.0;
-                val = -uv * base;
-            }
-            w.A[e] = val;
-        }
-        const int jmin = wave_null_column(w, rows, 12, lane);
-        if (lane == 0) {
-            double p[12];
-            for (int k = 0; k < 12; ++k) {
-                p[k] = w.Vt[k * LD + jmin];
-                if (null_out != nullptr) {
-                    null_out[static_cast<size_t>(h) * 12 + k] = p[k];
-                }
-            }
-            // :260 column-major 3x4 map of the row-major DLT vector (reference behaviour, kept)
-            double R0[9], t0[3];
-            for (int c = 0; c < 3; ++c) {
-                for (int r = 0; r < 3; ++r) {
-                    R0[r * 3 + c] = p[c * 3 + r];
-                }
-            }
-            for (int r = 0; r < 3; ++r) {
-                t0[r] = p[9 + r];
-            }
-            double Ur[9], Sr[3], Vr[9], Vrt[9], UVt[9], UD[9], Rm[9];
-            svd3(R0, Ur, Sr, Vr);
-            for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) {
-                    Vrt[i * 3 + j] = Vr[j * 3 + i];
-                }
-            }
-            mul3(Ur, Vrt, UVt);
-            const double det = det3(UVt);
-            const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, det};
-            mul3(Ur, D, UD);
-            mul3(UD, Vrt, Rm);
-            double fro = 0.0;
-            for (int k = 0; k < 9; ++k) {
-                fro += R0[k] * R0[k];
-            }
-            fro = sqrt(fro);
-            for (int k = 0; k < 9; ++k) {
-                R_out[static_cast<size_t>(h) * 9 + k] = Rm[k];
-            }
-            for (int k = 0; k < 3; ++k) {
-                t_out[static_cast<size_t>(h) * 3 + k] = t0[k] / fro;
-            }
-        }
-        wave_sync();
+        const double* b3 = p3d + static_cast<size_t>(h) * n_points * 3;
+        const double* b2 = p2d + static_cast<size_t>(h) * n_points * 2;
+        wave_solve_pnp(
+            w, n_points, [&](int i) { return b3 + 3 * i; }, [&](int i) { return b2 + 2 * i; }, lane,
+            R_out + static_cast<size_t>(h) * 9, t_out + static_cast<size_t>(h) * 3,
+            null_out != nullptr ? null_out + static_cast<size_t>(h) * 12 : nullptr);
     }
 }
 
@@ -549,94 +568,375 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double* __restri
     }
 }
 
-// ---------------- f3: essential matrix from 8 correspondences, one wave per hypothesis ----------------
-// The reference calls cv::findEssentialMat(points1, points2, K, cv::RANSAC) (pose_estimator.cpp:37-47,
-// third-party).  This build's own estimator: normalised 8-point algorithm on K^-1-normalised points
-// (Hartley conditioning of the 8 samples, null vector of the 8 x 9 constraint matrix with the same
-// MFMA Gram / Jacobi iteration as the PnP, projection onto the essential manifold by a 3 x 3 SVD),
-// hypotheses scored by the Sampson distance.  x1, x2: [n_hyp][8][2] normalised sample coordinates.
-__global__ __launch_bounds__(256) void essential_8pt_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
-                                                            int n_hyp, double* __restrict__ E_out) {
-    extern __shared__ double pose_lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork) / sizeof(double)));
-    for (int h = blockIdx.x * 4 + wave; h < n_hyp; h += gridDim.x * 4) {  // wave-uniform
-        const double* a = x1 + static_cast<size_t>(h) * 16;
-        const double* b = x2 + static_cast<size_t>(h) * 16;
-        // Hartley conditioning: centroid to the origin, mean distance sqrt(2) (every lane computes it)
-        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
-        for (int i = 0; i < 8; ++i) {
-            c1x += a[2 * i];
-            c1y += a[2 * i + 1];
-            c2x += b[2 * i];
-            c2y += b[2 * i + 1];
+// =====================================================================================================================
+// The pose stage of a batch: every kernel below runs over ALL frame pairs of the batch in one launch (blockIdx.y or
+// blockIdx.x = frame slot) and reads its sizes from device memory, so the host enqueues a fixed sequence of launches
+// with no allocation, copy or synchronisation in between.  The one-pair entry points (slamx_essential_from_samples,
+// slamx_pnp_from_samples) run the SAME kernels on a workspace of one slot.
+//
+// Parallelisation.  A RANSAC hypothesis is a tiny dense problem; 256 pairs x 256 hypotheses are 65k of them.  The
+// 8-point solve maps ONE HYPOTHESIS TO ONE LANE, everything in registers: the null vector of the 8 x 9 constraint matrix
+// comes from 8 Householder reflections (A Q = [L 0], z = Q e_9: exact null vector of whatever rank A has, backward
+// stable, ~1.5k flops, no iteration) -- a wave per hypothesis (the first version: Gram matrix on MFMA + cyclic Jacobi
+// in LDS) spends 64 lanes on the scalar rotation arithmetic of one problem, ~250k wave instructions per hypothesis.  The
+// scoring kernels hold a correspondence per lane and stream the hypotheses through LDS.  What IS a dense contraction
+// stays on the FP64 matrix cores: the 9 x 9 normal matrix of the refit over all inliers of a pair (essential_refit_
+// kernel) and the DLT systems of solvePnP (pnp_hyp_kernel, A^T A of loop_closure.cpp:249-258).
+// =====================================================================================================================
+
+// Sampson test of one correspondence under one essential matrix (normalised units), as cv-style RANSACs score it:
+// r^2 / (|E x1|_xy^2 + |E^T x2|_xy^2) < thr2.  Same operations, same order as the CPU checker of the tests.
+__device__ __forceinline__ bool sampson_inlier(const double* e, double u1, double v1, double u2, double v2, double thr2) {
+    const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
+    const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
+    const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
+    const double et0 = e[0] * u2 + e[3] * v2 + e[6];
+    const double et1 = e[1] * u2 + e[4] * v2 + e[7];
+    const double r = u2 * ex0 + v2 * ex1 + ex2;
+    const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+    return den > 0.0 && r * r < thr2 * den;
+}
+
+// En (conditioned null vector, row-major 3 x 3) -> essential matrix: undo the conditioning (E = T2^T En T1,
+// T = [s 0 -s cx; 0 s -s cy; 0 0 1]) and project onto singular values (1, 1, 0).
+__device__ void essential_from_null_vector(const double* En, double s1, double c1x, double c1y, double s2, double c2x,
+                                           double c2y, double* Ef) {
+    const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+    const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
+    double tmp[9], E0[9], U[9], S[3], V[9], Vt3[9], UD[9];
+    mul3(En, T1, tmp);
+    mul3(T2t, tmp, E0);
+    svd3(E0, U, S, V);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            Vt3[i * 3 + j] = V[j * 3 + i];
         }
-        c1x /= 8.0;
-        c1y /= 8.0;
-        c2x /= 8.0;
-        c2y /= 8.0;
-        double d1 = 0, d2 = 0;
-        for (int i = 0; i < 8; ++i) {
-            const double ux = a[2 * i] - c1x, uy = a[2 * i + 1] - c1y;
-            const double vx = b[2 * i] - c2x, vy = b[2 * i + 1] - c2y;
-            d1 += sqrt(ux * ux + uy * uy);
-            d2 += sqrt(vx * vx + vy * vy);
-        }
-        const double s1 = d1 > 0.0 ? sqrt(2.0) * 8.0 / d1 : 1.0;
-        const double s2 = d2 > 0.0 ? sqrt(2.0) * 8.0 / d2 : 1.0;
-        // constraint rows x2^T E x1 = 0, E row-major: [u2 u1, u2 v1, u2, v2 u1, v2 v1, v2, u1, v1, 1]
-        for (int e = lane; e < 8 * LD; e += 64) {
-            const int r = e / LD;
-            const int c = e - r * LD;
-            const double u1 = (a[2 * r] - c1x) * s1, v1 = (a[2 * r + 1] - c1y) * s1;
-            const double u2 = (b[2 * r] - c2x) * s2, v2 = (b[2 * r + 1] - c2y) * s2;
-            const double p1[3] = {u1, v1, 1.0};
-            const double p2[3] = {u2, v2, 1.0};
-            w.A[e] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
-        }
-        wave_sync();
-        const int jmin = wave_null_column(w, 8, 9, lane);
-        if (lane == 0) {
-            double En[9];
-            for (int k = 0; k < 9; ++k) {
-                En[k] = w.Vt[k * LD + jmin];
-            }
-            // undo the conditioning: E = T2^T En T1, T = [s 0 -s cx; 0 s -s cy; 0 0 1]
-            const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
-            const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
-            double tmp[9], E0[9];
-            mul3(En, T1, tmp);
-            mul3(T2t, tmp, E0);
-            // nearest essential matrix: singular values (1, 1, 0)
-            double U[9], S[3], V[9], Vt3[9], UD[9], Ef[9];
-            svd3(E0, U, S, V);
-            for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) {
-                    Vt3[i * 3 + j] = V[j * 3 + i];
-                }
-            }
-            const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
-            mul3(U, D, UD);
-            mul3(UD, Vt3, Ef);
-            for (int k = 0; k < 9; ++k) {
-                E_out[static_cast<size_t>(h) * 9 + k] = Ef[k];
-            }
-        }
-        wave_sync();
+    }
+    const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+    mul3(U, D, UD);
+    mul3(UD, Vt3, Ef);
+}
+
+// ---- correspondences of every pair, from where the keypoints and matches are ----
+// pair p = QUERY frame p against its train frame (p - 1, or first_train_frame for p = 0).  "Frame 1" of
+// PoseEstimator::estimate / triangulatePoints is the TRAIN frame (the older one), "frame 2" the query frame.
+__global__ __launch_bounds__(256) void pose_gather_kernel(PoseSource src, PoseWork w, PoseParams prm, int first_train_frame) {
+    const int p = blockIdx.y;
+    const int tf = p > 0 ? p - 1 : first_train_frame;
+    int n = tf >= 0 ? src.n_matches[p] : 0;
+    int status = tf >= 0 ? 0 : SLAMX_POSE_NO_TRAIN_FRAME;
+    if (n > prm.cap) {
+        n = prm.cap;
+        status |= SLAMX_POSE_MATCH_OVERFLOW;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.n[p] = n;
+        slamx_pose_result r{};  // E = 0; R = I, t = 0 until a pose is found (the reference leaves R, t untouched)
+        r.R[0] = r.R[4] = r.R[8] = 1.0;
+        r.pnp_R[0] = r.pnp_R[4] = r.pnp_R[8] = 1.0;
+        r.n_matches = n;
+        r.best_hypothesis = -1;
+        r.status = status | (n < 8 && tf >= 0 ? SLAMX_POSE_TOO_FEW_MATCHES : 0);
+        w.res[p] = r;
+    }
+    const slamx_match* mm = src.matches + static_cast<size_t>(p) * src.maxK;
+    const slamx_keypoint* kq = src.kps + static_cast<size_t>(p) * src.maxK;
+    const slamx_keypoint* kt = src.kps + static_cast<size_t>(tf < 0 ? 0 : tf) * src.maxK;
+    const size_t base = static_cast<size_t>(p) * prm.cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const slamx_match m = mm[i];
+        const float2 a = make_float2(kt[m.trainIdx].x, kt[m.trainIdx].y);
+        const float2 b = make_float2(kq[m.queryIdx].x, kq[m.queryIdx].y);
+        w.p1[base + i] = a;
+        w.p2[base + i] = b;
+        // pose_estimator.cpp:60-65: (pt.x - cx) / fx in double
+        w.x1[base + i] = make_double2((static_cast<double>(a.x) - prm.cx) / prm.fx, (static_cast<double>(a.y) - prm.cy) / prm.fy);
+        w.x2[base + i] = make_double2((static_cast<double>(b.x) - prm.cx) / prm.fx, (static_cast<double>(b.y) - prm.cy) / prm.fy);
     }
 }
 
-// Least-squares refit of the winning hypothesis on its inliers (flags): the same conditioned
-// 8-point equations over all inliers, 9 x 9 normal matrix accumulated on MFMA in chunks of 64 rows,
-// smallest eigenvector by cyclic Jacobi, projection onto the essential manifold.  One wave.
-__global__ __launch_bounds__(64) void essential_refit_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
-                                                             const uint8_t* __restrict__ flags, int n,
-                                                             double* __restrict__ E_out) {
+// one pair whose pixel points (p1, p2) and count (n[0]) came from the host
+__global__ __launch_bounds__(256) void pose_load_points_kernel(PoseWork w, PoseParams prm) {
+    const int n = w.n[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 a = w.p1[i], b = w.p2[i];
+        w.x1[i] = make_double2((static_cast<double>(a.x) - prm.cx) / prm.fx, (static_cast<double>(a.y) - prm.cy) / prm.fy);
+        w.x2[i] = make_double2((static_cast<double>(b.x) - prm.cx) / prm.fx, (static_cast<double>(b.y) - prm.cy) / prm.fy);
+    }
+}
+
+// ---- f3: essential matrix from 8 correspondences, ONE LANE per hypothesis ----
+// The reference calls cv::findEssentialMat(points1, points2, K, cv::RANSAC) (pose_estimator.cpp:37-47, third-party).
+// This build's own estimator: normalised 8-point algorithm on K^-1-normalised points -- Hartley conditioning of the 8
+// samples, null vector of the 8 x 9 constraint matrix, projection onto the essential manifold by a 3 x 3 SVD --,
+// hypotheses scored by the Sampson distance.
+__global__ __launch_bounds__(64) void essential_hyp_kernel(PoseWork w, PoseParams prm) {
+    const int p = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = w.n[p];
+    if (h >= prm.iterations || n < 8) {
+        return;
+    }
+    const size_t hh = static_cast<size_t>(p) * prm.iterations + h;
+    int idx[8];
+    if (prm.device_sampling != 0) {
+        pose_draw_sample(prm.seed, 0, p, h, n, 8, idx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            w.idx[hh * 8 + i] = idx[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = w.idx[hh * 8 + i];
+            idx[i] = c < 0 ? 0 : (c >= n ? n - 1 : c);  // a caller's table: keep the loads inside the pair
+        }
+    }
+    const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
+    const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
+    double a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 u = X1[idx[i]], v = X2[idx[i]];
+        a[2 * i] = u.x;
+        a[2 * i + 1] = u.y;
+        b[2 * i] = v.x;
+        b[2 * i + 1] = v.y;
+    }
+    // Hartley conditioning: centroid to the origin, mean distance sqrt(2)
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c1x += a[2 * i];
+        c1y += a[2 * i + 1];
+        c2x += b[2 * i];
+        c2y += b[2 * i + 1];
+    }
+    c1x /= 8.0;
+    c1y /= 8.0;
+    c2x /= 8.0;
+    c2y /= 8.0;
+    double d1 = 0, d2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double ux = a[2 * i] - c1x, uy = a[2 * i + 1] - c1y;
+        const double vx = b[2 * i] - c2x, vy = b[2 * i + 1] - c2y;
+        d1 += sqrt(ux * ux + uy * uy);
+        d2 += sqrt(vx * vx + vy * vy);
+    }
+    const double s1 = d1 > 0.0 ? sqrt(2.0) * 8.0 / d1 : 1.0;
+    const double s2 = d2 > 0.0 ? sqrt(2.0) * 8.0 / d2 : 1.0;
+    // constraint rows x2^T E x1 = 0, E row-major: [u2 u1, u2 v1, u2, v2 u1, v2 v1, v2, u1, v1, 1]
+    double A[8][9];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const double u1 = (a[2 * r] - c1x) * s1, v1 = (a[2 * r + 1] - c1y) * s1;
+        const double u2 = (b[2 * r] - c2x) * s2, v2 = (b[2 * r + 1] - c2y) * s2;
+        A[r][0] = u2 * u1;
+        A[r][1] = u2 * v1;
+        A[r][2] = u2;
+        A[r][3] = v2 * u1;
+        A[r][4] = v2 * v1;
+        A[r][5] = v2;
+        A[r][6] = u1;
+        A[r][7] = v1;
+        A[r][8] = 1.0;
+    }
+    // Null vector by Householder reflections from the right: A H_0 ... H_7 = [L 0], so z = H_0 ... H_7 e_8 satisfies
+    // A z = 0 whatever the rank of A.  H_k = I - beta_k v_k v_k^T acts on columns k..8; v_k replaces row k's tail.
+    double beta[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = k; c < 9; ++c) {
+            s += A[k][c] * A[k][c];
+        }
+        const double nrm = sqrt(s);
+        const double alpha = A[k][k] >= 0.0 ? -nrm : nrm;
+        A[k][k] -= alpha;  // v = x - alpha e_1 (no cancellation: alpha has the opposite sign of x_0)
+        double vtv = 0.0;
+#pragma unroll
+        for (int c = k; c < 9; ++c) {
+            vtv += A[k][c] * A[k][c];
+        }
+        const double bk = vtv > 0.0 ? 2.0 / vtv : 0.0;
+        beta[k] = bk;
+#pragma unroll
+        for (int j = k + 1; j < 8; ++j) {
+            double d = 0.0;
+#pragma unroll
+            for (int c = k; c < 9; ++c) {
+                d += A[j][c] * A[k][c];
+            }
+            d *= bk;
+#pragma unroll
+            for (int c = k; c < 9; ++c) {
+                A[j][c] -= d * A[k][c];
+            }
+        }
+    }
+    double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1.0};
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        double d = 0.0;
+#pragma unroll
+        for (int c = k; c < 9; ++c) {
+            d += z[c] * A[k][c];
+        }
+        d *= beta[k];
+#pragma unroll
+        for (int c = k; c < 9; ++c) {
+            z[c] -= d * A[k][c];
+        }
+    }
+    double Ef[9];
+    essential_from_null_vector(z, s1, c1x, c1y, s2, c2x, c2y, Ef);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        w.Eh[hh * 9 + k] = Ef[k];
+    }
+    w.counts[hh] = 0;  // sampson_score_kernel adds into it
+}
+
+// ---- every hypothesis against every correspondence of its pair ----
+// A lane holds SCORE_PPT correspondences in registers; the hypotheses of the pair stream through LDS in tiles of 64.
+// counts[p][h] += number of correspondences of this block's chunk that pass.  Integer sums: order-free.
+constexpr int SCORE_PPT = 2;
+constexpr int SCORE_TILE = 64;
+__global__ __launch_bounds__(256) void sampson_score_kernel(PoseWork w, PoseParams prm) {
+    __shared__ double Et[SCORE_TILE * 9];
+    __shared__ int cnt[SCORE_TILE];
+    const int p = blockIdx.y;
+    const int n = w.n[p];
+    const int first = blockIdx.x * (256 * SCORE_PPT);
+    if (n < 8 || first >= n) {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
+    const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
+    double u1[SCORE_PPT], v1[SCORE_PPT], u2[SCORE_PPT], v2[SCORE_PPT];
+    bool live[SCORE_PPT];
+#pragma unroll
+    for (int q = 0; q < SCORE_PPT; ++q) {
+        const int i = first + q * 256 + static_cast<int>(threadIdx.x);
+        live[q] = i < n;
+        const double2 a = live[q] ? X1[i] : make_double2(0.0, 0.0);
+        const double2 b = live[q] ? X2[i] : make_double2(0.0, 0.0);
+        u1[q] = a.x;
+        v1[q] = a.y;
+        u2[q] = b.x;
+        v2[q] = b.y;
+    }
+    const double* Eh = w.Eh + static_cast<size_t>(p) * prm.iterations * 9;
+    int* counts = w.counts + static_cast<size_t>(p) * prm.iterations;
+    for (int h0 = 0; h0 < prm.iterations; h0 += SCORE_TILE) {
+        const int nh = min(SCORE_TILE, prm.iterations - h0);
+        __syncthreads();  // the previous tile has been consumed
+        for (int e = threadIdx.x; e < nh * 9; e += 256) {
+            Et[e] = Eh[static_cast<size_t>(h0) * 9 + e];
+        }
+        if (threadIdx.x < SCORE_TILE) {
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        int mine = 0;  // lane l of a wave keeps the wave's count for hypothesis h0 + l
+        for (int k = 0; k < nh; ++k) {
+            const double* e = Et + k * 9;
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < SCORE_PPT; ++q) {
+                const bool in = live[q] && sampson_inlier(e, u1[q], v1[q], u2[q], v2[q], prm.thr2);
+                c += __builtin_popcountll(__ballot(in));
+            }
+            mine += lane == k ? c : 0;
+        }
+        if (lane < nh && mine != 0) {
+            atomicAdd(&cnt[lane], mine);
+        }
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < nh && cnt[threadIdx.x] != 0) {
+            atomicAdd(&counts[h0 + threadIdx.x], cnt[threadIdx.x]);
+        }
+    }
+}
+
+// ---- first maximum, its matrix and its inlier flags; one workgroup per pair ----
+__global__ __launch_bounds__(256) void pose_select_kernel(PoseWork w, PoseParams prm) {
+    __shared__ int best_c[256], best_i[256];
+    __shared__ double eb[9];
+    const int p = blockIdx.x;
+    const int n = w.n[p];
+    if (n < 8) {
+        return;  // uniform
+    }
+    const int* counts = w.counts + static_cast<size_t>(p) * prm.iterations;
+    int bc = -1, bi = 0x7fffffff;
+    for (int h = threadIdx.x; h < prm.iterations; h += 256) {  // ascending: strict '>' keeps the first maximum
+        const int c = counts[h];
+        if (c > bc) {
+            bc = c;
+            bi = h;
+        }
+    }
+    best_c[threadIdx.x] = bc;
+    best_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (static_cast<int>(threadIdx.x) < d) {
+            const int oc = best_c[threadIdx.x + d], oi = best_i[threadIdx.x + d];
+            if (oc > best_c[threadIdx.x] || (oc == best_c[threadIdx.x] && oi < best_i[threadIdx.x])) {
+                best_c[threadIdx.x] = oc;
+                best_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int best = best_i[0];
+    if (threadIdx.x < 9) {
+        const double v = w.Eh[(static_cast<size_t>(p) * prm.iterations + best) * 9 + threadIdx.x];
+        eb[threadIdx.x] = v;
+        w.Ebest[static_cast<size_t>(p) * 9 + threadIdx.x] = v;
+        w.Efit[static_cast<size_t>(p) * 9 + threadIdx.x] = v;  // the refit replaces it when it has 8 inliers to work with
+    }
+    if (threadIdx.x == 0) {
+        w.sel[p * 4 + 0] = best;
+        w.sel[p * 4 + 1] = best_c[0];
+    }
+    __syncthreads();
+    const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
+    const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
+    uint8_t* fa = w.flags_a + static_cast<size_t>(p) * prm.cap;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        e[k] = eb[k];
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double2 a = X1[i], b = X2[i];
+        fa[i] = sampson_inlier(e, a.x, a.y, b.x, b.y, prm.thr2) ? 1 : 0;
+    }
+}
+
+// ---- least-squares refit of the winning hypothesis on its inliers; one wave per pair ----
+// The same conditioned 8-point equations over all inliers: the 9 x 9 normal matrix is accumulated on the FP64 matrix
+// cores in chunks of 64 rows (A^T A: the dense contraction of this step), smallest eigenvector by cyclic Jacobi,
+// projection onto the essential manifold.
+__global__ __launch_bounds__(64) void essential_refit_kernel(PoseWork w, PoseParams prm) {
     extern __shared__ double pose_lds[];
     __shared__ double red[64][6];
+    const int p = blockIdx.x;
+    const int n = w.n[p];
+    if (n < 8) {
+        return;
+    }
     const int lane = threadIdx.x;
-    PnpWork& w = *reinterpret_cast<PnpWork*>(pose_lds);
+    const double* x1 = reinterpret_cast<const double*>(w.x1 + static_cast<size_t>(p) * prm.cap);
+    const double* x2 = reinterpret_cast<const double*>(w.x2 + static_cast<size_t>(p) * prm.cap);
+    const uint8_t* flags = w.flags_a + static_cast<size_t>(p) * prm.cap;
+    double* E_out = w.Efit + static_cast<size_t>(p) * 9;
+    PnpWork& wk = *reinterpret_cast<PnpWork*>(pose_lds);  // A: the 64 rows of a chunk
     // conditioning over the inliers: centroids, then mean distances
     double acc[6] = {0, 0, 0, 0, 0, 0};  // sum u1, v1, u2, v2, count
     for (int i = lane; i < n; i += 64) {
@@ -660,7 +960,7 @@ __global__ __launch_bounds__(64) void essential_refit_kernel(const double* __res
     }
     const double cnt = tot[4];
     if (cnt < 8.0) {
-        return;  // wave-uniform; E_out keeps the minimal-sample model
+        return;  // wave-uniform; Efit keeps the minimal-sample model
     }
     const double c1x = tot[0] / cnt, c1y = tot[1] / cnt, c2x = tot[2] / cnt, c2y = tot[3] / cnt;
     double dd[2] = {0, 0};
@@ -683,97 +983,513 @@ __global__ __launch_bounds__(64) void essential_refit_kernel(const double* __res
     }
     const double s1 = d1 > 0.0 ? sqrt(2.0) * cnt / d1 : 1.0;
     const double s2 = d2 > 0.0 ? sqrt(2.0) * cnt / d2 : 1.0;
-    // normal matrix, 64 correspondences per MFMA pass (outliers contribute zero rows)
-    for (int e = lane; e < LD * LD; e += 64) {
-        w.Vt[e] = 0.0;  // running sum of the Gram matrices
-    }
+    // normal matrix: 64 correspondences per pass (outliers contribute zero rows), lane = row, one accumulator tile for
+    // the whole pair (the MFMA adds in k order: the same sum whichever way the chunks are cut)
+    d4 gacc = {0.0, 0.0, 0.0, 0.0};
+    const int col = lane & 15;
+    const int kk = lane >> 4;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const bool in = i < n && flags[i] != 0;
         const double p1[3] = {in ? (x1[2 * i] - c1x) * s1 : 0.0, in ? (x1[2 * i + 1] - c1y) * s1 : 0.0, in ? 1.0 : 0.0};
         const double p2[3] = {in ? (x2[2 * i] - c2x) * s2 : 0.0, in ? (x2[2 * i + 1] - c2y) * s2 : 0.0, in ? 1.0 : 0.0};
+        wave_sync();  // the previous chunk's rows have been read
+#pragma unroll
         for (int c = 0; c < LD; ++c) {
-            w.A[lane * LD + c] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
+            wk.A[lane * LD + c] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
         }
         wave_sync();
-        mfma_gram(w.A, 64, w.G, lane);
-        wave_sync();
-        for (int e = lane; e < LD * LD; e += 64) {
-            w.Vt[e] += w.G[e];
+#pragma unroll
+        for (int k0 = 0; k0 < 64; k0 += 4) {
+            const double a = wk.A[(k0 + kk) * LD + col];
+            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, gacc, 0, 0, 0);
         }
-        wave_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wk.G[(kk + 4 * r) * LD + col] = gacc[r];  // C/D: col = lane & 15, row = (lane >> 4) + 4 * reg
     }
     for (int e = lane; e < LD * LD; e += 64) {
-        w.G[e] = w.Vt[e];
-        w.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
+        wk.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
     }
     wave_sync();
-    jacobi_sym(w.G, w.Vp, 9, lane);
+    jacobi_sym(wk.G, wk.Vp, 9, lane);
     wave_sync();
     if (lane == 0) {
         int jmin = 0;
         for (int j = 1; j < 9; ++j) {
-            if (w.G[j * LD + j] < w.G[jmin * LD + jmin]) {
+            if (wk.G[j * LD + j] < wk.G[jmin * LD + jmin]) {
                 jmin = j;
             }
         }
-        double En[9];
+        double En[9], Ef[9];
         for (int k = 0; k < 9; ++k) {
-            En[k] = w.Vp[k * LD + jmin];
+            En[k] = wk.Vp[k * LD + jmin];
         }
-        const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
-        const double T2t[9] = {s2, 0, 0, 0, s2, 0, -s2 * c2x, -s2 * c2y, 1};
-        double tmp[9], E0[9], U[9], S[3], V[9], Vt3[9], UD[9], Ef[9];
-        mul3(En, T1, tmp);
-        mul3(T2t, tmp, E0);
-        svd3(E0, U, S, V);
-        for (int i = 0; i < 3; ++i) {
-            for (int j = 0; j < 3; ++j) {
-                Vt3[i * 3 + j] = V[j * 3 + i];
-            }
-        }
-        const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
-        mul3(U, D, UD);
-        mul3(UD, Vt3, Ef);
+        essential_from_null_vector(En, s1, c1x, c1y, s2, c2x, c2y, Ef);
         for (int k = 0; k < 9; ++k) {
             E_out[k] = Ef[k];
         }
     }
 }
 
-// Sampson distance of every correspondence under every hypothesis, one workgroup per hypothesis:
-// counts[h] = number of points with r^2 / (|E x1|_xy^2 + |E^T x2|_xy^2) < thr2 (normalised units);
-// flags (optional, n_hyp == 1 use): 1 per inlier.
-__global__ __launch_bounds__(256) void sampson_kernel(const double* __restrict__ x1, const double* __restrict__ x2, int n,
-                                                      const double* __restrict__ E, double thr2, int32_t* __restrict__ counts,
-                                                      uint8_t* __restrict__ flags) {
+// decomposeEssential (simple_pose_recover.cpp:6-18) and the four projection matrices K [R|t] of :61-65
+__device__ void decompose_essential(const double* E, const double* K, double* poses, double* KP) {
+    double U[9], S[3], V[9], Vt[9], UW[9], R1[9], R2[9];
+    svd3(E, U, S, V);
+    const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    const double Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            Vt[i * 3 + j] = V[j * 3 + i];
+        }
+    }
+    mul3(U, W, UW);
+    mul3(UW, Vt, R1);
+    mul3(U, Wt, UW);
+    mul3(UW, Vt, R2);
+    const double t_[3] = {U[2], U[5], U[8]};
+    if (det3(R1) < 0) {
+        for (int k = 0; k < 9; ++k) {
+            R1[k] = -R1[k];
+        }
+    }
+    if (det3(R2) < 0) {
+        for (int k = 0; k < 9; ++k) {
+            R2[k] = -R2[k];
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const double* Rs = (i & 1) ? R2 : R1;
+        const double sg = i < 2 ? 1.0 : -1.0;
+        double P[12];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                P[r * 4 + c] = Rs[r * 3 + c];
+                poses[i * 12 + r * 3 + c] = Rs[r * 3 + c];
+            }
+            P[r * 4 + 3] = sg * t_[r];
+            poses[i * 12 + 9 + r] = sg * t_[r];
+        }
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 4; ++c) {
+                KP[i * 12 + r * 4 + c] = K[r * 3] * P[c] + K[r * 3 + 1] * P[4 + c] + K[r * 3 + 2] * P[8 + c];
+            }
+        }
+    }
+}
+
+// ---- does the refit explain at least as many correspondences?  Then the result's matrix, flags and the four
+//      candidate poses; one workgroup per pair ----
+__global__ __launch_bounds__(256) void pose_final_kernel(PoseWork w, PoseParams prm) {
     __shared__ int total;
-    const int h = blockIdx.x;
-    const double* e = E + static_cast<size_t>(h) * 9;
+    const int p = blockIdx.x;
+    const int n = w.n[p];
+    if (n < 8) {
+        return;
+    }
     if (threadIdx.x == 0) {
         total = 0;
     }
     __syncthreads();
+    const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
+    const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
+    const uint8_t* fa = w.flags_a + static_cast<size_t>(p) * prm.cap;
+    uint8_t* fb = w.flags_b + static_cast<size_t>(p) * prm.cap;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        e[k] = w.Efit[static_cast<size_t>(p) * 9 + k];
+    }
     int mine = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
-        const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
-        const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
-        const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
-        const double et0 = e[0] * u2 + e[3] * v2 + e[6];
-        const double et1 = e[1] * u2 + e[4] * v2 + e[7];
-        const double r = u2 * ex0 + v2 * ex1 + ex2;
-        const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
-        const bool in = den > 0.0 && r * r < thr2 * den;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double2 a = X1[i], b = X2[i];
+        const bool in = sampson_inlier(e, a.x, a.y, b.x, b.y, prm.thr2);
+        fb[i] = in ? 1 : 0;
         mine += in ? 1 : 0;
-        if (flags != nullptr) {
-            flags[static_cast<size_t>(h) * n + i] = in ? 1 : 0;
+    }
+    if (mine != 0) {
+        atomicAdd(&total, mine);
+    }
+    __syncthreads();
+    const int count_best = w.sel[p * 4 + 1];
+    const bool use_fit = total >= count_best;  // kept only if it explains at least as many correspondences
+    if (!use_fit) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            fb[i] = fa[i];
         }
     }
-    atomicAdd(&total, mine);
-    __syncthreads();
     if (threadIdx.x == 0) {
-        counts[h] = total;
+        w.sel[p * 4 + 2] = total;
+        w.sel[p * 4 + 3] = use_fit ? 1 : 0;
+        const double* src = (use_fit ? w.Efit : w.Ebest) + static_cast<size_t>(p) * 9;
+        slamx_pose_result& r = w.res[p];
+        double E[9];
+        for (int k = 0; k < 9; ++k) {
+            E[k] = src[k];
+            r.E[k] = E[k];
+        }
+        r.n_inliers = use_fit ? total : count_best;
+        r.best_hypothesis = w.sel[p * 4 + 0];
+        decompose_essential(E, prm.K, w.poses4 + static_cast<size_t>(p) * 48, w.KP + static_cast<size_t>(p) * 48);
+        for (int i = 0; i < 4; ++i) {
+            w.front[p * 4 + i] = 0;
+        }
+    }
+}
+
+// ---- simpleRecoverPose's vote (simple_pose_recover.cpp:67-82): one lane per (candidate, correspondence) ----
+// The reference triangulates the NORMALISED points (float, pose_estimator.cpp:59-66) against K [I|0] and K [R|t].
+__global__ __launch_bounds__(256) void cheirality_pairs_kernel(PoseWork w, PoseParams prm) {
+    const int p = blockIdx.z;
+    const int i = blockIdx.y;
+    const int n = w.n[p];
+    if (n < 8 || static_cast<int>(blockIdx.x * blockDim.x) >= n) {
+        return;
+    }
+    double KP0[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            KP0[r * 4 + c] = c < 3 ? prm.K[r * 3 + c] : 0.0;
+        }
+    }
+    double kp[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        kp[k] = w.KP[static_cast<size_t>(p) * 48 + i * 12 + k];
+    }
+    const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
+    const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
+    int mine = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const double2 a = X1[j], b = X2[j];
+        double X[4];
+        triangulate_dlt(KP0, kp, static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(b.x),
+                        static_cast<float>(b.y), X);
+        const double inv = 1.0 / X[3];
+        for (int k = 0; k < 4; ++k) {
+            X[k] = X[k] * inv;
+        }
+        const double z1 = X[2];
+        const double z2 = kp[8] * X[0] + kp[9] * X[1] + kp[10] * X[2] + kp[11] * X[3];
+        if (z1 > 0 && z2 > 0) {
+            mine++;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        mine += __shfl_xor(mine, d);
+    }
+    if ((threadIdx.x & 63) == 0 && mine != 0) {
+        atomicAdd(&w.front[p * 4 + i], mine);
+    }
+}
+
+// ---- the pose the vote selects (first maximum from maxFront = -1) and triangulatePoints with it ----
+// pose_estimator.cpp:69-104: K [I|0] and K [R|t] (sums in k order from 0.0), PIXEL points, float32 homogeneous store.
+__global__ __launch_bounds__(256) void triangulate_pairs_kernel(PoseWork w, PoseParams prm) {
+    const int p = blockIdx.y;
+    const int n = w.n[p];
+    if (n < 8) {
+        return;
+    }
+    int best = 0, maxFront = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = w.front[p * 4 + i];
+        if (f > maxFront) {
+            maxFront = f;
+            best = i;
+        }
+    }
+    const double* pose = w.poses4 + static_cast<size_t>(p) * 48 + best * 12;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        slamx_pose_result& r = w.res[p];
+        for (int k = 0; k < 9; ++k) {
+            r.R[k] = pose[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            r.t[k] = pose[9 + k];
+        }
+        for (int i = 0; i < 4; ++i) {
+            r.front[i] = w.front[p * 4 + i];
+        }
+    }
+    if (static_cast<int>(blockIdx.x * blockDim.x) >= n) {
+        return;
+    }
+    double T1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double T2[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            T2[r * 4 + c] = pose[r * 3 + c];
+        }
+        T2[r * 4 + 3] = pose[9 + r];
+    }
+    double P1[12], P2[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s1 += prm.K[i * 3 + k] * T1[k * 4 + j];
+                s2 += prm.K[i * 3 + k] * T2[k * 4 + j];
+            }
+            P1[i * 4 + j] = s1;
+            P2[i * 4 + j] = s2;
+        }
+    }
+    const float2* A = w.p1 + static_cast<size_t>(p) * prm.cap;
+    const float2* B = w.p2 + static_cast<size_t>(p) * prm.cap;
+    double* xyz = w.xyz + static_cast<size_t>(p) * prm.cap * 3;
+    float* x4 = w.x4 != nullptr ? w.x4 + static_cast<size_t>(p) * prm.cap * 4 : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 a = A[i], b = B[i];
+        double X[4];
+        triangulate_dlt(P1, P2, a.x, a.y, b.x, b.y, X);
+        float xf[4];
+        for (int k = 0; k < 4; ++k) {
+            xf[k] = static_cast<float>(X[k]);
+            if (x4 != nullptr) {
+                x4[4 * i + k] = xf[k];
+            }
+        }
+        // cv "x /= w" on CV_32F == multiply by float(1.0 / double(w))
+        const float alpha = static_cast<float>(1.0 / static_cast<double>(xf[3]));
+        for (int k = 0; k < 3; ++k) {
+            xyz[3 * static_cast<size_t>(i) + k] = static_cast<double>(__fmul_rn(xf[k], alpha));
+        }
+    }
+}
+
+// ---- a12 for the batch: the 3D-2D correspondences of LoopClosure::verifyGeometricConsistency (loop_closure.cpp:166-171)
+// points2d = the QUERY frame's keypoint of every match, points3d = the map point of the match's TRAIN keypoint.  The
+// train frame's map points are those its own pair triangulated, one per match of the train frame, i.e. per QUERY
+// keypoint of that pair; match lists are in ascending queryIdx order, so the map point of keypoint k is found by a
+// binary search.  Matches whose train keypoint has no map point drop out; the order of the others is kept.
+__global__ __launch_bounds__(1024) void pnp_gather_kernel(PoseSource src, PoseWork w, PoseParams prm, int first_train_frame) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int p = blockIdx.x;
+    const int tf = p > 0 ? p - 1 : first_train_frame;
+    const int n = w.n[p];
+    const int nt = tf >= 0 ? w.n[tf] : 0;  // map points of the train frame (none when its pair had fewer than 8 matches)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int carry = 0;
+    if (tf >= 0 && nt >= 8) {
+        const slamx_match* mq = src.matches + static_cast<size_t>(p) * src.maxK;
+        const slamx_match* mt = src.matches + static_cast<size_t>(tf) * src.maxK;
+        const slamx_keypoint* kq = src.kps + static_cast<size_t>(p) * src.maxK;
+        const double* xyz = w.xyz + static_cast<size_t>(tf) * prm.cap * 3;
+        double* c3 = w.c3 + static_cast<size_t>(p) * prm.cap * 3;
+        double* c2 = w.c2 + static_cast<size_t>(p) * prm.cap * 2;
+        for (int base = 0; base < n; base += 1024) {
+            const int j = base + static_cast<int>(threadIdx.x);
+            int found = -1;
+            slamx_match m{};
+            if (j < n) {
+                m = mq[j];
+                int lo = 0, hi = nt - 1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int q = mt[mid].queryIdx;
+                    if (q == m.trainIdx) {
+                        found = mid;
+                        break;
+                    }
+                    if (q < m.trainIdx) {
+                        lo = mid + 1;
+                    } else {
+                        hi = mid - 1;
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(found >= 0);
+            const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) {
+                wave_tot[wv] = __builtin_popcountll(bal);
+            }
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int k = 0; k < 16; ++k) {
+                const int c = wave_tot[k];
+                woff += k < wv ? c : 0;
+                tot += c;
+            }
+            if (found >= 0) {
+                const size_t pos = static_cast<size_t>(carry + woff + before);
+                c3[pos * 3 + 0] = xyz[static_cast<size_t>(found) * 3 + 0];
+                c3[pos * 3 + 1] = xyz[static_cast<size_t>(found) * 3 + 1];
+                c3[pos * 3 + 2] = xyz[static_cast<size_t>(found) * 3 + 2];
+                c2[pos * 2 + 0] = static_cast<double>(kq[m.queryIdx].x);
+                c2[pos * 2 + 1] = static_cast<double>(kq[m.queryIdx].y);
+            }
+            carry += tot;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        w.m[p] = carry;
+        w.res[p].pnp_correspondences = carry;
+        const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
+        if (carry < need) {
+            w.res[p].status |= SLAMX_POSE_PNP_SKIPPED;
+        }
+        carry_s = carry;
+    }
+    (void)carry_s;
+}
+
+// ---- a11 for the batch: solvePnP on a 6-point sample, one WAVE per hypothesis (the 12 x 12 DLT system on FP64 MFMA) ----
+constexpr int PNP_WAVES = 8;
+__global__ __launch_bounds__(64 * PNP_WAVES) void pnp_hyp_kernel(PoseWork w, PoseParams prm) {
+    extern __shared__ double pose_lds[];
+    const int p = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int h = blockIdx.x * PNP_WAVES + wave;
+    const int m = w.m[p];
+    const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
+    if (h >= prm.pnp_iterations || m < need) {
+        return;  // wave-uniform
+    }
+    PnpWork6& wk = *reinterpret_cast<PnpWork6*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork6) / sizeof(double)));
+    const size_t hh = static_cast<size_t>(p) * prm.pnp_iterations + h;
+    // the sample: drawn (or read) by every lane alike, kept in LDS so that the row builder can index it
+    int* sidx = reinterpret_cast<int*>(wk.T);  // (T is scratch of the solve, free until its first pass)
+    if (prm.device_sampling != 0) {
+        int idx[6];
+        pose_draw_sample(prm.seed, 1, p, h, m, 6, idx);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                sidx[k] = idx[k];
+                w.pidx[hh * 6 + k] = idx[k];
+            }
+        }
+    } else if (lane < 6) {
+        const int c = w.pidx[hh * 6 + lane];
+        sidx[lane] = c < 0 ? 0 : (c >= m ? m - 1 : c);
+    }
+    wave_sync();
+    const double* c3 = w.c3 + static_cast<size_t>(p) * prm.cap * 3;
+    const double* c2 = w.c2 + static_cast<size_t>(p) * prm.cap * 2;
+    wave_solve_pnp(
+        wk, 6, [&](int i) { return c3 + 3 * static_cast<size_t>(sidx[i]); },
+        [&](int i) { return c2 + 2 * static_cast<size_t>(sidx[i]); }, lane, w.pRt + hh * 12, w.pRt + hh * 12 + 9, nullptr);
+    if (lane == 0) {
+        w.pcounts[hh] = 0;
+    }
+}
+
+// reprojection test of loop_closure.cpp:201-215 for one (R, t): Rt = R row-major (9) then t (3)
+__device__ __forceinline__ bool pnp_inlier(const double* Rt, const double* K, double X, double Y, double Z, double u, double v,
+                                           double threshold) {
+    double tp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        tp[r] = Rt[r * 3] * X + Rt[r * 3 + 1] * Y + Rt[r * 3 + 2] * Z + Rt[9 + r];
+    }
+    if (tp[2] <= 0) {
+        return false;
+    }
+    const double q0 = tp[0] / tp[2], q1 = tp[1] / tp[2], q2 = tp[2] / tp[2];
+    const double px = K[0] * q0 + K[1] * q1 + K[2] * q2;
+    const double py = K[3] * q0 + K[4] * q1 + K[5] * q2;
+    const double ex = u - px;
+    const double ey = v - py;
+    return sqrt(ex * ex + ey * ey) < threshold;
+}
+
+// every PnP hypothesis against every correspondence of its frame (the structure of sampson_score_kernel)
+__global__ __launch_bounds__(256) void pnp_score_kernel(PoseWork w, PoseParams prm) {
+    __shared__ double Rt[SCORE_TILE * 12];
+    __shared__ int cnt[SCORE_TILE];
+    const int p = blockIdx.y;
+    const int m = w.m[p];
+    const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
+    const int first = blockIdx.x * 256;
+    if (m < need || first >= m) {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int i = first + static_cast<int>(threadIdx.x);
+    const bool live = i < m;
+    const double* c3 = w.c3 + static_cast<size_t>(p) * prm.cap * 3;
+    const double* c2 = w.c2 + static_cast<size_t>(p) * prm.cap * 2;
+    const double X = live ? c3[3 * static_cast<size_t>(i)] : 0.0, Y = live ? c3[3 * static_cast<size_t>(i) + 1] : 0.0,
+                 Z = live ? c3[3 * static_cast<size_t>(i) + 2] : 0.0;
+    const double u = live ? c2[2 * static_cast<size_t>(i)] : 0.0, v = live ? c2[2 * static_cast<size_t>(i) + 1] : 0.0;
+    const double* src = w.pRt + static_cast<size_t>(p) * prm.pnp_iterations * 12;
+    int* counts = w.pcounts + static_cast<size_t>(p) * prm.pnp_iterations;
+    for (int h0 = 0; h0 < prm.pnp_iterations; h0 += SCORE_TILE) {
+        const int nh = min(SCORE_TILE, prm.pnp_iterations - h0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nh * 12; e += 256) {
+            Rt[e] = src[static_cast<size_t>(h0) * 12 + e];
+        }
+        if (threadIdx.x < SCORE_TILE) {
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int k = 0; k < nh; ++k) {
+            const bool in = live && pnp_inlier(Rt + k * 12, prm.K, X, Y, Z, u, v, prm.pnp_threshold);
+            const int c = __builtin_popcountll(__ballot(in));
+            mine += lane == k ? c : 0;
+        }
+        if (lane < nh && mine != 0) {
+            atomicAdd(&cnt[lane], mine);
+        }
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < nh && cnt[threadIdx.x] != 0) {
+            atomicAdd(&counts[h0 + threadIdx.x], cnt[threadIdx.x]);
+        }
+    }
+}
+
+// loop_closure.cpp:217-221: strict '>' from maxInliers = 0, identity / zero as the initial best; one wave per frame
+__global__ __launch_bounds__(64) void pnp_select_kernel(PoseWork w, PoseParams prm) {
+    const int p = blockIdx.x;
+    const int m = w.m[p];
+    const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
+    if (m < need) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const int* counts = w.pcounts + static_cast<size_t>(p) * prm.pnp_iterations;
+    int bc = 0, bi = 0x7fffffff;
+    for (int h = lane; h < prm.pnp_iterations; h += 64) {
+        const int c = counts[h];
+        if (c > bc) {
+            bc = c;
+            bi = h;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int oc = __shfl_xor(bc, d), oi = __shfl_xor(bi, d);
+        if (oc > bc || (oc == bc && oi < bi)) {
+            bc = oc;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        slamx_pose_result& r = w.res[p];
+        r.pnp_inliers = bc;
+        if (bc > 0) {
+            const double* Rt = w.pRt + (static_cast<size_t>(p) * prm.pnp_iterations + bi) * 12;
+            for (int k = 0; k < 9; ++k) {
+                r.pnp_R[k] = Rt[k];
+            }
+            for (int k = 0; k < 3; ++k) {
+                r.pnp_t[k] = Rt[9 + k];
+            }
+        }
     }
 }
 
@@ -817,31 +1533,77 @@ void launch_triangulate(const double* P1, const double* P2, const float* pts1, c
     hipLaunchKernelGGL(triangulate_kernel, dim3(bx < 1 ? 1 : bx), dim3(256), 0, stream, P1, P2, pts1, pts2, n, x4, xyz);
 }
 
-void launch_essential_8pt(const double* x1, const double* x2, int n_hyp, double* E, hipStream_t stream) {
-    const size_t lds = 4 * sizeof(PnpWork);
-    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(essential_8pt_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
-                              true);
-    (void)once;
-    int blocks = (n_hyp + 3) / 4;
-    if (blocks > 2048) {
-        blocks = 2048;
-    }
-    hipLaunchKernelGGL(essential_8pt_kernel, dim3(blocks), dim3(256), lds, stream, x1, x2, n_hyp, E);
+namespace {
+int pose_blocks(int cap, int per_block) {
+    const int b = (cap + per_block - 1) / per_block;
+    return b < 1 ? 1 : b;
+}
+template <typename Kernel>
+void allow_lds(Kernel k, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+}  // namespace
+
+void launch_pose_gather(const PoseSource& src, const PoseWork& w, const PoseParams& prm, int nframes, int first_train_frame,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(pose_gather_kernel, dim3(std::min(pose_blocks(prm.cap, 256), 64), nframes), dim3(256), 0, stream, src, w,
+                       prm, first_train_frame);
 }
 
-void launch_essential_refit(const double* x1, const double* x2, const uint8_t* flags, int n, double* E, hipStream_t stream) {
+void launch_pose_load_points(const PoseWork& w, const PoseParams& prm, hipStream_t stream) {
+    hipLaunchKernelGGL(pose_load_points_kernel, dim3(std::min(pose_blocks(prm.cap, 256), 256)), dim3(256), 0, stream, w, prm);
+}
+
+void launch_essential_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(essential_hyp_kernel, dim3((prm.iterations + 63) / 64, npairs), dim3(64), 0, stream, w, prm);
+}
+
+void launch_sampson_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(sampson_score_kernel, dim3(pose_blocks(prm.cap, 256 * SCORE_PPT), npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_pose_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(pose_select_kernel, dim3(npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_essential_refit_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
     const size_t lds = sizeof(PnpWork);
-    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(essential_refit_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
-                              true);
+    static const bool once = (allow_lds(essential_refit_kernel, lds), true);
     (void)once;
-    hipLaunchKernelGGL(essential_refit_kernel, dim3(1), dim3(64), lds, stream, x1, x2, flags, n, E);
+    hipLaunchKernelGGL(essential_refit_kernel, dim3(npairs), dim3(64), lds, stream, w, prm);
 }
 
-void launch_sampson(const double* x1, const double* x2, int n, const double* E, int n_hyp, double thr2, int32_t* counts,
-                    uint8_t* flags, hipStream_t stream) {
-    hipLaunchKernelGGL(sampson_kernel, dim3(n_hyp), dim3(256), 0, stream, x1, x2, n, E, thr2, counts, flags);
+void launch_pose_final(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(pose_final_kernel, dim3(npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_cheirality_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(cheirality_pairs_kernel, dim3(pose_blocks(prm.cap, 256), 4, npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_triangulate_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(triangulate_pairs_kernel, dim3(pose_blocks(prm.cap, 256), npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_pnp_gather(const PoseSource& src, const PoseWork& w, const PoseParams& prm, int nframes, int first_train_frame,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(pnp_gather_kernel, dim3(nframes), dim3(1024), 0, stream, src, w, prm, first_train_frame);
+}
+
+void launch_pnp_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    const size_t lds = PNP_WAVES * sizeof(PnpWork6);
+    static const bool once = (allow_lds(pnp_hyp_kernel, lds), true);
+    (void)once;
+    hipLaunchKernelGGL(pnp_hyp_kernel, dim3((prm.pnp_iterations + PNP_WAVES - 1) / PNP_WAVES, npairs), dim3(64 * PNP_WAVES), lds,
+                       stream, w, prm);
+}
+
+void launch_pnp_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(pose_blocks(prm.cap, 256), npairs), dim3(256), 0, stream, w, prm);
+}
+
+void launch_pnp_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
+    hipLaunchKernelGGL(pnp_select_kernel, dim3(npairs), dim3(64), 0, stream, w, prm);
 }
 
 }  // namespace slamx

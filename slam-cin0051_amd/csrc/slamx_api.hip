@@ -16,120 +16,18 @@
 #include <string>
 #include <vector>
 
-#include "slamx_internal.h"
+#include "api_common.h"
 #include <dlfcn.h>
 #include "yaml_lite.hpp"
 
 using namespace slamx;
 
-namespace {
-
-thread_local std::string g_last_error;
-
-int fail(int code, const std::string& msg) {
-    g_last_error = msg;
-    return code;
+namespace slamx {
+std::string& last_error_slot() {
+    thread_local std::string g_last_error;
+    return g_last_error;
 }
-
-#define HIP_TRY(expr)                                                                                      \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) {                                                                            \
-            return fail(SLAMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
-        }                                                                                                  \
-    } while (0)
-
-#define SLAMX_TRY(expr)       \
-    do {                      \
-        int rc_ = (expr);     \
-        if (rc_ != SLAMX_OK) { \
-            return rc_;       \
-        }                     \
-    } while (0)
-
-template <typename T>
-int dev_alloc(T** p, size_t count) {
-    *p = nullptr;
-    if (count == 0) {
-        count = 1;
-    }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
-    return SLAMX_OK;
-}
-template <typename T>
-void dev_free(T*& p) {
-    if (p != nullptr) {
-        (void)hipFree(p);
-        p = nullptr;
-    }
-}
-
-}  // namespace
-
-struct slamx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = false;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    std::string name;
-    int n_cus = 0;
-    // second queue of the context: the blur of a batch beside its sort + NMS (blur_beside_sort), created on first use
-    hipStream_t side = nullptr;
-    hipEvent_t e_fork = nullptr, e_join = nullptr;
-};
-
-struct slamx_detector {
-    slamx_ctx* ctx = nullptr;
-    slamx_detector_config cfg{};
-    std::vector<int32_t> pattern;  // x1,y1,x2,y2 per surviving pair
-    int8_t* pattern_dev = nullptr;
-    uint2* moment_weights_dev = nullptr;  // moment_weight_table() for PatchSize / 2 <= 15
-    double* weights_dev = nullptr;
-    slamx_batch* single = nullptr;  // lazily created 1-frame batch behind the host-buffer API
-};
-
-struct slamx_matcher {
-    slamx_ctx* ctx = nullptr;
-    slamx_matcher_config cfg{};
-    // scratch behind slamx_matcher_match: a 2-"frame" layout, frame 0 = train, frame 1 = query
-    int cap = 0, width = 0;
-    uint8_t* desc = nullptr;
-    slamx_keypoint* kps = nullptr;
-    int* n_kp = nullptr;
-    slamx_match* matches = nullptr;
-    int* n_matches = nullptr;
-    int2* best = nullptr;
-    int* second = nullptr;
-    uint8_t* xdesc = nullptr;  // [2][cap][64]
-};
-
-struct slamx_batch {
-    slamx_detector* det = nullptr;
-    slamx_batch_shape shape{};
-    BatchView v{};
-    uint8_t* frames = nullptr;
-    // matcher outputs (allocated on first use)
-    slamx_match* matches = nullptr;
-    int* n_matches = nullptr;
-    int2* best = nullptr;
-    int* second = nullptr;
-    uint8_t* xdesc = nullptr;  // [F][maxK][64] expanded descriptors of the matrix-core matcher
-    uint8_t* pack = nullptr;   // packed results of slamx_batch_download_packed_async (worst-case size, on first use)
-    size_t pack_bytes = 0;
-    // profiling: n_sets event sets of NEV events; event i of a set brackets the stages
-    // 0|FAST|1|SCAN|2|EXPAND|3|SORT|4|NMS_BUILD|5|NMS_ROUNDS|6|BLUR|7|MOMENTS|8|TRIG|9|BRIEF|10|MATCH|11|EMIT|12
-    static constexpr int NEV = SLAMX_STAGE_COUNT + 1;
-    int n_sets = 0;
-    std::vector<hipEvent_t> ev;
-    std::vector<char> ev_valid;
-    long long calls = 0;  // detect_and_compute calls since profiling was switched on
-    int cur_set = 0;
-    int every = 1;        // only every `every`-th call records events (an event between two kernels keeps
-                          // the second from ramping up while the first drains: ~9 % on the bench step)
-    bool active = false;  // the current call records
-    int last_frames = 0;
-    int last_status = 0;  // per-frame status bits seen by the most recent slamx_batch_download
-};
+}  // namespace slamx
 
 namespace {
 
@@ -441,7 +339,7 @@ uint64_t splitmix64(uint64_t& s) {
 
 extern "C" {
 
-const char* slamx_last_error(void) { return g_last_error.c_str(); }
+const char* slamx_last_error(void) { return slamx::last_error_slot().c_str(); }
 const char* slamx_version(void) { return "slamx 0.2 (gfx950)"; }
 int slamx_matcher_mfma_threshold(void) { return match_mfma_min_keypoints(); }
 
@@ -500,6 +398,10 @@ void slamx_ctx_destroy(slamx_ctx* ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream != nullptr) {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    slamx::pose_release_context(ctx);  // the one-pair pose workspace and the scratch arena (pose_api.hip)
     if (ctx->t0 != nullptr) {
         (void)hipEventDestroy(ctx->t0);
     }
@@ -1700,314 +1602,8 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     return SLAMX_OK;
 }
 
-// ------------------------------------------------------------------ pose solves
-extern "C++" {
-namespace {
-
-// Scoped device buffers for the host-pointer pose API (small, per call).
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() {
-        if (p != nullptr) {
-            (void)hipFree(p);
-        }
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 1); }
-    template <typename T>
-    T* as() const {
-        return static_cast<T*>(p);
-    }
-};
-
-}  // namespace
-}  // extern "C++"
-
-int slamx_pnp_dlt_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n_points, int n_hyp, double* R,
-                        double* t, double* nullvec) {
-    if (n_points < 6) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "solvePnP needs at least 6 points");  // returns false in the reference
-    }
-    if (n_points > 32 || n_hyp < 0 || p3d == nullptr || p2d == nullptr || R == nullptr || t == nullptr) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pnp arguments invalid (6 <= n_points <= 32)");
-    }
-    if (n_hyp == 0) {
-        return SLAMX_OK;
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const size_t H = static_cast<size_t>(n_hyp);
-    DevBuf d3, d2, dR, dt, dn;
-    HIP_TRY(d3.alloc(H * n_points * 3 * sizeof(double)));
-    HIP_TRY(d2.alloc(H * n_points * 2 * sizeof(double)));
-    HIP_TRY(dR.alloc(H * 9 * sizeof(double)));
-    HIP_TRY(dt.alloc(H * 3 * sizeof(double)));
-    HIP_TRY(dn.alloc(H * 12 * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(d3.p, p3d, H * n_points * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d2.p, p2d, H * n_points * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_pnp_dlt(d3.as<double>(), d2.as<double>(), n_points, n_hyp, dR.as<double>(), dt.as<double>(), dn.as<double>(), s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(R, dR.p, H * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(t, dt.p, H * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (nullvec != nullptr) {
-        HIP_TRY(hipMemcpyAsync(nullvec, dn.p, H * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-    return SLAMX_OK;
-}
-
-int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
-                              const double* R, const double* t, int n_hyp, double threshold, int32_t* counts) {
-    if (n < 0 || n_hyp < 0 || K == nullptr || counts == nullptr) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "inlier arguments invalid");
-    }
-    if (n_hyp == 0) {
-        return SLAMX_OK;
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const size_t H = static_cast<size_t>(n_hyp);
-    DevBuf d3, d2, dK, dR, dt, dc;
-    HIP_TRY(d3.alloc(static_cast<size_t>(n) * 3 * sizeof(double)));
-    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 2 * sizeof(double)));
-    HIP_TRY(dK.alloc(9 * sizeof(double)));
-    HIP_TRY(dR.alloc(H * 9 * sizeof(double)));
-    HIP_TRY(dt.alloc(H * 3 * sizeof(double)));
-    HIP_TRY(dc.alloc(H * sizeof(int)));
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d3.p, p3d, static_cast<size_t>(n) * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d2.p, p2d, static_cast<size_t>(n) * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    HIP_TRY(hipMemcpyAsync(dK.p, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dR.p, R, H * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dt.p, t, H * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_inliers(d3.as<double>(), d2.as<double>(), n, dK.as<double>(), dR.as<double>(), dt.as<double>(), threshold,
-                   n_hyp, dc.as<int>(), s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(counts, dc.p, H * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SLAMX_OK;
-}
-
-int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, int iterations,
-                     double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers) {
-    if (n < 6 || iterations <= 0 || p3d == nullptr || p2d == nullptr || K == nullptr || R == nullptr || t == nullptr) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "ransac arguments invalid (needs >= 6 correspondences)");
-    }
-    // loop_closure.cpp:177-193: the same generator, distribution and distinct-index rule
-    std::mt19937 rng(seed);
-    std::uniform_int_distribution<int> dist(0, n - 1);
-    constexpr int sampleSize = 6;
-    std::vector<double> s3(static_cast<size_t>(iterations) * sampleSize * 3);
-    std::vector<double> s2(static_cast<size_t>(iterations) * sampleSize * 2);
-    for (int i = 0; i < iterations; ++i) {
-        std::vector<int> sampleIndices;
-        while (sampleIndices.size() < sampleSize) {
-            const int idx = dist(rng);
-            if (std::find(sampleIndices.begin(), sampleIndices.end(), idx) == sampleIndices.end()) {
-                const size_t k = sampleIndices.size();
-                sampleIndices.push_back(idx);
-                std::memcpy(&s3[(static_cast<size_t>(i) * sampleSize + k) * 3], p3d + static_cast<size_t>(idx) * 3, 24);
-                std::memcpy(&s2[(static_cast<size_t>(i) * sampleSize + k) * 2], p2d + static_cast<size_t>(idx) * 2, 16);
-            }
-        }
-    }
-    std::vector<double> Rs(static_cast<size_t>(iterations) * 9), ts(static_cast<size_t>(iterations) * 3);
-    std::vector<int32_t> counts(static_cast<size_t>(iterations));
-    SLAMX_TRY(slamx_pnp_dlt_batch(ctx, s3.data(), s2.data(), sampleSize, iterations, Rs.data(), ts.data(), nullptr));
-    SLAMX_TRY(slamx_count_inliers_batch(ctx, p3d, p2d, n, K, Rs.data(), ts.data(), iterations, threshold, counts.data()));
-    // :217-221 strict '>' from maxInliers = 0, identity / zero as the initial best
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    std::memcpy(R, I3, sizeof(I3));
-    t[0] = t[1] = t[2] = 0.0;
-    int best = 0;
-    for (int i = 0; i < iterations; ++i) {
-        if (counts[static_cast<size_t>(i)] > best) {
-            best = counts[static_cast<size_t>(i)];
-            std::memcpy(R, &Rs[static_cast<size_t>(i) * 9], 72);
-            std::memcpy(t, &ts[static_cast<size_t>(i) * 3], 24);
-        }
-    }
-    if (max_inliers != nullptr) {
-        *max_inliers = best;
-    }
-    return SLAMX_OK;
-}
-
-int slamx_essential_ransac(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K, int iterations,
-                           double threshold_px, uint32_t seed, double* E, int32_t* n_inliers, uint8_t* inlier_mask) {
-    if (iterations <= 0 || pts1 == nullptr || pts2 == nullptr || K == nullptr || E == nullptr || threshold_px <= 0.0) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "essential ransac arguments invalid");
-    }
-    if (n < 8) {
-        // PoseEstimator::estimate refuses fewer than 8 matches (pose_estimator.cpp:21-25)
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "Cannot estimate pose, not enough matches. Required at least 8.");
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    // K^-1-normalised coordinates, as pose_estimator.cpp:60-65 forms them for simpleRecoverPose
-    std::vector<double> x1(static_cast<size_t>(n) * 2), x2(static_cast<size_t>(n) * 2);
-    for (int i = 0; i < n; ++i) {
-        x1[2 * static_cast<size_t>(i)] = (static_cast<double>(pts1[2 * i]) - cx) / fx;
-        x1[2 * static_cast<size_t>(i) + 1] = (static_cast<double>(pts1[2 * i + 1]) - cy) / fy;
-        x2[2 * static_cast<size_t>(i)] = (static_cast<double>(pts2[2 * i]) - cx) / fx;
-        x2[2 * static_cast<size_t>(i) + 1] = (static_cast<double>(pts2[2 * i + 1]) - cy) / fy;
-    }
-    // the sampling rule of the reference's own RANSAC (loop_closure.cpp:177-193): mt19937,
-    // uniform_int_distribution, indices redrawn until distinct -- here with an explicit seed
-    std::mt19937 rng(seed);
-    std::uniform_int_distribution<int> dist(0, n - 1);
-    constexpr int sampleSize = 8;
-    std::vector<double> s1(static_cast<size_t>(iterations) * sampleSize * 2), s2(static_cast<size_t>(iterations) * sampleSize * 2);
-    for (int i = 0; i < iterations; ++i) {
-        int idx[sampleSize];
-        int have = 0;
-        while (have < sampleSize) {
-            const int c = dist(rng);
-            if (std::find(idx, idx + have, c) == idx + have) {
-                idx[have] = c;
-                const size_t o = (static_cast<size_t>(i) * sampleSize + have) * 2;
-                s1[o] = x1[2 * static_cast<size_t>(c)];
-                s1[o + 1] = x1[2 * static_cast<size_t>(c) + 1];
-                s2[o] = x2[2 * static_cast<size_t>(c)];
-                s2[o + 1] = x2[2 * static_cast<size_t>(c) + 1];
-                ++have;
-            }
-        }
-    }
-    const size_t H = static_cast<size_t>(iterations);
-    DevBuf ds1, ds2, dx1, dx2, dE, dcnt, dflags;
-    HIP_TRY(ds1.alloc(s1.size() * sizeof(double)));
-    HIP_TRY(ds2.alloc(s2.size() * sizeof(double)));
-    HIP_TRY(dx1.alloc(x1.size() * sizeof(double)));
-    HIP_TRY(dx2.alloc(x2.size() * sizeof(double)));
-    HIP_TRY(dE.alloc(H * 9 * sizeof(double)));
-    HIP_TRY(dcnt.alloc(H * sizeof(int32_t)));
-    HIP_TRY(dflags.alloc(static_cast<size_t>(n)));
-    HIP_TRY(hipMemcpyAsync(ds1.p, s1.data(), s1.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ds2.p, s2.data(), s2.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dx1.p, x1.data(), x1.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dx2.p, x2.data(), x2.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    // cv::findEssentialMat scales its pixel threshold by the focal length; same convention
-    const double thr = threshold_px / (0.5 * (fx + fy));
-    launch_essential_8pt(ds1.as<double>(), ds2.as<double>(), iterations, dE.as<double>(), s);
-    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, dE.as<double>(), iterations, thr * thr, dcnt.as<int32_t>(), nullptr, s);
-    HIP_TRY(hipGetLastError());
-    std::vector<int32_t> counts(H);
-    HIP_TRY(hipMemcpyAsync(counts.data(), dcnt.p, H * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    int best = 0;  // first maximum wins
-    for (int i = 1; i < iterations; ++i) {
-        if (counts[static_cast<size_t>(i)] > counts[static_cast<size_t>(best)]) {
-            best = i;
-        }
-    }
-    // refit on the inliers of the winner; kept only if it explains at least as many correspondences
-    double* e_best = dE.as<double>() + static_cast<size_t>(best) * 9;
-    DevBuf dfit;
-    HIP_TRY(dfit.alloc(72 + sizeof(int32_t) + static_cast<size_t>(n)));
-    double* e_fit = dfit.as<double>();
-    int32_t* fit_cnt = reinterpret_cast<int32_t*>(dfit.as<char>() + 72);
-    uint8_t* fit_flags = reinterpret_cast<uint8_t*>(dfit.as<char>() + 72 + sizeof(int32_t));
-    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, e_best, 1, thr * thr, dcnt.as<int32_t>(), dflags.as<uint8_t>(), s);
-    HIP_TRY(hipMemcpyAsync(e_fit, e_best, 72, hipMemcpyDeviceToDevice, s));
-    launch_essential_refit(dx1.as<double>(), dx2.as<double>(), dflags.as<uint8_t>(), n, e_fit, s);
-    launch_sampson(dx1.as<double>(), dx2.as<double>(), n, e_fit, 1, thr * thr, fit_cnt, fit_flags, s);
-    HIP_TRY(hipGetLastError());
-    int32_t refit_count = 0;
-    HIP_TRY(hipMemcpyAsync(&refit_count, fit_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const bool use_fit = refit_count >= counts[static_cast<size_t>(best)];
-    HIP_TRY(hipMemcpyAsync(E, use_fit ? e_fit : e_best, 72, hipMemcpyDeviceToHost, s));
-    if (inlier_mask != nullptr) {
-        HIP_TRY(hipMemcpyAsync(inlier_mask, use_fit ? fit_flags : dflags.as<uint8_t>(), static_cast<size_t>(n),
-                               hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-    if (n_inliers != nullptr) {
-        *n_inliers = use_fit ? refit_count : counts[static_cast<size_t>(best)];
-    }
-    return SLAMX_OK;
-}
-
-int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
-                       double* R, double* t, int32_t* front) {
-    if (n < 0 || E == nullptr || K == nullptr || R == nullptr || t == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "recover pose arguments invalid");
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    DevBuf dE, dK, d1, d2, dposes, dKP, dKP0, dfront;
-    HIP_TRY(dE.alloc(72));
-    HIP_TRY(dK.alloc(72));
-    HIP_TRY(d1.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(dposes.alloc(4 * 12 * sizeof(double)));
-    HIP_TRY(dKP.alloc(4 * 12 * sizeof(double)));
-    HIP_TRY(dKP0.alloc(12 * sizeof(double)));
-    HIP_TRY(dfront.alloc(4 * sizeof(int)));
-    HIP_TRY(hipMemcpyAsync(dE.p, E, 72, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dK.p, K, 72, hipMemcpyHostToDevice, s));
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d1.p, pts1, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d2.p, pts2, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
-    }
-    HIP_TRY(hipMemsetAsync(dfront.p, 0, 4 * sizeof(int), s));
-    launch_recover_pose(dE.as<double>(), dK.as<double>(), d1.as<float>(), d2.as<float>(), n, dposes.as<double>(),
-                        dKP.as<double>(), dKP0.as<double>(), dfront.as<int>(), s);
-    HIP_TRY(hipGetLastError());
-    double poses[48];
-    int fr[4];
-    HIP_TRY(hipMemcpyAsync(poses, dposes.p, sizeof(poses), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(fr, dfront.p, sizeof(fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    int best = 0, maxFront = -1;  // simple_pose_recover.cpp:67-82: first maximum wins
-    for (int i = 0; i < 4; ++i) {
-        if (fr[i] > maxFront) {
-            maxFront = fr[i];
-            best = i;
-        }
-    }
-    std::memcpy(R, poses + best * 12, 72);
-    std::memcpy(t, poses + best * 12 + 9, 24);
-    if (front != nullptr) {
-        std::memcpy(front, fr, sizeof(fr));
-    }
-    return SLAMX_OK;
-}
-
-int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
-                      float* x4, double* xyz) {
-    if (n < 0 || P1 == nullptr || P2 == nullptr || xyz == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "triangulate arguments invalid");
-    }
-    if (n == 0) {
-        return SLAMX_OK;
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    DevBuf dP1, dP2, d1, d2, dx4, dxyz;
-    HIP_TRY(dP1.alloc(96));
-    HIP_TRY(dP2.alloc(96));
-    HIP_TRY(d1.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(d2.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(dx4.alloc(static_cast<size_t>(n) * 16));
-    HIP_TRY(dxyz.alloc(static_cast<size_t>(n) * 24));
-    HIP_TRY(hipMemcpyAsync(dP1.p, P1, 96, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dP2.p, P2, 96, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d1.p, pts1, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d2.p, pts2, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice, s));
-    launch_triangulate(dP1.as<double>(), dP2.as<double>(), d1.as<float>(), d2.as<float>(), n, dx4.as<float>(),
-                       dxyz.as<double>(), s);
-    HIP_TRY(hipGetLastError());
-    if (x4 != nullptr) {
-        HIP_TRY(hipMemcpyAsync(x4, dx4.p, static_cast<size_t>(n) * 16, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipMemcpyAsync(xyz, dxyz.p, static_cast<size_t>(n) * 24, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SLAMX_OK;
-}
-
+// (the pose solves -- slamx_pnp_* / slamx_essential_ransac / slamx_recover_pose / slamx_triangulate / slamx_pose_* --
+// live in pose_api.hip)
 // ------------------------------------------------------------------ image pyramid (pyramid.hip)
 }  // extern "C"
 

@@ -259,12 +259,111 @@ void launch_inliers(const double* p3d, const double* p2d, int n, const double* K
                     double threshold, int n_hyp, int* counts, hipStream_t stream);
 void launch_recover_pose(const double* E, const double* K, const float* pts1, const float* pts2, int n, double* poses,
                          double* KP, double* KP0, int* front, hipStream_t stream);
-void launch_essential_8pt(const double* x1, const double* x2, int n_hyp, double* E, hipStream_t stream);
-void launch_essential_refit(const double* x1, const double* x2, const uint8_t* flags, int n, double* E, hipStream_t stream);
-void launch_sampson(const double* x1, const double* x2, int n, const double* E, int n_hyp, double thr2, int32_t* counts,
-                    uint8_t* flags, hipStream_t stream);
 void launch_triangulate(const double* P1, const double* P2, const float* pts1, const float* pts2, int n, float* x4,
                         double* xyz, hipStream_t stream);
+
+// ---- the pose stage of a batch (pose.hip; host side in pose_api.hip) ----
+// Counter-based sample generator of the batched RANSAC loops: draw d of hypothesis h of frame slot s is
+// splitmix64-mix(key(seed, stream) + counter(s, h, d)), reduced to [0, n) by multiply-high; indices are redrawn until
+// distinct (loop_closure.cpp:185-193's rule).  Host and device run the same function.
+#if defined(__HIPCC__)
+#define SLAMX_HD __host__ __device__
+#else
+#define SLAMX_HD
+#endif
+SLAMX_HD inline unsigned long long pose_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// k <= 8 distinct indices out of [0, n), n >= k
+SLAMX_HD inline void pose_draw_sample(unsigned seed, int stream, int slot, int hyp, int n, int k, int* out) {
+    const unsigned long long key = pose_mix64((static_cast<unsigned long long>(seed) << 1 | 1ull) +
+                                              static_cast<unsigned long long>(stream) * 0xD1B54A32D192ED03ull);
+    const unsigned long long ctr0 = (static_cast<unsigned long long>(static_cast<unsigned>(slot)) << 40) |
+                                    (static_cast<unsigned long long>(static_cast<unsigned>(hyp)) << 16);
+    int have = 0;
+    for (unsigned draw = 0; have < k && draw < 4096u; ++draw) {
+        const unsigned long long z = pose_mix64(key + (ctr0 | draw) * 0x9E3779B97F4A7C15ull);
+        const int c = static_cast<int>(((z >> 32) * static_cast<unsigned long long>(static_cast<unsigned>(n))) >> 32);
+        bool seen = false;
+        for (int j = 0; j < have; ++j) {
+            seen = seen || out[j] == c;
+        }
+        if (!seen) {
+            out[have++] = c;
+        }
+    }
+    for (int c = 0; have < k && c < n; ++c) {  // (4096 draws without k distinct values: never in practice; still total)
+        bool seen = false;
+        for (int j = 0; j < have; ++j) {
+            seen = seen || out[j] == c;
+        }
+        if (!seen) {
+            out[have++] = c;
+        }
+    }
+}
+
+struct PoseParams {
+    double K[9];
+    double fx, fy, cx, cy;
+    double thr2;           // (threshold_px / mean focal length)^2: Sampson threshold in normalised units
+    double pnp_threshold;  // pixels
+    int iterations, pnp_iterations, pnp_min;
+    unsigned seed;
+    int cap;               // slots per frame pair in every correspondence-parallel array
+    int device_sampling;   // 1: the hypothesis kernels draw their samples (and record them in idx / pidx); 0: read them
+};
+// Device arrays of the stage; [P] = frame slot (the QUERY frame of the pair), H = iterations, Hp = pnp_iterations.
+struct PoseWork {
+    int* n;              // [P] correspondences of the pair (matches of the frame, clamped to cap; 0 without a train frame)
+    double2* x1;         // [P][cap] K^-1-normalised point in the TRAIN frame ("frame 1" of PoseEstimator::estimate)
+    double2* x2;         // [P][cap] ... in the QUERY frame
+    float2* p1;          // [P][cap] the same points in pixels (triangulatePoints takes those)
+    float2* p2;
+    int* idx;            // [P][H][8] sample table
+    double* Eh;          // [P][H][9] hypotheses
+    int* counts;         // [P][H] Sampson inlier counts
+    uint8_t* flags_a;    // [P][cap] inlier flags of the winning hypothesis
+    uint8_t* flags_b;    // [P][cap] ... of the refit, then of whichever of the two was kept (the result's mask)
+    double* Ebest;       // [P][9]
+    double* Efit;        // [P][9]
+    int* sel;            // [P][4] winning hypothesis, its count, the refit's count, refit kept
+    double* poses4;      // [P][4][12] the four (R, t) candidates of decomposeEssential
+    double* KP;          // [P][4][12] K [R|t] of each
+    int* front;          // [P][4] cheirality votes
+    slamx_pose_result* res;  // [P]
+    double* xyz;         // [P][cap][3] map points, parallel to the pair's matches
+    float* x4;           // [P][cap][4] homogeneous float points (cv::triangulatePoints' output) or nullptr
+    int* m;              // [P] 3D-2D correspondences of the PnP step
+    double* c3;          // [P][cap][3]
+    double* c2;          // [P][cap][2]
+    int* pidx;           // [P][Hp][6]
+    double* pRt;         // [P][Hp][12] R row-major, t
+    int* pcounts;        // [P][Hp]
+};
+struct PoseSource {  // where the keypoints and matches of the batch are
+    const slamx_keypoint* kps;  // [F][maxK]
+    const slamx_match* matches;  // [F][maxK], queryIdx ascending
+    const int* n_matches;        // [F]
+    int maxK;
+};
+void launch_pose_gather(const PoseSource& src, const PoseWork& w, const PoseParams& prm, int nframes, int first_train_frame,
+                        hipStream_t stream);
+void launch_pose_load_points(const PoseWork& w, const PoseParams& prm, hipStream_t stream);  // one pair: p1, p2, n[0] uploaded
+void launch_essential_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_sampson_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_pose_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_essential_refit_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_pose_final(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_cheirality_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_triangulate_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_pnp_gather(const PoseSource& src, const PoseWork& w, const PoseParams& prm, int nframes, int first_train_frame,
+                       hipStream_t stream);
+void launch_pnp_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_pnp_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
+void launch_pnp_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream);
 
 // image pyramid (pyramid.hip): dst level frames from src level frames (tables built by the host), and the
 // append of a level's results, scaled to level-0 coordinates, to level 0's keypoint / descriptor arrays

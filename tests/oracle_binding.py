@@ -167,6 +167,23 @@ class Oracle:
                                                 _p(mask), _p(E_all), _p(counts))
         return E, cnt.value, mask, best, E_all, counts
 
+    def essential_from_samples(self, pts1, pts2, K, table, threshold_px=1.0):
+        """The same loop with the sample table given (iterations x 8 indices)."""
+        a = np.ascontiguousarray(pts1, np.float32)
+        b = np.ascontiguousarray(pts2, np.float32)
+        tb = np.ascontiguousarray(table, np.int32)
+        n, iterations = a.shape[0], tb.shape[0]
+        E = np.empty((3, 3))
+        cnt = C.c_int()
+        mask = np.zeros(n, np.uint8)
+        E_all = np.empty((iterations, 9))
+        counts = np.empty(iterations, np.int32)
+        self.lib.oracle_essential_from_samples.restype = C.c_int
+        best = self.lib.oracle_essential_from_samples(_p(a), _p(b), n, _p(np.ascontiguousarray(K, np.float64)), _p(tb),
+                                                      iterations, C.c_double(threshold_px), _p(E), C.byref(cnt), _p(mask),
+                                                      _p(E_all), _p(counts))
+        return E, cnt.value, mask, best, E_all, counts
+
     def recover_pose(self, E, pts1, pts2, K):
         a = np.ascontiguousarray(pts1, np.float32)
         b = np.ascontiguousarray(pts2, np.float32)

@@ -1,0 +1,334 @@
+"""GPU tests of the pose stage of a batch (slamx_pose_* / slamx_batch_pose, include/slamx.h): BASELINE.json configs[2]'s
+"+ 2-view essential-matrix / PnP pose" half, device-resident and batched over all frame pairs.
+
+What is compared with what:
+* the batched result of every pair with the ONE-PAIR entry points fed the sample tables the device drew
+  (slamx_essential_from_samples, slamx_pnp_from_samples): same kernels, so E, counts, masks, R, t are bit-identical;
+* with the oracle (oracle_essential_from_samples on the same table, oracle_recover_pose, oracle_triangulate,
+  oracle_count_inliers): floating point from two different SVD iterations -- north_star's tolerance is 1e-5 relative,
+  the assertions use 1e-6 or tighter on sign-invariant quantities;
+* the 3D-2D correspondences of the PnP step with a numpy restatement of loop_closure.cpp:166-171 (exact).
+
+Scenes: a camera moving through a 3-D point cloud, keypoints = projections (float32) in a per-frame random order,
+matches in ascending queryIdx order with wrong matches mixed in, written into the batch's keypoint / match arrays
+(slamx_batch_upload_results) at sizes from 40 to 10,000 keypoints per frame -- the c3 workload's size.  The c3 workload's
+OWN frames are a pure image translation of a planar pattern: every correct match moves by the same pixel vector, the
+linear 8-point system then has a three-dimensional null space (x2 = H x1 with a homography H makes x2^T E x1 = 0 for every
+E with H^T E antisymmetric), and which vector of it an SVD returns is rounding noise -- no two implementations agree on
+E there, and the reference's cv::findEssentialMat would not either.  Those lists are therefore checked for what IS
+defined (batched == one-pair call bit for bit, the inlier set covers the correct matches, R is a rotation, |t| = 1).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K = np.array([[984.2439, 0.0, 690.0], [0.0, 980.8141, 233.1966], [0.0, 0.0, 1.0]])  # test/data/camera.yml K0
+
+
+def rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def fix_sign(E):
+    k = np.abs(E).argmax()
+    return E * np.sign(E.flat[k])
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def sequence(slamx, rng, n_frames, n_points, outliers=0.2, noise=0.15, keep=0.85):
+    """Keypoints and match lists of a camera moving through a point cloud.  -> per frame (kps, matches)."""
+    X = rng.uniform(-4, 4, (n_points, 3)) + np.array([0, 0, 11.0])
+    frames = []
+    prev_slot = None
+    for k in range(n_frames):
+        R = rot(*(0.02 * k * rng.uniform(0.5, 1.5, 3)))
+        t = np.array([0.25 * k, 0.03 * k, 0.05 * k]) + rng.uniform(-0.02, 0.02, 3)
+        x = (K @ (R @ X.T + t[:, None])).T
+        uv = x[:, :2] / x[:, 2:] + rng.normal(0, noise, (n_points, 2))
+        order = rng.permutation(n_points)          # keypoint slot i of this frame shows world point order[i]
+        slot = np.empty(n_points, np.int64)
+        slot[order] = np.arange(n_points)
+        kps = np.zeros(n_points, slamx.KEYPOINT_DTYPE)
+        kps["x"], kps["y"] = uv[order, 0].astype(np.float32), uv[order, 1].astype(np.float32)
+        kps["size"] = 6.0
+        matches = np.zeros(0, slamx.MATCH_DTYPE)
+        if prev_slot is not None:
+            q = np.sort(rng.choice(n_points, int(keep * n_points), replace=False))  # query keypoints that found a match
+            tr = prev_slot[order[q]]                                              # the same world point in the train frame
+            bad = rng.random(len(q)) < outliers
+            tr[bad] = rng.integers(0, n_points, int(bad.sum()))
+            matches = np.zeros(len(q), slamx.MATCH_DTYPE)
+            matches["queryIdx"], matches["trainIdx"], matches["distance"] = q, tr, 3.0
+        frames.append((kps, matches))
+        prev_slot = slot
+    return frames
+
+
+def host_samples(seed, stream, slot, hyp, n, k):
+    """pose_draw_sample (slamx_internal.h) restated: the counter-based generator of the batched RANSAC loops."""
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    key = mix((((seed << 1) | 1) + stream * 0xD1B54A32D192ED03) & M)
+    ctr0 = (slot << 40) | (hyp << 16)
+    out = []
+    draw = 0
+    while len(out) < k and draw < 4096:
+        z = mix((key + (ctr0 | draw) * 0x9E3779B97F4A7C15) & M)
+        c = ((z >> 32) * n) >> 32
+        if c not in out:
+            out.append(c)
+        draw += 1
+    return out
+
+
+def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_oracle=True):
+    kq, m = frames[k]
+    kt = frames[k - 1][0]
+    p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+    p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+    r = res[k]
+    assert r["status"] & (slamx.POSE_TOO_FEW_MATCHES | slamx.POSE_NO_TRAIN_FRAME | slamx.POSE_MATCH_OVERFLOW) == 0
+    assert r["n_matches"] == len(m)
+    table, ptable = pose.samples(k)
+    # --- the one-pair call on the device's table: the same kernels, bit for bit
+    Es, cs, ms = ctx.essential_from_samples(p1, p2, K, table, thr_px)
+    xyz, mask = pose.points(k)
+    assert np.array_equal(Es, r["E"]) and cs == r["n_inliers"] and np.array_equal(ms, mask)
+    sv = np.linalg.svd(r["E"], compute_uv=False)
+    assert abs(sv[0] - 1) < 1e-9 and abs(sv[1] - 1) < 1e-9 and sv[2] < 1e-9
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    n1 = np.stack([(p1[:, 0].astype(np.float64) - cx) / fx, (p1[:, 1].astype(np.float64) - cy) / fy], 1).astype(np.float32)
+    n2 = np.stack([(p2[:, 0].astype(np.float64) - cx) / fx, (p2[:, 1].astype(np.float64) - cy) / fy], 1).astype(np.float32)
+    Rs, ts, fs = ctx.recover_pose(r["E"], n1, n2, K)
+    assert np.array_equal(fs, r["front"]) and np.array_equal(Rs, r["R"]) and np.array_equal(ts, r["t"])
+    assert np.abs(r["R"].T @ r["R"] - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(r["R"]) - 1) < 1e-9
+    assert abs(np.linalg.norm(r["t"]) - 1) < 1e-9
+    P1 = np.zeros((3, 4))
+    P2 = np.zeros((3, 4))
+    T2 = np.hstack([r["R"], r["t"][:, None]])
+    T1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    for i in range(3):
+        for j in range(4):
+            s1 = s2 = 0.0
+            for q in range(3):
+                s1 += K[i, q] * T1[q, j]
+                s2 += K[i, q] * T2[q, j]
+            P1[i, j], P2[i, j] = s1, s2
+    _, xyz_s = ctx.triangulate(P1, P2, p1, p2)
+    assert np.array_equal(xyz_s, xyz)
+    if check_oracle:
+        # --- the oracle on the same table
+        Eo, co, mo, best, _, counts = oracle.essential_from_samples(p1, p2, K, table, thr_px)
+        assert abs(co - r["n_inliers"]) <= 2 and (mo != mask).sum() <= 2
+        assert np.abs(fix_sign(Eo) - fix_sign(r["E"])).max() < 1e-6
+        assert best == r["best_hypothesis"] or counts[best] == counts[r["best_hypothesis"]]
+        Ro, to, fo = oracle.recover_pose(r["E"], n1, n2, K)
+        assert sorted(fo.tolist()) == sorted(r["front"].tolist())
+        if sorted(fo.tolist())[-1] != sorted(fo.tolist())[-2]:
+            assert rel(r["R"], Ro) < 1e-7 and rel(r["t"], to) < 1e-7
+        _, xyz_o = oracle.triangulate(P1, P2, p1, p2)
+        good = np.isfinite(xyz_o).all(1) & (np.abs(xyz_o).max(1) < 1e4)  # (a wrong match can triangulate to infinity)
+        assert good.mean() > 0.7
+        assert np.abs(xyz[good] - xyz_o[good]).max() <= 1e-5 * np.abs(xyz_o[good]).max()
+    # --- the PnP step: correspondences of loop_closure.cpp:166-171, restated
+    if pose.cfg.pnp_iterations > 0:
+        c3, c2 = pose.correspondences(k)
+        if k >= 2 and len(frames[k - 1][1]) >= 8:
+            prev_pts, _ = pose.points(k - 1)
+            pm = frames[k - 1][1]
+            where = {int(q): i for i, q in enumerate(pm["queryIdx"])}  # map point of the train frame's keypoint
+            rows = [(where[int(t)], int(q)) for q, t in zip(m["queryIdx"], m["trainIdx"]) if int(t) in where]
+            want3 = prev_pts[[a for a, _ in rows]] if rows else np.zeros((0, 3))
+            want2 = np.stack([kq["x"][[b for _, b in rows]], kq["y"][[b for _, b in rows]]], 1).astype(np.float64) if rows else np.zeros((0, 2))
+            assert c3.tobytes() == want3.tobytes() and c2.tobytes() == want2.tobytes()
+        else:
+            assert len(c3) == 0
+        assert r["pnp_correspondences"] == len(c3)
+        if len(c3) >= max(6, pose.cfg.pnp_min_correspondences):
+            assert r["status"] & slamx.POSE_PNP_SKIPPED == 0
+            Rp, tp, bp = ctx.pnp_from_samples(c3, c2, K, ptable, pnp_thr)
+            assert bp == r["pnp_inliers"] and np.array_equal(Rp, r["pnp_R"]) and np.array_equal(tp, r["pnp_t"])
+            fin = np.isfinite(c3).all(1)
+            assert bp == oracle.count_inliers(c3[fin], c2[fin], K, Rp, tp, pnp_thr)
+            if bp > 0:
+                assert np.abs(Rp.T @ Rp - np.eye(3)).max() < 1e-9
+            else:
+                assert np.array_equal(Rp, np.eye(3)) and not tp.any()  # :173-175 identity / zero when nothing scores
+        else:
+            assert r["status"] & slamx.POSE_PNP_SKIPPED
+
+
+@pytest.mark.parametrize("n_points,iterations,pnp_thr", [(40, 64, 2.0), (600, 128, 2.0), (600, 200, 1.0e5), (2500, 256, 50.0)])
+def test_batch_pose_matches_one_pair_calls_and_oracle(slamx, gpu_ctx, oracle, n_points, iterations, pnp_thr):
+    rng = np.random.default_rng(n_points + iterations)
+    F = 6
+    frames = sequence(slamx, rng, F, n_points)
+    frames[4] = (frames[4][0], frames[4][1][:5])  # a frame with fewer than 8 matches: no pose, no map points
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 12, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, max(n_points, 256))
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    pose = slamx.PoseStage(batch, K, iterations=iterations, threshold_px=1.0, seed=77, pnp_iterations=60, pnp_threshold=pnp_thr)
+    pose.run(F, -1)
+    res = pose.download(F)
+    assert res[0]["status"] == slamx.POSE_NO_TRAIN_FRAME | slamx.POSE_PNP_SKIPPED and res[0]["n_matches"] == 0
+    assert res[4]["status"] & slamx.POSE_TOO_FEW_MATCHES and np.array_equal(res[4]["R"], np.eye(3)) and not res[4]["t"].any()
+    assert len(pose.points(4)[0]) == 0
+    assert res[5]["pnp_correspondences"] == 0  # frame 4 left no map points
+    for k in (1, 2, 3, 5):
+        check_pair(slamx, gpu_ctx, oracle, pose, res, frames, k, 1.0, pnp_thr)
+    # the recovered motion is the simulated one (frame 1 against frame 0: translation mostly along x)
+    if n_points >= 600:  # (40 points with a fifth of them wrong do not pin the direction)
+        ang = np.arccos(np.clip((np.trace(res[1]["R"]) - 1) / 2, -1, 1))
+        assert ang < 0.1 and abs(res[1]["t"][0]) > 0.8, (ang, res[1]["t"])
+    if pnp_thr > 1e4:
+        assert max(res[k]["pnp_inliers"] for k in (2, 3)) > 0  # the selection logic saw non-zero counts
+    # a second run gives the same bytes (no atomics on floating point anywhere)
+    pose.run(F, -1)
+    assert pose.download(F).tobytes() == res.tobytes()
+    # the sample tables are the documented counter-based generator
+    table, ptable = pose.samples(2)
+    n2 = len(frames[2][1])
+    for h in (0, 1, iterations - 1):
+        assert table[h].tolist() == host_samples(77, 0, 2, h, n2, 8)
+    m2 = int(res[2]["pnp_correspondences"])
+    if m2 >= 6:
+        assert ptable[3].tolist() == host_samples(77, 1, 2, 3, m2, 6)
+
+
+def test_batch_pose_first_train_frame_and_capacity(slamx, gpu_ctx, oracle):
+    """Frame 0 against a named slot (a streaming caller's previous frame), and a pair with more matches than
+    max_matches: the first max_matches are used and the frame says so."""
+    rng = np.random.default_rng(5)
+    F = 4
+    frames = sequence(slamx, rng, F, 500)
+    # frame 0's matches refer to slot 3 (the "previous batch's last frame")
+    seq2 = sequence(slamx, rng, 2, 500)
+    frames[3] = (seq2[0][0], frames[3][1])
+    frames[0] = (seq2[1][0], seq2[1][1])
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 12, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, 512)
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    pose = slamx.PoseStage(batch, K, iterations=96, threshold_px=1.0, seed=3)
+    pose.run(F, 3)
+    res = pose.download(F)
+    r = res[0]
+    assert r["status"] == 0 and r["n_matches"] == len(frames[0][1])
+    kq, m = frames[0]
+    kt = frames[3][0]
+    p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+    p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+    Es, cs, _ = gpu_ctx.essential_from_samples(p1, p2, K, pose.samples(0)[0], 1.0)
+    assert np.array_equal(Es, r["E"]) and cs == r["n_inliers"]
+    small = slamx.PoseStage(batch, K, iterations=32, threshold_px=1.0, seed=3, max_matches=100)
+    small.run(F, -1)
+    rs = small.download(F)
+    assert rs[1]["status"] & slamx.POSE_MATCH_OVERFLOW and rs[1]["n_matches"] == 100
+    kq, m = frames[1][0], frames[1][1][:100]
+    kt = frames[0][0]
+    p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+    p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+    Es, cs, _ = gpu_ctx.essential_from_samples(p1, p2, K, small.samples(1)[0], 1.0)
+    assert np.array_equal(Es, rs[1]["E"]) and cs == rs[1]["n_inliers"]
+    with pytest.raises(ValueError):
+        slamx.PoseStage(batch, K, iterations=0)
+    with pytest.raises(ValueError):
+        batch.upload_results(0, frames[0][0], frames[0][1][::-1])  # queryIdx must ascend
+
+
+def test_batch_pose_at_the_size_of_configs_2(slamx, gpu_ctx, oracle):
+    """BASELINE.json configs[2] -- 10k keypoints per 1080p frame -- at its own size: 10,000 keypoints and ~8,500 matches
+    per pair with a quarter of them wrong, on scenes with real depth (see the module text for why not the c3 frames)."""
+    rng = np.random.default_rng(10)
+    F = 4
+    frames = sequence(slamx, rng, F, 10000, outliers=0.25)
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 8, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, 16384)
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    pose = slamx.PoseStage(batch, K, iterations=256, threshold_px=1.0, seed=11, pnp_iterations=100, pnp_threshold=2.0,
+                           pnp_min_correspondences=20)
+    pose.run(F, -1)
+    res = pose.download(F)
+    for k in (1, 2, 3):
+        check_pair(slamx, gpu_ctx, oracle, pose, res, frames, k, 1.0, 2.0)
+        assert res[k]["n_inliers"] > 0.65 * res[k]["n_matches"]  # the correct three quarters are found
+        assert np.arccos(np.clip((np.trace(res[k]["R"]) - 1) / 2, -1, 1)) < 0.1 and abs(res[k]["t"][0]) > 0.8
+
+
+def test_batch_pose_on_the_c3_workloads_own_match_lists(slamx, gpu_ctx):
+    """The c3 workload itself (1080p, ~10k keypoints per frame): detect + describe + match + pose on the device, the
+    pose stage fed from the on-device match lists.  The frames are a planar pattern translated by (2, 1) px per frame,
+    so E is defined only up to the null space described in the module text: checked are the batched == one-pair
+    identity, the inlier set (every correct match satisfies every E of that family), and the shape of R, t."""
+    F = 4
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 8, 31, 256), gpu_ctx)
+    matcher = slamx.FeatureMatcher(slamx.MatcherConfig(0, 0, 20, 1, 0.5), gpu_ctx)
+    frames = np.stack([slamx.synth_frame(0x5EED0051, k, 1080, 1920, 32000, 3, 16) for k in range(F)])
+    batch = slamx.Batch(det, 1080, 1920, F, 131072, 16384)
+    batch.upload(frames)
+    batch.detect_and_compute(F)
+    batch.match_consecutive(matcher, F, use_keypoints=True, first_train_frame=-1)
+    Kc = np.array([[0.9 * 1920, 0, 960.0], [0, 0.9 * 1920, 540.0], [0, 0, 1.0]])
+    pose = slamx.PoseStage(batch, Kc, iterations=256, threshold_px=1.0, seed=1, pnp_iterations=100, pnp_threshold=2.0)
+    pose.run(F, -1)
+    res = pose.download(F)
+    _, nkp, nm = batch.counts(F)
+    assert nkp.min() > 9000
+    for k in range(1, F):
+        kq, _ = batch.download(k)
+        kt, _ = batch.download(k - 1)
+        m = batch.download_matches(matcher, k)
+        r = res[k]
+        assert r["n_matches"] == len(m) == nm[k] and r["status"] & 5 == 0
+        p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+        p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+        Es, cs, ms = gpu_ctx.essential_from_samples(p1, p2, Kc, pose.samples(k)[0], 1.0)
+        xyz, mask = pose.points(k)
+        assert np.array_equal(Es, r["E"]) and cs == r["n_inliers"] and np.array_equal(ms, mask)
+        d = p2 - p1
+        shift = np.array([2.0, 1.0], np.float32) * np.sign(np.median(d[:, 0]))  # the pattern moves by (2, 1) px per frame
+        true = (np.abs(d - shift).max(1) == 0)
+        assert true.mean() > 0.8 and mask[true].mean() > 0.95, (np.median(d, 0), true.mean(), mask[true].mean())
+        assert np.abs(r["R"].T @ r["R"] - np.eye(3)).max() < 1e-9 and abs(np.linalg.norm(r["t"]) - 1) < 1e-9
+        assert len(xyz) == len(m)
+        if k >= 2:
+            c3, c2 = pose.correspondences(k)
+            assert len(c3) == r["pnp_correspondences"] > 0.5 * len(m)
+
+
+def test_essential_one_pair_call_allocates_nothing_in_steady_state(slamx, gpu_ctx):
+    """the one-pair entry points once paid 8 hipMalloc + 8 hipFree per call.  Repeated calls of the same
+    size now reuse the context's workspace: the device pointer a fresh hipMalloc returns before and after is the same
+    free block (nothing was allocated or freed in between), and results repeat bit for bit."""
+    rng = np.random.default_rng(2)
+    fr = sequence(slamx, rng, 2, 700)
+    kq, m = fr[1]
+    kt = fr[0][0]
+    p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
+    p2 = np.stack([kq["x"][m["queryIdx"]], kq["y"][m["queryIdx"]]], 1).astype(np.float32)
+    first = gpu_ctx.essential_ransac(p1, p2, K, iterations=300, threshold_px=1.0, seed=9)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free0, total = ctypes.c_size_t(), ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total))
+    for _ in range(5):
+        again = gpu_ctx.essential_ransac(p1, p2, K, iterations=300, threshold_px=1.0, seed=9)
+        assert np.array_equal(again[0], first[0]) and again[1] == first[1]
+    free1 = ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total))
+    assert free1.value == free0.value
