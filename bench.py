@@ -573,6 +573,11 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-upload-inclusive leg (N == 1 only)")
     ap.add_argument("--no-keypoints", action="store_true", help="diagnostic: match without the jump-radius penalty")
+    ap.add_argument("--with-pose", action="store_true",
+                    help="configs[2]'s second half inside the timed step: essential-matrix RANSAC, simpleRecoverPose, "
+                         "triangulatePoints and PnP RANSAC for every frame pair of the batch (slamx_batch_pose)")
+    ap.add_argument("--pose-iterations", type=int, default=256, help="essential-matrix hypotheses per frame pair")
+    ap.add_argument("--pnp-iterations", type=int, default=100, help="PnP hypotheses per frame (loop_closure.yml: 100); 0 = off")
     ap.add_argument("--no-extras", action="store_true",
                     help="default workload only: skip the short runs of c3 / c3p / c4 reported under other_workloads")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -636,6 +641,13 @@ def main(argv=None):
         batch = mod.Batch(det, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"])
     batch.upload(frames)
     ctx.synchronize()
+    pose = None
+    if args.with_pose:
+        # a pinhole camera for the synthetic frames (the reference's camera.yml belongs to its 1392 x 512 KITTI frames)
+        f = 0.9 * wl["cols"]
+        Kcam = np.array([[f, 0, wl["cols"] / 2.0], [0, f, wl["rows"] / 2.0], [0, 0, 1.0]])
+        pose = mod.PoseStage(batch, Kcam, iterations=args.pose_iterations, threshold_px=1.0, seed=SEED & 0xFFFFFFFF,
+                             pnp_iterations=args.pnp_iterations, pnp_threshold=2.0, pnp_min_correspondences=20)
 
     def step():
         if pyr is not None:
@@ -643,6 +655,8 @@ def main(argv=None):
         else:
             batch.detect_and_compute(B)
         batch.match_consecutive(matcher, B, use_keypoints=not args.no_keypoints, first_train_frame=B - 1)
+        if pose is not None:
+            pose.run(B, B - 1)
 
     for _ in range(args.warmup):
         step()
@@ -664,6 +678,8 @@ def main(argv=None):
     every = 8 if K >= 16 else (4 if K >= 8 else 1)
     sets = min((K + every - 1) // every, 256)
     batch.set_profiling(sets, every)
+    if pose is not None:
+        pose.set_profiling(every)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -801,6 +817,10 @@ def main(argv=None):
                              "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
             "device": ctx.device_name,
         }
+        if pose is not None:
+            out["pose"] = pose_report(mod, pose, B, args, elapsed / K * 1e3)
+            out["config"]["workload"] += (" + pose stage per frame pair (essential-matrix RANSAC %d hypotheses, simpleRecoverPose, "
+                                          "triangulatePoints, PnP RANSAC %d hypotheses)" % (args.pose_iterations, args.pnp_iterations))
         if pyr is not None:
             out["config"]["pyramid"] = {"levels": wl["levels"], "scale_factor": wl["scale"], "level_shapes": pyr.shapes,
                                         "note": "stage_ms_per_step / roofline are level 0's kernels (candidates_per_frame too) plus "
@@ -822,6 +842,61 @@ def main(argv=None):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# vector FP64 peak of MI355X: 78.6 TFLOP/s counting an FMA as two (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz); the
+# parity path rounds every operation separately (no FMA contraction), so its instruction-rate ceiling is half of that
+VALU_F64_PEAK_TFLOPS = 78.6
+
+
+def pose_report(mod, pose, B, args, ms_per_step):
+    """Per-kernel times of the pose stage (hipEvents on the context stream around every launch of the recorded steps),
+    what the stage found, and the kernels against their ceilings: the two scoring kernels are FP64 vector arithmetic
+    (33 flops per hypothesis and correspondence for the Sampson test; 3 x 8 + 20 flops and three IEEE divisions for the
+    reprojection test), the refit and the DLT solves are the FP64 matrix-core contractions of the stage."""
+    import numpy as np
+
+    ms, nsets = pose.stage_ms()
+    res = pose.download(B)
+    n = res["n_matches"].astype(np.float64)
+    m = res["pnp_correspondences"].astype(np.float64)
+    H, Hp = args.pose_iterations, args.pnp_iterations
+    total = sum(ms.values())
+    out = {"ms_per_step": total, "share_of_step": total / ms_per_step if ms_per_step > 0 else None,
+           "stage_ms_per_step": ms, "steps_timed": nsets,
+           "hypotheses_per_pair": H, "pnp_hypotheses_per_frame": Hp,
+           "matches_per_pair": float(n.mean()), "essential_inliers_per_pair": float(res["n_inliers"].mean()),
+           "pairs_with_a_pose": int((res["status"] & (mod.POSE_TOO_FEW_MATCHES | mod.POSE_NO_TRAIN_FRAME) == 0).sum()),
+           "pnp_correspondences_per_frame": float(m.mean()), "pnp_inliers_per_frame": float(res["pnp_inliers"].mean()),
+           "pnp_frames_skipped": int((res["status"] & mod.POSE_PNP_SKIPPED != 0).sum())}
+    rl = {}
+    if ms["score"] > 0:
+        fl = 33.0 * H * float(n.sum())
+        a = fl / (ms["score"] * 1e-3) / 1e12
+        rl["sampson_score_kernel"] = {"bound": "valu-f64", "achieved": a, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": a / VALU_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl, "avg_launch_ms": ms["score"],
+                                      "note": "33 flops per (hypothesis, correspondence), each rounded on its own (no FMA): "
+                                              "the instruction-rate ceiling of that form is half the peak"}
+    if ms["refit"] > 0:
+        fl = 2.0 * 81.0 * float(res["n_inliers"].sum())
+        issued = 2.0 * 256.0 * float((np.ceil(n / 64.0) * 64.0).sum())
+        a = issued / (ms["refit"] * 1e-3) / 1e12
+        rl["essential_refit_kernel"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": a / MFMA_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl, "issued_per_launch": issued,
+                                        "avg_launch_ms": ms["refit"],
+                                        "note": "one wave per pair: the 9 x 9 normal matrix over all inliers as 16 x 16 x 4 FP64 "
+                                                "MFMAs; latency of one wave per CU, not the matrix cores, bounds it"}
+    if ms["pnp_solve"] > 0 and Hp > 0:
+        nh = float((res["status"] & mod.POSE_PNP_SKIPPED == 0).sum()) * Hp
+        issued = 36.0 * 2048.0 * nh          # 3 passes x (3 Gram + 4 + 4 update MFMAs) + the final Gram, 16 x 16 x 4 each
+        fl = 4.0 * 576.0 * 6.0 * nh          # SURVEY 8d: 576 n flops per Gram pass of the 2n x 12 DLT system, n = 6
+        a = issued / (ms["pnp_solve"] * 1e-3) / 1e12
+        rl["pnp_hyp_kernel"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": a / MFMA_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl, "issued_per_launch": issued,
+                                "survey_achieved": fl / (ms["pnp_solve"] * 1e-3) / 1e12, "avg_launch_ms": ms["pnp_solve"],
+                                "note": "a wave per hypothesis: the Jacobi rotations between the MFMA passes are the time"}
+    out["rooflines"] = rl
+    return out
 
 
 def other_workloads():

@@ -388,13 +388,15 @@ int oracle_essential_from_samples(const float* pts1, const float* pts2, int n, c
         int c = 0;
         for (int i = 0; i < n; ++i) {
             const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
-            const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
-            const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
-            const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
-            const double et0 = e[0] * u2 + e[3] * v2 + e[6];
-            const double et1 = e[1] * u2 + e[4] * v2 + e[7];
-            const double r = u2 * ex0 + v2 * ex1 + ex2;
-            const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+            // chains of fused multiply-adds, innermost term first: the estimator is the build's own, and this is how it
+            // defines the Sampson test (18 FP64 operations on the GPU instead of 33)
+            const double ex0 = std::fma(e[0], u1, std::fma(e[1], v1, e[2]));
+            const double ex1 = std::fma(e[3], u1, std::fma(e[4], v1, e[5]));
+            const double ex2 = std::fma(e[6], u1, std::fma(e[7], v1, e[8]));
+            const double et0 = std::fma(e[0], u2, std::fma(e[3], v2, e[6]));
+            const double et1 = std::fma(e[1], u2, std::fma(e[4], v2, e[7]));
+            const double r = std::fma(u2, ex0, std::fma(v2, ex1, ex2));
+            const double den = std::fma(ex0, ex0, std::fma(ex1, ex1, std::fma(et0, et0, et1 * et1)));
             const bool in = den > 0.0 && r * r < thr2 * den;
             c += in ? 1 : 0;
             if (flags != nullptr) {

@@ -34,23 +34,34 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// ---------------- per-lane one-sided Jacobi SVD of a tiny M x N matrix (row-major) ----------------
-// W = U diag(S) V^T, S descending (ties keep column order), U columns of zero singular values are
-// left zero.  Same algorithm as the oracle's svd_jacobi.
+// 1 / x, 1 / sqrt(x) and sqrt(x) from the hardware estimates plus Newton steps (a few ulps): the IEEE-exact division and
+// square-root sequences cost ~25-30 instructions each, and a Jacobi rotation has seven of them.  Used where a result is
+// an iterate of a self-correcting iteration (rotation angles), never where the reference's rounding is observable.
+__device__ __forceinline__ double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ double rsq_fast(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+
+// ---------------- per-lane one-sided Jacobi (Hestenes) iteration on a tiny M x N matrix ----------------
+// Rotates the columns of W (and of Vt, which starts as the identity) until every pair is orthogonal to 1e-15 relative:
+// W = U diag(S) Vt^T.  Same cyclic order as the CPU checker's svd_jacobi; a pair that is already orthogonal to that level
+// is left alone (the checker rotates it by ~1e-16), and the sweep that finds nothing to rotate ends the iteration.
 template <int M, int N>
-__device__ void svd_small(const double* A, double* U, double* S, double* V) {
-    double W[M * N];
-    double Vt[N * N];
-#pragma unroll
-    for (int i = 0; i < M * N; ++i) {
-        W[i] = A[i];
-    }
+__device__ __forceinline__ void jacobi_columns(double* W, double* Vt) {
 #pragma unroll
     for (int i = 0; i < N * N; ++i) {
         Vt[i] = (i / N == i % N) ? 1.0 : 0.0;
     }
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0;
+        bool rotated = false;
 #pragma unroll
         for (int p = 0; p < N - 1; ++p) {
 #pragma unroll
@@ -64,11 +75,15 @@ __device__ void svd_small(const double* A, double* U, double* S, double* V) {
                     beta += b * b;
                     gamma += a * b;
                 }
-                if (gamma != 0.0) {
-                    off = fmax(off, fabs(gamma) / sqrt(fmax(alpha * beta, 1e-300)));
-                    const double zeta = (beta - alpha) / (2.0 * gamma);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t);
+                if (gamma * gamma > 1e-30 * (alpha * beta)) {
+                    rotated = true;
+                    const double zeta = (beta - alpha) * rcp_fast(2.0 * gamma);
+                    const double az = fabs(zeta);
+                    const double q1 = 1.0 + az * az;
+                    // |zeta| + sqrt(1 + zeta^2); beyond 1e150 the square overflows and the sum is 2 |zeta| to 1e-300
+                    const double den = az > 1e150 ? 2.0 * az : az + q1 * rsq_fast(q1);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) * rcp_fast(den);
+                    const double c = rsq_fast(1.0 + t * t);
                     const double s = c * t;
 #pragma unroll
                     for (int k = 0; k < M; ++k) {
@@ -87,10 +102,22 @@ __device__ void svd_small(const double* A, double* U, double* S, double* V) {
                 }
             }
         }
-        if (off < 1e-15) {
+        if (!rotated) {
             break;
         }
     }
+}
+
+// W = U diag(S) V^T, S descending (ties keep column order), U columns of zero singular values are left zero.
+template <int M, int N>
+__device__ void svd_small(const double* A, double* U, double* S, double* V) {
+    double W[M * N];
+    double Vt[N * N];
+#pragma unroll
+    for (int i = 0; i < M * N; ++i) {
+        W[i] = A[i];
+    }
+    jacobi_columns<M, N>(W, Vt);
     double sv[N];
     int order[N];
 #pragma unroll
@@ -126,6 +153,44 @@ __device__ void svd_small(const double* A, double* U, double* S, double* V) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             V[k * N + jj] = Vt[k * N + j];
+        }
+    }
+}
+
+// Only the right singular vector of the SMALLEST singular value (the last column of V above): no square roots, no U.
+// Among equal smallest values the stable descending sort puts the highest column last.
+template <int M, int N>
+__device__ void smallest_right_singular_vector(const double* A, double* x) {
+    double W[M * N];
+    double Vt[N * N];
+#pragma unroll
+    for (int i = 0; i < M * N; ++i) {
+        W[i] = A[i];
+    }
+    jacobi_columns<M, N>(W, Vt);
+    double nn[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            v += W[k * N + j] * W[k * N + j];
+        }
+        nn[j] = v;
+    }
+    double best = nn[0];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        x[k] = Vt[k * N];
+    }
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+        if (nn[j] <= best) {
+            best = nn[j];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                x[k] = Vt[k * N + j];
+            }
         }
     }
 }
@@ -169,12 +234,7 @@ __device__ void triangulate_dlt(const double* P1, const double* P2, float x1, fl
         A[2 * 4 + j] = static_cast<double>(x2) * P2[8 + j] - P2[0 + j];
         A[3 * 4 + j] = static_cast<double>(y2) * P2[8 + j] - P2[4 + j];
     }
-    double U[16], S[4], V[16];
-    svd_small<4, 4>(A, U, S, V);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        X[k] = V[k * 4 + 3];
-    }
+    smallest_right_singular_vector<4, 4>(A, X);
 }
 
 // ---------------- a11: DLT PnP, one wave per hypothesis ----------------
@@ -191,7 +251,6 @@ struct JacobiWork {
     double T[(ROWS > LD ? ROWS : LD) * LD];
 };
 typedef JacobiWork<PNP_MAX_ROWS> PnpWork;  // solvePnP with up to 32 points (slamx_pnp_dlt_batch)
-typedef JacobiWork<16> PnpWork6;           // the RANSAC's 6-point samples: 12 rows
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -586,15 +645,25 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double* __restri
 
 // Sampson test of one correspondence under one essential matrix (normalised units), as cv-style RANSACs score it:
 // r^2 / (|E x1|_xy^2 + |E^T x2|_xy^2) < thr2.  Same operations, same order as the CPU checker of the tests.
-__device__ __forceinline__ bool sampson_inlier(const double* e, double u1, double v1, double u2, double v2, double thr2) {
-    const double ex0 = e[0] * u1 + e[1] * v1 + e[2];
-    const double ex1 = e[3] * u1 + e[4] * v1 + e[5];
-    const double ex2 = e[6] * u1 + e[7] * v1 + e[8];
-    const double et0 = e[0] * u2 + e[3] * v2 + e[6];
-    const double et1 = e[1] * u2 + e[4] * v2 + e[7];
-    const double r = u2 * ex0 + v2 * ex1 + ex2;
-    const double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
-    return den > 0.0 && r * r < thr2 * den;
+// A pointer into the CONSTANT address space: a load through it with a wave-uniform address is a scalar load (s_load),
+// and its result a scalar operand.  Only for arrays no lane writes while the kernel runs (the hypotheses of the scoring
+// kernels, written by the kernel before).
+typedef const double __attribute__((address_space(4))) * uniform_doubles;
+__device__ __forceinline__ uniform_doubles as_uniform(const double* p) { return (uniform_doubles)p; }
+
+template <typename Ptr>
+__device__ __forceinline__ bool sampson_inlier(Ptr e, double u1, double v1, double u2, double v2, double thr2) {
+    // Every product-sum is a chain of fused multiply-adds, innermost term first (the estimator is this build's own, so
+    // its rounding is this build's to define: the CPU checker evaluates the same chain with std::fma) -- 18 FP64
+    // instructions per test instead of 33.
+    const double ex0 = __builtin_fma(e[0], u1, __builtin_fma(e[1], v1, e[2]));
+    const double ex1 = __builtin_fma(e[3], u1, __builtin_fma(e[4], v1, e[5]));
+    const double ex2 = __builtin_fma(e[6], u1, __builtin_fma(e[7], v1, e[8]));
+    const double et0 = __builtin_fma(e[0], u2, __builtin_fma(e[3], v2, e[6]));
+    const double et1 = __builtin_fma(e[1], u2, __builtin_fma(e[4], v2, e[7]));
+    const double r = __builtin_fma(u2, ex0, __builtin_fma(v2, ex1, ex2));
+    const double den = __builtin_fma(ex0, ex0, __builtin_fma(ex1, ex1, __builtin_fma(et0, et0, et1 * et1)));
+    return (den > 0.0) & (r * r < thr2 * den);  // (no short circuit: straight-line code)
 }
 
 // En (conditioned null vector, row-major 3 x 3) -> essential matrix: undo the conditioning (E = T2^T En T1,
@@ -800,27 +869,26 @@ __global__ __launch_bounds__(64) void essential_hyp_kernel(PoseWork w, PoseParam
 }
 
 // ---- every hypothesis against every correspondence of its pair ----
-// A lane holds SCORE_PPT correspondences in registers; the hypotheses of the pair stream through LDS in tiles of 64.
-// counts[p][h] += number of correspondences of this block's chunk that pass.  Integer sums: order-free.
-constexpr int SCORE_PPT = 2;
-constexpr int SCORE_TILE = 64;
-__global__ __launch_bounds__(256) void sampson_score_kernel(PoseWork w, PoseParams prm) {
-    __shared__ double Et[SCORE_TILE * 9];
-    __shared__ int cnt[SCORE_TILE];
+// One wave per workgroup; a lane holds SCORE_PPT correspondences in registers.  A hypothesis is wave-uniform: its nine
+// doubles arrive through the scalar cache (s_load) and enter the FP64 instructions as scalar operands -- no LDS staging,
+// no barriers.  counts[p][h] += number of correspondences of this wave that pass (integer sums: order-free); lane l keeps
+// the wave's count for hypothesis h0 + l and one vector atomic per 64 hypotheses writes them out.
+constexpr int SCORE_PPT = 4;
+__global__ __launch_bounds__(64) void sampson_score_kernel(PoseWork w, PoseParams prm) {
     const int p = blockIdx.y;
     const int n = w.n[p];
-    const int first = blockIdx.x * (256 * SCORE_PPT);
+    const int first = blockIdx.x * (64 * SCORE_PPT);
     if (n < 8 || first >= n) {
         return;
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
     const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
     double u1[SCORE_PPT], v1[SCORE_PPT], u2[SCORE_PPT], v2[SCORE_PPT];
     bool live[SCORE_PPT];
 #pragma unroll
     for (int q = 0; q < SCORE_PPT; ++q) {
-        const int i = first + q * 256 + static_cast<int>(threadIdx.x);
+        const int i = first + q * 64 + lane;
         live[q] = i < n;
         const double2 a = live[q] ? X1[i] : make_double2(0.0, 0.0);
         const double2 b = live[q] ? X2[i] : make_double2(0.0, 0.0);
@@ -829,35 +897,43 @@ __global__ __launch_bounds__(256) void sampson_score_kernel(PoseWork w, PosePara
         u2[q] = b.x;
         v2[q] = b.y;
     }
-    const double* Eh = w.Eh + static_cast<size_t>(p) * prm.iterations * 9;
+    const double* __restrict__ Eh = w.Eh + static_cast<size_t>(p) * prm.iterations * 9;
     int* counts = w.counts + static_cast<size_t>(p) * prm.iterations;
-    for (int h0 = 0; h0 < prm.iterations; h0 += SCORE_TILE) {
-        const int nh = min(SCORE_TILE, prm.iterations - h0);
-        __syncthreads();  // the previous tile has been consumed
-        for (int e = threadIdx.x; e < nh * 9; e += 256) {
-            Et[e] = Eh[static_cast<size_t>(h0) * 9 + e];
+    const double thr2 = prm.thr2;
+    // the next hypothesis is requested while the current one is evaluated (a scalar load takes ~200 cycles to return)
+    double nxt[9];
+    {
+        const uniform_doubles e = as_uniform(Eh);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            nxt[j] = e[j];
         }
-        if (threadIdx.x < SCORE_TILE) {
-            cnt[threadIdx.x] = 0;
-        }
-        __syncthreads();
-        int mine = 0;  // lane l of a wave keeps the wave's count for hypothesis h0 + l
+    }
+    const int H = prm.iterations;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int nh = min(64, H - h0);
+        int mine = 0;
         for (int k = 0; k < nh; ++k) {
-            const double* e = Et + k * 9;
+            double cur[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                cur[j] = nxt[j];
+            }
+            const uniform_doubles e = as_uniform(Eh + static_cast<size_t>(min(h0 + k + 1, H - 1)) * 9);  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                nxt[j] = e[j];
+            }
             int c = 0;
 #pragma unroll
             for (int q = 0; q < SCORE_PPT; ++q) {
-                const bool in = live[q] && sampson_inlier(e, u1[q], v1[q], u2[q], v2[q], prm.thr2);
+                const bool in = live[q] & sampson_inlier(cur, u1[q], v1[q], u2[q], v2[q], thr2);
                 c += __builtin_popcountll(__ballot(in));
             }
             mine += lane == k ? c : 0;
         }
         if (lane < nh && mine != 0) {
-            atomicAdd(&cnt[lane], mine);
-        }
-        __syncthreads();
-        if (static_cast<int>(threadIdx.x) < nh && cnt[threadIdx.x] != 0) {
-            atomicAdd(&counts[h0 + threadIdx.x], cnt[threadIdx.x]);
+            atomicAdd(&counts[h0 + lane], mine);
         }
     }
 }
@@ -1345,50 +1421,212 @@ __global__ __launch_bounds__(1024) void pnp_gather_kernel(PoseSource src, PoseWo
     (void)carry_s;
 }
 
-// ---- a11 for the batch: solvePnP on a 6-point sample, one WAVE per hypothesis (the 12 x 12 DLT system on FP64 MFMA) ----
-constexpr int PNP_WAVES = 8;
-__global__ __launch_bounds__(64 * PNP_WAVES) void pnp_hyp_kernel(PoseWork w, PoseParams prm) {
+// ---- a11 for the batch: solvePnP (loop_closure.cpp:238-274) on a 6-point sample, one LANE per hypothesis ----
+// The 12 x 12 DLT matrix of a lane lives in LDS (element e of lane l at [e * 64 + l]: conflict-free), 72 KB per wave.
+// p = right singular vector of its smallest singular value: Householder QR (A = Q R; the right singular vectors of R are
+// A's), then inverse iteration with R^T R -- two triangular solves per step, no squaring of the condition number (the
+// pixel-scale rows give cond(A) ~ 1e5, which is why a one-shot eigen-solve of A^T A would not do) -- until the direction
+// moves by less than 1e-14 or 40 steps (a sample whose two smallest singular values coincide has no defined answer).
+// A wave per hypothesis (the first version: Gram matrix on MFMA + cyclic Jacobi in LDS, kept for slamx_pnp_dlt_batch)
+// took 4.9 ms for 256 x 100 hypotheses; this takes two orders of magnitude less.
+constexpr int DLT_N = 12;
+constexpr size_t PNP_HYP_LDS = static_cast<size_t>(DLT_N) * DLT_N * 64 * sizeof(double);
+__global__ __launch_bounds__(64) void pnp_hyp_kernel(PoseWork w, PoseParams prm) {
     extern __shared__ double pose_lds[];
     const int p = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const int h = blockIdx.x * PNP_WAVES + wave;
+    const int lane = threadIdx.x;
     const int m = w.m[p];
     const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
-    if (h >= prm.pnp_iterations || m < need) {
-        return;  // wave-uniform
+    if (m < need) {
+        return;  // uniform
     }
-    PnpWork6& wk = *reinterpret_cast<PnpWork6*>(pose_lds + static_cast<size_t>(wave) * (sizeof(PnpWork6) / sizeof(double)));
+    const int h_raw = blockIdx.x * 64 + lane;
+    const bool active = h_raw < prm.pnp_iterations;
+    const int h = active ? h_raw : prm.pnp_iterations - 1;  // spare lanes redo the last hypothesis and write nothing
     const size_t hh = static_cast<size_t>(p) * prm.pnp_iterations + h;
-    // the sample: drawn (or read) by every lane alike, kept in LDS so that the row builder can index it
-    int* sidx = reinterpret_cast<int*>(wk.T);  // (T is scratch of the solve, free until its first pass)
+    int idx[6];
     if (prm.device_sampling != 0) {
-        int idx[6];
         pose_draw_sample(prm.seed, 1, p, h, m, 6, idx);
-        if (lane == 0) {
+        if (active) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                sidx[k] = idx[k];
                 w.pidx[hh * 6 + k] = idx[k];
             }
         }
-    } else if (lane < 6) {
-        const int c = w.pidx[hh * 6 + lane];
-        sidx[lane] = c < 0 ? 0 : (c >= m ? m - 1 : c);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int c = w.pidx[hh * 6 + k];
+            idx[k] = c < 0 ? 0 : (c >= m ? m - 1 : c);
+        }
     }
-    wave_sync();
     const double* c3 = w.c3 + static_cast<size_t>(p) * prm.cap * 3;
     const double* c2 = w.c2 + static_cast<size_t>(p) * prm.cap * 2;
-    wave_solve_pnp(
-        wk, 6, [&](int i) { return c3 + 3 * static_cast<size_t>(sidx[i]); },
-        [&](int i) { return c2 + 2 * static_cast<size_t>(sidx[i]); }, lane, w.pRt + hh * 12, w.pRt + hh * 12 + 9, nullptr);
-    if (lane == 0) {
-        w.pcounts[hh] = 0;
+    double* A = pose_lds + lane;  // A[r][c] at A[(r * 12 + c) * 64]
+#define AL(r, c) A[((r) * DLT_N + (c)) * 64]
+    // rows of loop_closure.cpp:249-255
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double X = c3[3 * static_cast<size_t>(idx[i])], Y = c3[3 * static_cast<size_t>(idx[i]) + 1],
+                     Z = c3[3 * static_cast<size_t>(idx[i]) + 2];
+        const double u = c2[2 * static_cast<size_t>(idx[i])], v = c2[2 * static_cast<size_t>(idx[i]) + 1];
+        const double r0[12] = {X, Y, Z, 1.0, 0.0, 0.0, 0.0, 0.0, -u * X, -u * Y, -u * Z, -u};
+        const double r1[12] = {0.0, 0.0, 0.0, 0.0, X, Y, Z, 1.0, -v * X, -v * Y, -v * Z, -v};
+#pragma unroll
+        for (int c = 0; c < DLT_N; ++c) {
+            AL(2 * i, c) = r0[c];
+            AL(2 * i + 1, c) = r1[c];
+        }
     }
+    // Householder QR, column by column; R ends up in the upper triangle
+    double dmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < DLT_N; ++k) {
+        double v[DLT_N];
+        double s = 0.0;
+#pragma unroll
+        for (int r = k; r < DLT_N; ++r) {
+            v[r] = AL(r, k);
+            s += v[r] * v[r];
+        }
+        if (k == DLT_N - 1) {
+            dmax = fmax(dmax, fabs(v[k]));
+            break;
+        }
+        const double nrm = sqrt(s);
+        const double alpha = v[k] >= 0.0 ? -nrm : nrm;
+        v[k] -= alpha;
+        double vtv = 0.0;
+#pragma unroll
+        for (int r = k; r < DLT_N; ++r) {
+            vtv += v[r] * v[r];
+        }
+        const double bk = vtv > 0.0 ? 2.0 / vtv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < DLT_N; ++j) {
+            double col[DLT_N];
+            double d = 0.0;
+#pragma unroll
+            for (int r = k; r < DLT_N; ++r) {
+                col[r] = AL(r, j);
+                d += v[r] * col[r];
+            }
+            d *= bk;
+#pragma unroll
+            for (int r = k; r < DLT_N; ++r) {
+                AL(r, j) = col[r] - d * v[r];
+            }
+        }
+        AL(k, k) = alpha;
+        dmax = fmax(dmax, nrm);
+    }
+    // reciprocal diagonal; a vanishing pivot (exact data: A is singular) is replaced by a tiny one of the same sign
+    double rd[DLT_N];
+    const double tiny = dmax * 1e-18 + 1e-300;
+#pragma unroll
+    for (int k = 0; k < DLT_N; ++k) {
+        const double d = AL(k, k);
+        rd[k] = 1.0 / (fabs(d) < tiny ? (d < 0.0 ? -tiny : tiny) : d);
+    }
+    double x[DLT_N];
+#pragma unroll
+    for (int k = 0; k < DLT_N; ++k) {
+        x[k] = 0.28867513459481287;  // 1 / sqrt(12)
+    }
+    bool done = false;
+    for (int it = 0; it < 40; ++it) {
+        if (__ballot(!done) == 0ull) {
+            break;  // every lane of the wave has converged
+        }
+        double y[DLT_N], z[DLT_N];
+        // R^T y = x (forward)
+#pragma unroll
+        for (int i = 0; i < DLT_N; ++i) {
+            double acc = x[i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                acc -= AL(j, i) * y[j];
+            }
+            y[i] = acc * rd[i];
+        }
+        // R z = y (backward)
+#pragma unroll
+        for (int i = DLT_N - 1; i >= 0; --i) {
+            double acc = y[i];
+#pragma unroll
+            for (int j = i + 1; j < DLT_N; ++j) {
+                acc -= AL(i, j) * z[j];
+            }
+            z[i] = acc * rd[i];
+        }
+        double nn = 0.0, dot = 0.0;
+#pragma unroll
+        for (int k = 0; k < DLT_N; ++k) {
+            nn += z[k] * z[k];
+            dot += z[k] * x[k];
+        }
+        const double scale = (dot < 0.0 ? -1.0 : 1.0) * rsq_fast(nn);  // keep the direction's sign from step to step
+        double moved = 0.0;
+#pragma unroll
+        for (int k = 0; k < DLT_N; ++k) {
+            const double nx = z[k] * scale;
+            moved = fmax(moved, fabs(nx - x[k]));
+            x[k] = done ? x[k] : nx;
+        }
+        done = done || !(moved > 1e-14) || !(nn > 0.0) || !(nn < 1e300);
+    }
+#undef AL
+    if (!active) {
+        return;
+    }
+    // :260 column-major 3x4 map of the row-major DLT vector (reference behaviour, kept), :262-271 orthonormalisation
+    double R0[9], t0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            R0[r * 3 + c] = x[c * 3 + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        t0[r] = x[9 + r];
+    }
+    double Ur[9], Sr[3], Vr[9], Vrt[9], UVt[9], UD[9], Rm[9];
+    svd3(R0, Ur, Sr, Vr);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            Vrt[i * 3 + j] = Vr[j * 3 + i];
+        }
+    }
+    mul3(Ur, Vrt, UVt);
+    const double det = det3(UVt);
+    const double D[9] = {1, 0, 0, 0, 1, 0, 0, 0, det};
+    mul3(Ur, D, UD);
+    mul3(UD, Vrt, Rm);
+    double fro = 0.0;
+    for (int k = 0; k < 9; ++k) {
+        fro += R0[k] * R0[k];
+    }
+    fro = sqrt(fro);
+    double* out = w.pRt + hh * 12;
+    for (int k = 0; k < 9; ++k) {
+        out[k] = Rm[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        out[9 + k] = t0[k] / fro;
+    }
+    if (w.pnull != nullptr) {
+        for (int k = 0; k < 12; ++k) {
+            w.pnull[hh * 12 + k] = x[k];
+        }
+    }
+    w.pcounts[hh] = 0;
 }
 
 // reprojection test of loop_closure.cpp:201-215 for one (R, t): Rt = R row-major (9) then t (3)
-__device__ __forceinline__ bool pnp_inlier(const double* Rt, const double* K, double X, double Y, double Z, double u, double v,
+template <typename Ptr>
+__device__ __forceinline__ bool pnp_inlier(Ptr Rt, const double* K, double X, double Y, double Z, double u, double v,
                                            double threshold) {
     double tp[3];
 #pragma unroll
@@ -1406,49 +1644,94 @@ __device__ __forceinline__ bool pnp_inlier(const double* Rt, const double* K, do
     return sqrt(ex * ex + ey * ey) < threshold;
 }
 
-// every PnP hypothesis against every correspondence of its frame (the structure of sampson_score_kernel)
-__global__ __launch_bounds__(256) void pnp_score_kernel(PoseWork w, PoseParams prm) {
-    __shared__ double Rt[SCORE_TILE * 12];
-    __shared__ int cnt[SCORE_TILE];
+// The same decision from reciprocals instead of three divisions and a square root: compare the squared error computed
+// with a few-ulp reciprocal against the squared threshold; only when the two are closer than 1e-9 relative (or anything is
+// not finite) does the reference's own sequence decide.  The verdict is ALWAYS pnp_inlier's.
+template <typename Ptr>
+__device__ __forceinline__ bool pnp_inlier_quick(Ptr Rt, const double* K, double X, double Y, double Z, double u, double v,
+                                                 double threshold, double thr2) {
+    double tp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        tp[r] = Rt[r * 3] * X + Rt[r * 3 + 1] * Y + Rt[r * 3 + 2] * Z + Rt[9 + r];
+    }
+    if (!(tp[2] > 0)) {
+        return tp[2] <= 0 ? false : pnp_inlier(Rt, K, X, Y, Z, u, v, threshold);  // (NaN depth: the exact sequence)
+    }
+    const double inv = rcp_fast(tp[2]);
+    const double q0 = tp[0] * inv, q1 = tp[1] * inv;
+    const double ex = u - (K[0] * q0 + K[1] * q1 + K[2]);
+    const double ey = v - (K[3] * q0 + K[4] * q1 + K[5]);
+    const double e2 = ex * ex + ey * ey;
+    const double gap = fabs(e2 - thr2);
+    if (gap > 1e-9 * (e2 + thr2)) {
+        return e2 < thr2;
+    }
+    return pnp_inlier(Rt, K, X, Y, Z, u, v, threshold);
+}
+
+// every PnP hypothesis against every correspondence of its frame (the structure of sampson_score_kernel: one wave per
+// workgroup, the hypothesis' twelve doubles through the scalar cache)
+__global__ __launch_bounds__(64) void pnp_score_kernel(PoseWork w, PoseParams prm) {
     const int p = blockIdx.y;
     const int m = w.m[p];
     const int need = prm.pnp_min > 6 ? prm.pnp_min : 6;
-    const int first = blockIdx.x * 256;
+    const int first = blockIdx.x * (64 * SCORE_PPT);
     if (m < need || first >= m) {
         return;
     }
-    const int lane = threadIdx.x & 63;
-    const int i = first + static_cast<int>(threadIdx.x);
-    const bool live = i < m;
+    const int lane = threadIdx.x;
     const double* c3 = w.c3 + static_cast<size_t>(p) * prm.cap * 3;
     const double* c2 = w.c2 + static_cast<size_t>(p) * prm.cap * 2;
-    const double X = live ? c3[3 * static_cast<size_t>(i)] : 0.0, Y = live ? c3[3 * static_cast<size_t>(i) + 1] : 0.0,
-                 Z = live ? c3[3 * static_cast<size_t>(i) + 2] : 0.0;
-    const double u = live ? c2[2 * static_cast<size_t>(i)] : 0.0, v = live ? c2[2 * static_cast<size_t>(i) + 1] : 0.0;
-    const double* src = w.pRt + static_cast<size_t>(p) * prm.pnp_iterations * 12;
+    double X[SCORE_PPT], Y[SCORE_PPT], Z[SCORE_PPT], u[SCORE_PPT], v[SCORE_PPT];
+    bool live[SCORE_PPT];
+#pragma unroll
+    for (int q = 0; q < SCORE_PPT; ++q) {
+        const int i = first + q * 64 + lane;
+        live[q] = i < m;
+        const size_t ii = static_cast<size_t>(live[q] ? i : 0);
+        X[q] = c3[3 * ii];
+        Y[q] = c3[3 * ii + 1];
+        Z[q] = c3[3 * ii + 2];
+        u[q] = c2[2 * ii];
+        v[q] = c2[2 * ii + 1];
+    }
+    const double* __restrict__ src = w.pRt + static_cast<size_t>(p) * prm.pnp_iterations * 12;
     int* counts = w.pcounts + static_cast<size_t>(p) * prm.pnp_iterations;
-    for (int h0 = 0; h0 < prm.pnp_iterations; h0 += SCORE_TILE) {
-        const int nh = min(SCORE_TILE, prm.pnp_iterations - h0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < nh * 12; e += 256) {
-            Rt[e] = src[static_cast<size_t>(h0) * 12 + e];
+    const double thr = prm.pnp_threshold, thr2 = prm.pnp_threshold * prm.pnp_threshold;
+    double nxt[12];
+    {
+        const uniform_doubles e = as_uniform(src);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            nxt[j] = e[j];
         }
-        if (threadIdx.x < SCORE_TILE) {
-            cnt[threadIdx.x] = 0;
-        }
-        __syncthreads();
+    }
+    const int H = prm.pnp_iterations;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int nh = min(64, H - h0);
         int mine = 0;
         for (int k = 0; k < nh; ++k) {
-            const bool in = live && pnp_inlier(Rt + k * 12, prm.K, X, Y, Z, u, v, prm.pnp_threshold);
-            const int c = __builtin_popcountll(__ballot(in));
+            double cur[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                cur[j] = nxt[j];
+            }
+            const uniform_doubles e = as_uniform(src + static_cast<size_t>(min(h0 + k + 1, H - 1)) * 12);  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                nxt[j] = e[j];
+            }
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < SCORE_PPT; ++q) {
+                const bool in = live[q] & pnp_inlier_quick(cur, prm.K, X[q], Y[q], Z[q], u[q], v[q], thr, thr2);
+                c += __builtin_popcountll(__ballot(in));
+            }
             mine += lane == k ? c : 0;
         }
         if (lane < nh && mine != 0) {
-            atomicAdd(&cnt[lane], mine);
-        }
-        __syncthreads();
-        if (static_cast<int>(threadIdx.x) < nh && cnt[threadIdx.x] != 0) {
-            atomicAdd(&counts[h0 + threadIdx.x], cnt[threadIdx.x]);
+            atomicAdd(&counts[h0 + lane], mine);
         }
     }
 }
@@ -1559,7 +1842,7 @@ void launch_essential_hypotheses(const PoseWork& w, const PoseParams& prm, int n
 }
 
 void launch_sampson_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
-    hipLaunchKernelGGL(sampson_score_kernel, dim3(pose_blocks(prm.cap, 256 * SCORE_PPT), npairs), dim3(256), 0, stream, w, prm);
+    hipLaunchKernelGGL(sampson_score_kernel, dim3(pose_blocks(prm.cap, 64 * SCORE_PPT), npairs), dim3(64), 0, stream, w, prm);
 }
 
 void launch_pose_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
@@ -1591,15 +1874,13 @@ void launch_pnp_gather(const PoseSource& src, const PoseWork& w, const PoseParam
 }
 
 void launch_pnp_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
-    const size_t lds = PNP_WAVES * sizeof(PnpWork6);
-    static const bool once = (allow_lds(pnp_hyp_kernel, lds), true);
+    static const bool once = (allow_lds(pnp_hyp_kernel, PNP_HYP_LDS), true);
     (void)once;
-    hipLaunchKernelGGL(pnp_hyp_kernel, dim3((prm.pnp_iterations + PNP_WAVES - 1) / PNP_WAVES, npairs), dim3(64 * PNP_WAVES), lds,
-                       stream, w, prm);
+    hipLaunchKernelGGL(pnp_hyp_kernel, dim3((prm.pnp_iterations + 63) / 64, npairs), dim3(64), PNP_HYP_LDS, stream, w, prm);
 }
 
 void launch_pnp_score(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
-    hipLaunchKernelGGL(pnp_score_kernel, dim3(pose_blocks(prm.cap, 256), npairs), dim3(256), 0, stream, w, prm);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(pose_blocks(prm.cap, 64 * SCORE_PPT), npairs), dim3(64), 0, stream, w, prm);
 }
 
 void launch_pnp_select(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {

@@ -116,6 +116,7 @@ int pose_workspace(slamx_pose* p, int slots, int cap, bool with_x4) {
     SLAMX_TRY(pose_alloc(p, &w.c2, P * C * 2));
     SLAMX_TRY(pose_alloc(p, &w.pidx, P * Hp * 6));
     SLAMX_TRY(pose_alloc(p, &w.pRt, P * Hp * 12));
+    SLAMX_TRY(pose_alloc(p, &w.pnull, P * Hp * 12));
     SLAMX_TRY(pose_alloc(p, &w.pcounts, P * Hp));
     p->slots = slots;
     hipStream_t s = p->ctx->stream;

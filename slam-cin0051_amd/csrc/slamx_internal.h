@@ -341,6 +341,7 @@ struct PoseWork {
     double* c2;          // [P][cap][2]
     int* pidx;           // [P][Hp][6]
     double* pRt;         // [P][Hp][12] R row-major, t
+    double* pnull;       // [P][Hp][12] the DLT null vector of every hypothesis (before the column-major re-map) or nullptr
     int* pcounts;        // [P][Hp]
 };
 struct PoseSource {  // where the keypoints and matches of the batch are
