@@ -377,6 +377,9 @@ int slamx_pose_download_samples(slamx_pose* p, int frame, int32_t* idx, int32_t*
 /* Intermediate products of step 1 for the parity tests: the essential matrix of every hypothesis of one frame
  * (E_all [iterations][9]) and its Sampson inlier count (counts [iterations]); either may be NULL. */
 int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int32_t* counts);
+/* ... and of step 3: pose (Rt_all [pnp_iterations][12]: R row-major, then t), DLT null vector before the column-major
+ * re-map (null_all [pnp_iterations][12]) and inlier count of every PnP hypothesis of one frame; any may be NULL. */
+int slamx_pose_download_pnp_hypotheses(slamx_pose* p, int frame, double* Rt_all, double* null_all, int32_t* counts);
 /* The 3D-2D correspondences step 3 formed for one frame (for tests): p3d n x 3, p2d n x 2 doubles. */
 int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, double* p2d, int cap, int* n);
 /* Per-kernel device time of the stage (hipEvents on the context stream around every launch of the calls since

@@ -115,7 +115,7 @@ EXPORTS = [
     "slamx_batch_download_packed_tail", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_essential_from_samples", "slamx_pnp_from_samples", "slamx_pose_create", "slamx_pose_destroy", "slamx_batch_pose",
-    "slamx_pose_download", "slamx_pose_download_points", "slamx_pose_download_samples", "slamx_pose_download_correspondences", "slamx_pose_download_hypotheses",
+    "slamx_pose_download", "slamx_pose_download_points", "slamx_pose_download_samples", "slamx_pose_download_correspondences", "slamx_pose_download_hypotheses", "slamx_pose_download_pnp_hypotheses",
     "slamx_pose_set_profiling", "slamx_pose_stage_ms", "slamx_batch_upload_results",
     "slamx_undistort",
     "slamx_pyramid_create", "slamx_pyramid_destroy", "slamx_pyramid_batch", "slamx_pyramid_level_shape",
@@ -214,6 +214,7 @@ def load_library():
     lib.slamx_pose_download_samples.argtypes = [vp, C.c_int, vp, vp]
     lib.slamx_pose_download_correspondences.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_pose_download_hypotheses.argtypes = [vp, C.c_int, vp, vp]
+    lib.slamx_pose_download_pnp_hypotheses.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.slamx_pose_set_profiling.argtypes = [vp, C.c_int]
     lib.slamx_pose_stage_ms.argtypes = [vp, vp, vp]
     lib.slamx_batch_upload_results.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
@@ -839,6 +840,13 @@ class PoseStage(_Owner):
         c = np.zeros(self.cfg.iterations, np.int32)
         _check(self.lib.slamx_pose_download_hypotheses(self.h, frame, _ptr(E), _ptr(c)))
         return E, c
+
+    def pnp_hypotheses(self, frame):
+        """-> (R [H, 3, 3], t [H, 3], null vector [H, 12], counts [H]) of one frame's PnP hypotheses"""
+        H = self.cfg.pnp_iterations
+        Rt, nv, c = np.empty((H, 12)), np.empty((H, 12)), np.zeros(H, np.int32)
+        _check(self.lib.slamx_pose_download_pnp_hypotheses(self.h, frame, _ptr(Rt), _ptr(nv), _ptr(c)))
+        return Rt[:, :9].reshape(H, 3, 3).copy(), Rt[:, 9:].copy(), nv, c
 
     def correspondences(self, frame):
         n = C.c_int()

@@ -667,6 +667,26 @@ int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int3
     return SLAMX_OK;
 }
 
+int slamx_pose_download_pnp_hypotheses(slamx_pose* p, int frame, double* Rt_all, double* null_all, int32_t* counts) {
+    if (p == nullptr || frame < 0 || frame >= p->slots || p->prm.pnp_iterations <= 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_pnp_hypotheses: arguments invalid (or no PnP step configured)");
+    }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const size_t H = static_cast<size_t>(p->prm.pnp_iterations);
+    if (Rt_all != nullptr) {
+        HIP_TRY(hipMemcpyAsync(Rt_all, p->w.pRt + static_cast<size_t>(frame) * H * 12, H * 96, hipMemcpyDeviceToHost, s));
+    }
+    if (null_all != nullptr) {
+        HIP_TRY(hipMemcpyAsync(null_all, p->w.pnull + static_cast<size_t>(frame) * H * 12, H * 96, hipMemcpyDeviceToHost, s));
+    }
+    if (counts != nullptr) {
+        HIP_TRY(hipMemcpyAsync(counts, p->w.pcounts + static_cast<size_t>(frame) * H, H * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return SLAMX_OK;
+}
+
 int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, double* p2d, int cap, int* n) {
     if (p == nullptr || frame < 0 || frame >= p->slots || n == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_correspondences: arguments invalid");

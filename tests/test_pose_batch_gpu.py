@@ -311,6 +311,52 @@ def test_batch_pose_on_the_c3_workloads_own_match_lists(slamx, gpu_ctx):
             assert len(c3) == r["pnp_correspondences"] > 0.5 * len(m)
 
 
+def test_pnp_hypotheses_of_the_batch_are_solvepnp(slamx, gpu_ctx, oracle):
+    """Every PnP hypothesis of the batched stage (one lane each: Householder QR + inverse iteration) against the same
+    6-point samples through slamx_pnp_dlt_batch (the wave-per-hypothesis Jacobi SVD on the matrix cores, which
+    test_pnp_dlt_matches_oracle pins to the oracle) and numpy's SVD: the DLT null vector up to its sign, and R, t as
+    loop_closure.cpp:260-271 derive them from the null vector WITH THE SIGN THE KERNEL CHOSE; and the per-hypothesis
+    inlier counts against the oracle's count for that pose."""
+    rng = np.random.default_rng(21)
+    F = 3
+    frames = sequence(slamx, rng, F, 400, outliers=0.1)
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 12, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, 512)
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    pose = slamx.PoseStage(batch, K, iterations=128, threshold_px=1.0, seed=4, pnp_iterations=150, pnp_threshold=1.0e4)
+    pose.run(F, -1)
+    res = pose.download(F)
+    c3, c2 = pose.correspondences(2)
+    assert len(c3) > 100
+    _, ptable = pose.samples(2)
+    R, t, nv, counts = pose.pnp_hypotheses(2)
+    ok = np.isfinite(c3[ptable]).all(axis=(1, 2)) & (np.abs(c3[ptable]).max(axis=(1, 2)) < 1e3)  # (wrong matches triangulate anywhere)
+    assert ok.sum() > 100
+    Rb, tb, nb = gpu_ctx.pnp_dlt_batch(c3[ptable][ok], c2[ptable][ok])
+    checked = 0
+    for j, h in enumerate(np.nonzero(ok)[0]):
+        A = np.zeros((12, 12))
+        for i, q in enumerate(ptable[h]):
+            X, Y, Z = c3[q]
+            u, v = c2[q]
+            A[2 * i] = [X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u]
+            A[2 * i + 1] = [0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v]
+        sv = np.linalg.svd(A, compute_uv=False)
+        if sv[-1] > 0.3 * sv[-2]:
+            continue  # the two smallest singular values nearly coincide: no implementation's vector is defined there
+        ref = np.linalg.svd(A)[2][-1]
+        s = np.sign(np.dot(nv[h], ref))
+        assert np.abs(s * nv[h] - ref).max() < 1e-7, h
+        assert np.abs(np.sign(np.dot(nb[j], nv[h])) * nb[j] - nv[h]).max() < 1e-7, h
+        Ro, to = oracle.pnp_from_null_vector(nv[h])
+        assert rel(R[h], Ro) < 1e-7 and rel(t[h], to) < 1e-7, h
+        assert counts[h] == oracle.count_inliers(c3[np.isfinite(c3).all(1)], c2[np.isfinite(c3).all(1)], K, R[h], t[h], 1.0e4)
+        checked += 1
+    assert checked > 80
+    assert res[2]["pnp_inliers"] == counts.max() and counts.max() > 0
+
+
 def test_essential_one_pair_call_allocates_nothing_in_steady_state(slamx, gpu_ctx):
     """the one-pair entry points once paid 8 hipMalloc + 8 hipFree per call.  Repeated calls of the same
     size now reuse the context's workspace: the device pointer a fresh hipMalloc returns before and after is the same
