@@ -722,6 +722,15 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     }
 }
 
+// Which kernel describes a frame is decided per frame, on the device: the shared tiles cost ~5.5 us of latency per
+// region (tile load, list, barriers; 4 workgroups per CU) and 0.22 ns per keypoint, the per-keypoint tiles of
+// describe_fused_kernel 0.36-0.48 ns per keypoint -- the tiles win from ~27 keypoints per region on (measured: 1080p with
+// 2.1k keypoints = 15 per region 0.61 against 0.51 ms per 512 frames; 10.4k keypoints = 77 per region 0.76 against 0.97 ms
+// per 256; 640 x 480 with 1.9k = 79 per region 0.56 against 0.71 ms per 1024).  Both kernels are launched, each leaves the
+// other's frames alone.
+constexpr int RT_MIN_KEYPOINTS_PER_REGION = 28;
+__device__ __forceinline__ bool frame_takes_tiles(int n_kp, int regions) { return n_kp >= RT_MIN_KEYPOINTS_PER_REGION * regions; }
+
 // ---- orientation + BRIEF in ONE pass over the blurred frame (PatchSize <= 31, <= 64 surviving pairs) ----
 // moments_kernel and brief_kernel each read every blurred frame from HBM once (the patches of ~2k
 // keypoints cover a 1080p frame), which is all their time.  Here a wave takes 4 keypoints per round and
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
 #endif
 template <int FUSED_PER_WAVE, int WPB, int OCC>
 __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
-                                                                      int nframes, int blocks_per_frame, int use_visit) {
+                                                                      int nframes, int blocks_per_frame, int use_visit, int tile_regions) {
     __shared__ uint32_t tiles[WPB][FUSED_PER_WAVE][TILE_ROWS * TILE_DW];
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
@@ -748,6 +757,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.n_kp[f];
+    if (tile_regions > 0 && frame_takes_tiles(n, tile_regions)) {
+        return;  // a dense frame: describe_tile_kernel takes it (uniform)
+    }
     const int radius = P.patch / 2;
     const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
@@ -956,6 +968,281 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
     }
 }
 
+// ---- orientation + BRIEF from SHARED image tiles (keypoints in detection order: the visiting list of the NMS) ----
+// describe_fused_kernel gives every keypoint its own 43 x 48-byte tile: three gathered loads and three LDS stores per
+// keypoint, a trig chain on 4 of 64 lanes per group, and ~80 scalar instructions per keypoint of pipelining around
+// it (255 issue slots per keypoint in all, which is its duration).  Here a workgroup owns a REGION of the frame --
+// 240 x 64 pixels -- stages the blurred region with its 21-pixel halo once (288 bytes x 106 rows = 30.5 KB, wide
+// coalesced buffer loads, zero fill above / below the frame) and serves every keypoint whose centre lies in the region
+// from that one tile in three phases separated by workgroup barriers:
+//   A  moments: a wave takes 4 keypoints per step, the 31 x 32-byte patch read straight from the shared tile
+//      (ds_read2 + v_alignbyte + v_dot4 as before; the 8 wave sums reduced together)
+//   B  atan2f -> degrees -> cosf, sinf: ONE KEYPOINT PER LANE over all keypoints of the region
+//   C  BRIEF: a wave per keypoint, lane = pattern pair, byte reads from the tile
+// The keypoints of a region come from region_index_kernel (a counting sort of the frame's keypoints by region, one
+// workgroup per frame).  A tile row is 72 dwords = 8 mod 64 banks: the 8 rows x 8 dwords a wave reads per moment slot
+// cover the 64 banks exactly once.
+constexpr int RT_W = 240;
+constexpr int RT_H = 64;
+constexpr int RT_DW = 72;                       // dwords per tile row (288 bytes: columns x0 - 24 .. x0 + 263)
+constexpr int RT_XOFF = 24;
+constexpr int RT_ROWS = RT_H + 2 * TILE_HALF;   // 106: rows y0 - 21 .. y0 + 84
+constexpr int RT_PIECES = RT_ROWS * (RT_DW / 4);
+constexpr int RT_LIST = 512;                    // keypoints held per pass (a pass starts with fewer than 256)
+
+// Keypoints of a frame binned by region: region_first[f][r] .. region_first[f][r + 1] delimit region r's slots in
+// region_list[f] (any order inside a region: every keypoint writes only its own angle and descriptor row).  One
+// workgroup per frame: histogram in LDS, prefix, scatter.  regions <= RT_MAX_REGIONS (else the caller keeps the
+// per-keypoint tiles).
+constexpr int RT_MAX_REGIONS = 4096;
+__global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int regions_x, int regions) {
+    __shared__ int hist[RT_MAX_REGIONS];
+    __shared__ int wave_tot[16];
+    const int f = blockIdx.x;
+    const int n = v.n_kp[f];
+    if (!frame_takes_tiles(n, regions)) {
+        return;  // describe_fused_kernel takes this frame
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
+    int* first = v.region_first + static_cast<size_t>(f) * (regions + 1);
+    int* list = v.region_list + static_cast<size_t>(f) * v.maxK;
+    for (int r = tid; r < regions; r += 1024) {
+        hist[r] = 0;
+    }
+    __syncthreads();
+    auto region_of = [&](int slot) {
+        const int x = min(max(kp_coord(kps[slot].x), 0), v.cols - 1);
+        const int y = min(max(kp_coord(kps[slot].y), 0), v.rows - 1);
+        return (y >> 6) * regions_x + x / RT_W;
+    };
+    for (int i = tid; i < n; i += 1024) {
+        atomicAdd(&hist[region_of(static_cast<int>(visit[i]))], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the regions (block scan in chunks of 1024), in place: hist[r] becomes the region's cursor
+    int carry = 0;
+    for (int base = 0; base < regions; base += 1024) {
+        const int r = base + tid;
+        const int c = r < regions ? hist[r] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            incl += lane >= d ? o : 0;
+        }
+        if (lane == 63) {
+            wave_tot[wv] = incl;
+        }
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            woff += k < wv ? wave_tot[k] : 0;
+            tot += wave_tot[k];
+        }
+        if (r < regions) {
+            const int excl = carry + woff + incl - c;
+            hist[r] = excl;
+            first[r] = excl;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        first[regions] = n;
+    }
+    for (int i = tid; i < n; i += 1024) {
+        const int slot = static_cast<int>(visit[i]);
+        list[atomicAdd(&hist[region_of(slot)], 1)] = slot;
+    }
+}
+
+__global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
+                                                            int nframes, int regions_x, int regions_per_frame) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[RT_ROWS * RT_DW];
+    __shared__ int l_slot[RT_LIST];
+    __shared__ uint32_t l_xy[RT_LIST];   // (y - y0 + 21) << 16 | (x - x0 + 24): tile coordinates of the centre
+    __shared__ int l_a[RT_LIST];         // m01, then cos bits
+    __shared__ int l_b[RT_LIST];         // m10 (0x7fffffff = patch leaves the image), then sin bits
+    int f, r;
+    if (!frame_block(nframes, regions_per_frame, &f, &r)) {
+        return;
+    }
+    const int by = r / regions_x;
+    const int bx = r - by * regions_x;
+    const int x0 = bx * RT_W, y0 = by * RT_H;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (!frame_takes_tiles(v.n_kp[f], regions_per_frame)) {
+        return;  // describe_fused_kernel takes this frame (uniform)
+    }
+    const int* first = v.region_first + static_cast<size_t>(f) * (regions_per_frame + 1);
+    const int lo = first[r], hi = first[r + 1];
+    if (lo >= hi) {
+        return;  // no keypoint in the region (uniform)
+    }
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
+    const int* list = v.region_list + static_cast<size_t>(f) * v.maxK;
+    const int radius = P.patch / 2;
+    const int words = v.width / 8;
+    // per-lane constants of the phases
+    constexpr int SLOTS = MOMENT_ALIGNED_SLOTS;
+    int mom_idx[SLOTS], vrow[SLOTS];
+    uint2 wal[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int e = lane + 64 * k;
+        const int ee = e < MOM_ROWS * 8 ? e : 0;  // surplus slots carry zero weights
+        const int rr = ee / 8;
+        mom_idx[k] = rr * RT_DW + (ee - rr * 8);
+        vrow[k] = rr - MOM_HALF;
+        wal[k] = P.moment_weights[4 * 5 * 64 + k * 64 + lane];
+    }
+    float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f;
+    if (lane < P.pattern_len) {
+        q1x = static_cast<float>(pattern[4 * lane + 0]);
+        q1y = static_cast<float>(pattern[4 * lane + 1]);
+        q2x = static_cast<float>(pattern[4 * lane + 2]);
+        q2y = static_cast<float>(pattern[4 * lane + 3]);
+    }
+    const unsigned long long all_pairs = low_mask_d(P.pattern_len);
+    bool tile_loaded = false;
+    for (int base = lo; base < hi; base += RT_LIST) {  // uniform; one pass unless a region holds more than RT_LIST keypoints
+        const int nl = min(RT_LIST, hi - base);
+        for (int k = tid; k < nl; k += 256) {
+            const int slot = list[base + k];
+            const int kx = min(max(kp_coord(kps[slot].x), 0), v.cols - 1), ky = min(max(kp_coord(kps[slot].y), 0), v.rows - 1);
+            l_slot[k] = slot;
+            l_xy[k] = static_cast<uint32_t>(ky - y0 + TILE_HALF) << 16 | static_cast<uint32_t>(kx - x0 + RT_XOFF);
+        }
+        // ---- the tile, once
+        if (!tile_loaded) {
+            tile_loaded = true;
+            const __amdgpu_buffer_rsrc_t frame_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
+            const int soff = (y0 - TILE_HALF) * v.pitch + (x0 - RT_XOFF);  // may be negative: such rows read as zero
+#pragma unroll
+            for (int k = 0; k < (RT_PIECES + 255) / 256; ++k) {
+                const int p = tid + 256 * k;
+                if (p < RT_PIECES) {
+                    const int rr = p / (RT_DW / 4);
+                    const int cc = p - rr * (RT_DW / 4);
+                    // rows above / below the frame: an offset beyond the buffer (zero fill by the range check)
+                    const int yy = y0 - TILE_HALF + rr;
+                    const int voff = (yy >= 0 && yy < v.rows) ? rr * v.pitch + cc * 16 + soff : 0x7ffffff0;
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, voff, 0, 0);
+                    *reinterpret_cast<uint4*>(&tile[rr * RT_DW + cc * 4]) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase A: moments, a wave takes 4 keypoints per step
+        for (int g = wave; g * 4 < nl; g += 4) {  // wave-uniform
+            int part[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                part[q] = 0;
+                part[4 + q] = 0;
+                const int k = g * 4 + q;
+                if (k < nl) {  // wave-uniform
+                    const uint32_t xy = l_xy[k];
+                    const int tx = static_cast<int>(xy & 0xffffu), ty = static_cast<int>(xy >> 16);
+                    const int po = tx - MOM_HALF;  // first patch column inside the tile row
+                    const uint32_t* t = tile + (ty - MOM_HALF) * RT_DW + (po >> 2);
+                    const uint32_t sh = static_cast<uint32_t>(po & 3);
+                    uint32_t su = 0, srow = 0;
+                    int sv = 0;
+#pragma unroll
+                    for (int kk = 0; kk < SLOTS; ++kk) {
+                        const uint32_t lo32 = t[mom_idx[kk]], hi32 = t[mom_idx[kk] + 1];
+                        const uint32_t cur = __builtin_amdgcn_alignbyte(hi32, lo32, sh);
+                        su = __builtin_amdgcn_udot4(cur, wal[kk].x, su, false);
+                        const uint32_t row = __builtin_amdgcn_udot4(cur, wal[kk].y, 0u, false);
+                        srow += row;
+                        sv += vrow[kk] * static_cast<int>(row);
+                    }
+                    part[q] = static_cast<int>(su) - MOM_HALF * static_cast<int>(srow);
+                    part[4 + q] = sv;
+                }
+            }
+            wave_sums_dpp<8>(part);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m10 = __builtin_amdgcn_readlane(part[q], 63);
+                const int m01 = __builtin_amdgcn_readlane(part[4 + q], 63);
+                const int k = g * 4 + q;
+                if (lane == q && k < nl) {
+                    const uint32_t xy = l_xy[k];
+                    const int x = static_cast<int>(xy & 0xffffu) - RT_XOFF + x0, y = static_cast<int>(xy >> 16) - TILE_HALF + y0;
+                    const bool inside = !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
+                    l_a[k] = m01;
+                    l_b[k] = inside ? m10 : 0x7fffffff;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase B: angle, cos, sin -- one keypoint per lane
+        for (int k = tid; k < nl; k += 256) {
+            const int m01 = l_a[k], m10 = l_b[k];
+            float angle = 0.0f, c = __uint_as_float(0x7fc00000u), sn = 0.0f;  // NaN cos marks "outside"
+            if (m10 != 0x7fffffff) {
+                angle = __fmul_rn(glibc_atan2f(static_cast<float>(m01), static_cast<float>(m10)), rad_to_deg());
+                const float ar = __fmul_rn(angle, deg_to_rad());
+                glibc_sincosf(ar, &sn, &c);
+            }
+            kps[l_slot[k]].angle = angle;  // feature_detector.cpp:37-38
+            l_a[k] = __float_as_int(c);
+            l_b[k] = __float_as_int(sn);
+        }
+        __syncthreads();
+        // ---- phase C: BRIEF, a wave per keypoint, lane = pattern pair
+        const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+        for (int k = wave; k < nl; k += 4) {  // wave-uniform
+            const uint32_t xy = l_xy[k];
+            const int tx = static_cast<int>(xy & 0xffffu), ty = static_cast<int>(xy >> 16);
+            const int x = tx - RT_XOFF + x0, y = ty - TILE_HALF + y0;
+            const float ca = __int_as_float(l_a[k]);
+            const float sa = __int_as_float(l_b[k]);
+            unsigned long long packed = 0;
+            if (ca == ca) {  // wave-uniform
+                const int dx1 = static_cast<int>(__fsub_rn(__fmul_rn(q1x, ca), __fmul_rn(q1y, sa)));
+                const int dy1 = static_cast<int>(__fadd_rn(__fmul_rn(q1x, sa), __fmul_rn(q1y, ca)));
+                const int dx2 = static_cast<int>(__fsub_rn(__fmul_rn(q2x, ca), __fmul_rn(q2y, sa)));
+                const int dy2 = static_cast<int>(__fadd_rn(__fmul_rn(q2x, sa), __fmul_rn(q2y, ca)));
+                const uint32_t I1 = t8[(dy1 + ty) * (RT_DW * 4) + tx + dx1];
+                const uint32_t I2 = t8[(dy2 + ty) * (RT_DW * 4) + tx + dx2];
+                const bool valid = static_cast<int>(static_cast<uint32_t>(dx1 + x) < static_cast<uint32_t>(v.cols)) &
+                                   static_cast<int>(static_cast<uint32_t>(dy1 + y) < static_cast<uint32_t>(v.rows)) &
+                                   static_cast<int>(static_cast<uint32_t>(dx2 + x) < static_cast<uint32_t>(v.cols)) &
+                                   static_cast<int>(static_cast<uint32_t>(dy2 + y) < static_cast<uint32_t>(v.rows)) &
+                                   static_cast<int>(lane < P.pattern_len);
+                const bool bit = I1 < I2;
+                const unsigned long long vm = __ballot(valid);
+                const unsigned long long bm = __ballot(valid && bit);
+                packed = bm;  // every pair valid: nothing to close up
+                if (vm != all_pairs) {
+                    const int c2 = __popcll(vm);
+                    bool outbit = false;
+                    if (lane < c2) {
+                        outbit = ((bm >> select64d(vm, lane)) & 1ull) != 0;
+                    }
+                    packed = __ballot(outbit);
+                }
+            }
+            if (lane < words) {  // descriptor rows are 8-byte aligned (width % 8 == 0)
+                uint8_t* desc = v.desc + (static_cast<size_t>(f) * v.maxK + l_slot[k]) * v.width;
+                reinterpret_cast<unsigned long long*>(desc)[lane] = lane == 0 ? packed : 0ull;
+            }
+        }
+        __syncthreads();  // the lists are refilled by the next pass
+    }
+}
+
 }  // namespace
 
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
@@ -975,15 +1262,28 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
     // SLAMX_NO_FUSED_DESCRIBE=1 keeps the three-kernel path (used by the tests to cover it)
     static const bool fused_allowed = getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr;
+    // SLAMX_DESCRIBE_TILES=0: per-keypoint tiles for every frame (describe_fused_kernel only)
+    static const bool tiles_allowed = getenv("SLAMX_DESCRIBE_TILES") == nullptr || atoi(getenv("SLAMX_DESCRIBE_TILES")) != 0;
     if (fused_allowed && radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 &&
         v.width % 8 == 0) {
+        // keypoints in detection order: dense frames from shared region tiles, the others from per-keypoint tiles -- each
+        // kernel checks the frame's keypoint count and leaves the other's frames alone (frame_takes_tiles)
+        int tile_regions = 0;
+        const int regions_x = (v.cols + RT_W - 1) / RT_W;
+        if (tiles_allowed && use_visit && v.region_first != nullptr && regions_x * v.nbands <= RT_MAX_REGIONS &&
+            v.maxK >= RT_MIN_KEYPOINTS_PER_REGION * regions_x * v.nbands) {
+            tile_regions = regions_x * v.nbands;
+            hipLaunchKernelGGL(region_index_kernel, dim3(nframes), dim3(1024), 0, stream, v, regions_x, tile_regions);
+            hipLaunchKernelGGL(describe_tile_kernel, dim3(frame_grid(nframes, tile_regions)), dim3(256), 0, stream, v, p, pattern_dev,
+                               nframes, regions_x, tile_regions);
+        }
         const int waves_per_frame = static_cast<int>(grid.x) * 4;
         // Measured alternatives (more waves per SIMD by capping the registers at 96 / 80 / 64 with 4, 3 or 2
         // tiles per wave and 1-, 2- or 4-wave workgroups) all spill and ran 25 % to 2.4x slower.
         const int wpb = 4;
         const int bpf = (waves_per_frame + wpb - 1) / wpb;
         hipLaunchKernelGGL((describe_fused_kernel<4, 4, 4>), dim3(frame_grid(nframes, bpf)), dim3(64 * wpb), 0, stream, v, p,
-                           pattern_dev, nframes, bpf, use_visit ? 1 : 0);
+                           pattern_dev, nframes, bpf, use_visit ? 1 : 0, tile_regions);
         if (ev_after_moments != nullptr) {
             (void)hipEventRecord(ev_after_moments, stream);
         }

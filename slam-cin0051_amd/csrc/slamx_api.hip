@@ -661,6 +661,14 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     A(&v.n_kp, F);
     A(&v.desc, F * v.maxK * v.width);
     A(&v.visit, F * v.maxK);
+    v.nbands = (v.rows + 63) / 64;
+    {
+        const size_t regions = static_cast<size_t>((v.cols + 239) / 240) * v.nbands;
+        if (regions <= 4096) {  // (describe.hip: RT_MAX_REGIONS; larger frames keep the per-keypoint tiles)
+            A(&v.region_first, F * (regions + 1));
+            A(&v.region_list, F * v.maxK);
+        }
+    }
     A(&v.moments, F * v.maxK);
     A(&v.cos_sin, F * v.maxK);
     A(&v.status, F);
@@ -719,6 +727,8 @@ void slamx_batch_destroy(slamx_batch* b) {
     dev_free(v.n_kp);
     dev_free(v.desc);
     dev_free(v.visit);
+    dev_free(v.region_first);
+    dev_free(v.region_list);
     dev_free(v.moments);
     dev_free(v.cos_sin);
     dev_free(v.status);
