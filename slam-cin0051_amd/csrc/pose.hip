@@ -237,6 +237,131 @@ __device__ void triangulate_dlt(const double* P1, const double* P2, float x1, fl
     smallest_right_singular_vector<4, 4>(A, X);
 }
 
+// ---- the cheirality vote's two signs without an SVD, where that is safe ----
+// simpleRecoverPose consumes only sign(z1) and sign(z2) of the triangulated point, X = smallest right singular vector of
+// the 4 x 4 DLT matrix A.  Screen: the smallest eigenpair of G = A^T A from its characteristic polynomial (Newton from 0
+// converges monotonically to the smallest root of a polynomial whose roots are all real and non-negative) and the adjugate
+// of G - lambda I -- ~650 instructions instead of the ~4000 of the Jacobi iteration -- and accept its signs only when a
+// residual bound certifies the direction of X to 5e-5 and X2, X3 and the second depth are farther than 1e-3 |X| from zero;
+// every other correspondence goes through the Jacobi iteration.  Returns 1 / 0 for "in front of both" / not, -1 for
+// "not decided".
+__device__ __forceinline__ int cheirality_screen(const double* A, const double* row2 /* third row of K [R|t] */) {
+    double g[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = i; j < 4; ++j) {
+            const double v = __builtin_fma(A[i], A[j], __builtin_fma(A[4 + i], A[4 + j], __builtin_fma(A[8 + i], A[8 + j], A[12 + i] * A[12 + j])));
+            g[i][j] = v;
+            g[j][i] = v;
+        }
+    }
+    // 2 x 2 minors of rows (0, 1) and (2, 3); det, and with the diagonal shifted the adjugate
+    auto minors = [&](double d0, double d1, double d2, double d3, double* sm, double* tm) {
+        sm[0] = d0 * d1 - g[0][1] * g[1][0];
+        sm[1] = d0 * g[1][2] - g[0][2] * g[1][0];
+        sm[2] = d0 * g[1][3] - g[0][3] * g[1][0];
+        sm[3] = g[0][1] * g[1][2] - g[0][2] * d1;
+        sm[4] = g[0][1] * g[1][3] - g[0][3] * d1;
+        sm[5] = g[0][2] * g[1][3] - g[0][3] * g[1][2];
+        tm[5] = d2 * d3 - g[2][3] * g[3][2];
+        tm[4] = g[2][1] * d3 - g[2][3] * g[3][1];
+        tm[3] = g[2][1] * g[3][2] - d2 * g[3][1];
+        tm[2] = g[2][0] * d3 - g[2][3] * g[3][0];
+        tm[1] = g[2][0] * g[3][2] - d2 * g[3][0];
+        tm[0] = g[2][0] * g[3][1] - g[2][1] * g[3][0];
+    };
+    double sm[6], tm[6];
+    minors(g[0][0], g[1][1], g[2][2], g[3][3], sm, tm);
+    const double c0 = sm[0] * tm[5] - sm[1] * tm[4] + sm[2] * tm[3] + sm[3] * tm[2] - sm[4] * tm[1] + sm[5] * tm[0];
+    const double c3 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
+    const double c2 = sm[0] + (g[0][0] * g[2][2] - g[0][2] * g[0][2]) + (g[0][0] * g[3][3] - g[0][3] * g[0][3]) +
+                      (g[1][1] * g[2][2] - g[1][2] * g[1][2]) + (g[1][1] * g[3][3] - g[1][3] * g[1][3]) + tm[5];
+    // principal 3 x 3 minors (without index k) = the diagonal of the adjugate
+    const double m3 = g[2][2] * sm[0] - g[1][2] * sm[1] + g[0][2] * sm[3];   // rows / cols 0 1 2
+    const double m2 = g[3][3] * sm[0] - g[1][3] * sm[2] + g[0][3] * sm[4];   // 0 1 3
+    const double m1 = g[0][0] * tm[5] - g[0][2] * tm[2] + g[0][3] * tm[1];   // 0 2 3
+    const double m0 = g[1][1] * tm[5] - g[1][2] * tm[4] + g[1][3] * tm[3];   // 1 2 3
+    const double c1 = m0 + m1 + m2 + m3;
+    if (!(c1 > 0.0) || !(c3 > 0.0) || !(c0 == c0)) {
+        return -1;
+    }
+    // smallest root of l^4 - c3 l^3 + c2 l^2 - c1 l + c0
+    double lam = 0.0;
+    bool conv = false;
+    const double eps = 1e-15 * c3;
+    for (int it = 0; it < 48; ++it) {
+        const double pv = (((lam - c3) * lam + c2) * lam - c1) * lam + c0;
+        const double dv = ((4.0 * lam - 3.0 * c3) * lam + 2.0 * c2) * lam - c1;
+        if (!(dv < 0.0)) {
+            break;  // past the first turning point: not the regime this screen is for
+        }
+        const double step = pv * rcp_fast(dv);
+        lam -= step;
+        if (fabs(step) <= eps) {
+            conv = true;
+            break;
+        }
+    }
+    if (!conv || !(lam >= -eps)) {
+        return -1;
+    }
+    minors(g[0][0] - lam, g[1][1] - lam, g[2][2] - lam, g[3][3] - lam, sm, tm);
+    const double d0 = g[0][0] - lam, d1 = g[1][1] - lam, d2 = g[2][2] - lam, d3 = g[3][3] - lam;
+    // diagonal of adj(G - lambda I): the column of the largest one is the best-conditioned null vector
+    const double a00 = d1 * tm[5] - g[1][2] * tm[4] + g[1][3] * tm[3];
+    const double a11 = d0 * tm[5] - g[0][2] * tm[2] + g[0][3] * tm[1];
+    const double a22 = d3 * sm[0] - g[1][3] * sm[2] + g[0][3] * sm[4];
+    const double a33 = d2 * sm[0] - g[1][2] * sm[1] + g[0][2] * sm[3];
+    const double amax = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fabs(a33)));
+    if (!(amax > 1e-6 * c1)) {
+        return -1;  // the two smallest eigenvalues (nearly) coincide: no well-defined vector from the adjugate
+    }
+    double X[4];
+    if (fabs(a00) == amax) {  // column 0 of the adjugate (cofactors of row 0, symmetric)
+        X[0] = a00;
+        X[1] = -g[1][0] * tm[5] + g[1][2] * tm[2] - g[1][3] * tm[1];
+        X[2] = g[1][0] * tm[4] - d1 * tm[2] + g[1][3] * tm[0];
+        X[3] = -g[1][0] * tm[3] + d1 * tm[1] - g[1][2] * tm[0];
+    } else if (fabs(a11) == amax) {
+        X[0] = -g[0][1] * tm[5] + g[0][2] * tm[4] - g[0][3] * tm[3];
+        X[1] = a11;
+        X[2] = -d0 * tm[4] + g[0][1] * tm[2] - g[0][3] * tm[0];
+        X[3] = d0 * tm[3] - g[0][1] * tm[1] + g[0][2] * tm[0];
+    } else if (fabs(a22) == amax) {
+        X[0] = g[3][1] * sm[5] - g[3][2] * sm[4] + d3 * sm[3];
+        X[1] = -g[3][0] * sm[5] + g[3][2] * sm[2] - d3 * sm[1];
+        X[2] = a22;
+        X[3] = -g[3][0] * sm[3] + g[3][1] * sm[1] - g[3][2] * sm[0];
+    } else {
+        X[0] = -g[2][1] * sm[5] + d2 * sm[4] - g[2][3] * sm[3];
+        X[1] = g[2][0] * sm[5] - d2 * sm[2] + g[2][3] * sm[1];
+        X[2] = -g[2][0] * sm[4] + g[2][1] * sm[2] - g[2][3] * sm[0];
+        X[3] = a33;
+    }
+    const double nx = fabs(X[0]) + fabs(X[1]) + fabs(X[2]) + fabs(X[3]);
+    // A-posteriori bound on the direction error of X: |G X - lambda X| / gap, with gap >= amax / c2 (amax <= l1 l2 (l3 - l4),
+    // c2 >= l1 l2).  It covers the rounding of the coefficients (c0 = det G loses digits when l4 << l1) as well as an
+    // unconverged root; beyond 5e-5 the correspondence goes to the Jacobi iteration.
+    double resid = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        resid += fabs(g[k][0] * X[0] + g[k][1] * X[1] + g[k][2] * X[2] + g[k][3] * X[3] - lam * X[k]);
+    }
+    if (!(resid * c2 < 2.5e-5 * amax * nx)) {
+        return -1;
+    }
+    const double z2n = row2[0] * X[0] + row2[1] * X[1] + row2[2] * X[2] + row2[3] * X[3];
+    const double rn = fabs(row2[0]) + fabs(row2[1]) + fabs(row2[2]) + fabs(row2[3]);
+    const double tol = 1e-3 * nx;
+    if (!(fabs(X[2]) > tol) || !(fabs(X[3]) > tol) || !(fabs(z2n) > tol * rn)) {
+        return -1;
+    }
+    const bool front1 = (X[2] > 0.0) == (X[3] > 0.0);
+    const bool front2 = (z2n > 0.0) == (X[3] > 0.0);
+    return front1 && front2 ? 1 : 0;
+}
+
 // ---------------- a11: DLT PnP, one wave per hypothesis ----------------
 constexpr int PNP_MAX_ROWS = 64;  // 2n <= 64
 constexpr int LD = 16;            // all LDS matrices are padded to 16 columns
@@ -305,14 +430,18 @@ __device__ void jacobi_sym(double* G, double* Vp, int n, int lane) {
                 const double app = G[p * LD + p];
                 const double aqq = G[q * LD + q];
                 const double apq = G[p * LD + q];
-                const double scale = sqrt(fmax(fabs(app * aqq), 1e-300));
-                if (apq == 0.0 || fabs(apq) <= 1e-17 * scale) {
+                // (angles from hardware reciprocals + Newton steps: the iteration corrects itself, see rcp_fast)
+                const double pq2 = fabs(app * aqq);
+                if (apq == 0.0 || apq * apq <= 1e-34 * pq2) {
                     continue;  // wave-uniform
                 }
-                off = fmax(off, fabs(apq) / scale);
-                const double zeta = (aqq - app) / (2.0 * apq);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t);
+                off = fmax(off, fabs(apq) * rsq_fast(fmax(pq2, 1e-300)));
+                const double zeta = (aqq - app) * rcp_fast(2.0 * apq);
+                const double az = fabs(zeta);
+                const double q1 = 1.0 + az * az;
+                const double den = az > 1e150 ? 2.0 * az : az + q1 * rsq_fast(q1);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) * rcp_fast(den);
+                const double c = rsq_fast(1.0 + t * t);
                 const double s = c * t;
                 double gkp = 0.0, gkq = 0.0, vkp = 0.0, vkq = 0.0;
                 if (lane < n) {
@@ -999,23 +1128,40 @@ __global__ __launch_bounds__(256) void pose_select_kernel(PoseWork w, PoseParams
 // The same conditioned 8-point equations over all inliers: the 9 x 9 normal matrix is accumulated on the FP64 matrix
 // cores in chunks of 64 rows (A^T A: the dense contraction of this step), smallest eigenvector by cyclic Jacobi,
 // projection onto the essential manifold.
-__global__ __launch_bounds__(64) void essential_refit_kernel(PoseWork w, PoseParams prm) {
-    extern __shared__ double pose_lds[];
-    __shared__ double red[64][6];
+// deterministic sum of a double over the workgroup's 256 threads: xor butterfly inside each wave (every lane ends with the
+// same value), the four wave sums added in wave order by everyone
+__device__ __forceinline__ double block_sum4(double v, double* wave_part /* [4] in LDS */, int wave) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += __shfl_xor(v, d);
+    }
+    __syncthreads();  // wave_part may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) {
+        wave_part[wave] = v;
+    }
+    __syncthreads();
+    return ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+}
+
+__global__ __launch_bounds__(256) void essential_refit_kernel(PoseWork w, PoseParams prm) {
+    extern __shared__ double pose_lds[];  // [4][64 x 16] chunk rows of the four waves, then [4][16 x 16] their Gram tiles
+    __shared__ double wave_part[4];
+    __shared__ double G[LD * LD], Vp[LD * LD];
     const int p = blockIdx.x;
     const int n = w.n[p];
     if (n < 8) {
         return;
     }
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double* x1 = reinterpret_cast<const double*>(w.x1 + static_cast<size_t>(p) * prm.cap);
     const double* x2 = reinterpret_cast<const double*>(w.x2 + static_cast<size_t>(p) * prm.cap);
     const uint8_t* flags = w.flags_a + static_cast<size_t>(p) * prm.cap;
     double* E_out = w.Efit + static_cast<size_t>(p) * 9;
-    PnpWork& wk = *reinterpret_cast<PnpWork*>(pose_lds);  // A: the 64 rows of a chunk
     // conditioning over the inliers: centroids, then mean distances
-    double acc[6] = {0, 0, 0, 0, 0, 0};  // sum u1, v1, u2, v2, count
-    for (int i = lane; i < n; i += 64) {
+    double acc[5] = {0, 0, 0, 0, 0};  // sum u1, v1, u2, v2, count
+    for (int i = tid; i < n; i += 256) {
         if (flags[i] != 0) {
             acc[0] += x1[2 * i];
             acc[1] += x1[2 * i + 1];
@@ -1024,23 +1170,18 @@ __global__ __launch_bounds__(64) void essential_refit_kernel(PoseWork w, PosePar
             acc[4] += 1.0;
         }
     }
-    for (int k = 0; k < 6; ++k) {
-        red[lane][k] = acc[k];
-    }
-    wave_sync();
-    double tot[6] = {0, 0, 0, 0, 0, 0};
-    for (int l = 0; l < 64; ++l) {  // every lane sums in the same order: identical values everywhere
-        for (int k = 0; k < 5; ++k) {
-            tot[k] += red[l][k];
-        }
+    double tot[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        tot[k] = block_sum4(acc[k], wave_part, wave);
     }
     const double cnt = tot[4];
     if (cnt < 8.0) {
-        return;  // wave-uniform; Efit keeps the minimal-sample model
+        return;  // uniform; Efit keeps the minimal-sample model
     }
     const double c1x = tot[0] / cnt, c1y = tot[1] / cnt, c2x = tot[2] / cnt, c2y = tot[3] / cnt;
     double dd[2] = {0, 0};
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += 256) {
         if (flags[i] != 0) {
             const double ux = x1[2 * i] - c1x, uy = x1[2 * i + 1] - c1y;
             const double vx = x2[2 * i] - c2x, vy = x2[2 * i + 1] - c2y;
@@ -1048,23 +1189,17 @@ __global__ __launch_bounds__(64) void essential_refit_kernel(PoseWork w, PosePar
             dd[1] += sqrt(vx * vx + vy * vy);
         }
     }
-    wave_sync();
-    red[lane][0] = dd[0];
-    red[lane][1] = dd[1];
-    wave_sync();
-    double d1 = 0, d2 = 0;
-    for (int l = 0; l < 64; ++l) {
-        d1 += red[l][0];
-        d2 += red[l][1];
-    }
+    const double d1 = block_sum4(dd[0], wave_part, wave);
+    const double d2 = block_sum4(dd[1], wave_part, wave);
     const double s1 = d1 > 0.0 ? sqrt(2.0) * cnt / d1 : 1.0;
     const double s2 = d2 > 0.0 ? sqrt(2.0) * cnt / d2 : 1.0;
-    // normal matrix: 64 correspondences per pass (outliers contribute zero rows), lane = row, one accumulator tile for
-    // the whole pair (the MFMA adds in k order: the same sum whichever way the chunks are cut)
+    // normal matrix: wave k takes the chunks k, k + 4, ... of 64 correspondences (outliers contribute zero rows), lane =
+    // row, one accumulator tile per wave over all its chunks; the four tiles are added in wave order afterwards
+    double* rows = pose_lds + static_cast<size_t>(wave) * 64 * LD;
     d4 gacc = {0.0, 0.0, 0.0, 0.0};
     const int col = lane & 15;
     const int kk = lane >> 4;
-    for (int base = 0; base < n; base += 64) {
+    for (int base = wave * 64; base < n; base += 256) {
         const int i = base + lane;
         const bool in = i < n && flags[i] != 0;
         const double p1[3] = {in ? (x1[2 * i] - c1x) * s1 : 0.0, in ? (x1[2 * i + 1] - c1y) * s1 : 0.0, in ? 1.0 : 0.0};
@@ -1072,35 +1207,41 @@ __global__ __launch_bounds__(64) void essential_refit_kernel(PoseWork w, PosePar
         wave_sync();  // the previous chunk's rows have been read
 #pragma unroll
         for (int c = 0; c < LD; ++c) {
-            wk.A[lane * LD + c] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
+            rows[lane * LD + c] = c < 9 ? p2[c / 3] * p1[c % 3] : 0.0;
         }
         wave_sync();
 #pragma unroll
         for (int k0 = 0; k0 < 64; k0 += 4) {
-            const double a = wk.A[(k0 + kk) * LD + col];
+            const double a = rows[(k0 + kk) * LD + col];
             gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, gacc, 0, 0, 0);
         }
     }
+    double* tiles = pose_lds + 4 * 64 * LD;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        wk.G[(kk + 4 * r) * LD + col] = gacc[r];  // C/D: col = lane & 15, row = (lane >> 4) + 4 * reg
+        tiles[wave * LD * LD + (kk + 4 * r) * LD + col] = gacc[r];  // C/D: col = lane & 15, row = (lane >> 4) + 4 * reg
+    }
+    __syncthreads();
+    if (wave != 0) {
+        return;
     }
     for (int e = lane; e < LD * LD; e += 64) {
-        wk.Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
+        G[e] = ((tiles[e] + tiles[LD * LD + e]) + tiles[2 * LD * LD + e]) + tiles[3 * LD * LD + e];
+        Vp[e] = (e / LD == e % LD) ? 1.0 : 0.0;
     }
     wave_sync();
-    jacobi_sym(wk.G, wk.Vp, 9, lane);
+    jacobi_sym(G, Vp, 9, lane);
     wave_sync();
     if (lane == 0) {
         int jmin = 0;
         for (int j = 1; j < 9; ++j) {
-            if (wk.G[j * LD + j] < wk.G[jmin * LD + jmin]) {
+            if (G[j * LD + j] < G[jmin * LD + jmin]) {
                 jmin = j;
             }
         }
         double En[9], Ef[9];
         for (int k = 0; k < 9; ++k) {
-            En[k] = wk.Vp[k * LD + jmin];
+            En[k] = Vp[k * LD + jmin];
         }
         essential_from_null_vector(En, s1, c1x, c1y, s2, c2x, c2y, Ef);
         for (int k = 0; k < 9; ++k) {
@@ -1241,18 +1382,29 @@ __global__ __launch_bounds__(256) void cheirality_pairs_kernel(PoseWork w, PoseP
     int mine = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const double2 a = X1[j], b = X2[j];
-        double X[4];
-        triangulate_dlt(KP0, kp, static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(b.x),
-                        static_cast<float>(b.y), X);
-        const double inv = 1.0 / X[3];
-        for (int k = 0; k < 4; ++k) {
-            X[k] = X[k] * inv;
+        const float fx1 = static_cast<float>(a.x), fy1 = static_cast<float>(a.y), fx2 = static_cast<float>(b.x),
+                    fy2 = static_cast<float>(b.y);
+        double A[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            A[0 * 4 + c] = static_cast<double>(fx1) * KP0[8 + c] - KP0[0 + c];
+            A[1 * 4 + c] = static_cast<double>(fy1) * KP0[8 + c] - KP0[4 + c];
+            A[2 * 4 + c] = static_cast<double>(fx2) * kp[8 + c] - kp[0 + c];
+            A[3 * 4 + c] = static_cast<double>(fy2) * kp[8 + c] - kp[4 + c];
         }
-        const double z1 = X[2];
-        const double z2 = kp[8] * X[0] + kp[9] * X[1] + kp[10] * X[2] + kp[11] * X[3];
-        if (z1 > 0 && z2 > 0) {
-            mine++;
+        int verdict = cheirality_screen(A, kp + 8);
+        if (verdict < 0) {  // (a few correspondences in a thousand: the reference's own sequence)
+            double X[4];
+            smallest_right_singular_vector<4, 4>(A, X);
+            const double inv = 1.0 / X[3];
+            for (int k = 0; k < 4; ++k) {
+                X[k] = X[k] * inv;
+            }
+            const double z1 = X[2];
+            const double z2 = kp[8] * X[0] + kp[9] * X[1] + kp[10] * X[2] + kp[11] * X[3];
+            verdict = (z1 > 0 && z2 > 0) ? 1 : 0;
         }
+        mine += verdict;
     }
     for (int d = 32; d >= 1; d >>= 1) {
         mine += __shfl_xor(mine, d);
@@ -1850,10 +2002,10 @@ void launch_pose_select(const PoseWork& w, const PoseParams& prm, int npairs, hi
 }
 
 void launch_essential_refit_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
-    const size_t lds = sizeof(PnpWork);
+    const size_t lds = (4 * 64 * LD + 4 * LD * LD) * sizeof(double);  // chunk rows + Gram tiles of the four waves
     static const bool once = (allow_lds(essential_refit_kernel, lds), true);
     (void)once;
-    hipLaunchKernelGGL(essential_refit_kernel, dim3(npairs), dim3(64), lds, stream, w, prm);
+    hipLaunchKernelGGL(essential_refit_kernel, dim3(npairs), dim3(256), lds, stream, w, prm);
 }
 
 void launch_pose_final(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {

@@ -8,7 +8,7 @@
 #   6. tools/microbench: sustained FP64 MFMA rate, issue rates of the VALU / LDS instructions the kernels lean on
 # usage: tools/collect_profiles.sh <tag>      (writes under gpurun_out/<tag>/)
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -19,7 +19,10 @@ python bench.py --workload c1 --steps 20 --warmup 3 --no-pcie > "$out/bench_c1.j
 python bench.py --workload c2 --steps 20 --warmup 3 --no-pcie > "$out/bench_c2.json"
 python bench.py --workload c3 --steps 10 --warmup 2 --no-pcie > "$out/bench_c3.json"
 echo "c3 done"
+python bench.py --workload c3 --with-pose --steps 10 --warmup 2 --no-pcie --no-cpu-baseline > "$out/bench_c3_pose.json"
+echo "c3 + pose done"
 python bench.py --workload c3p --steps 5 --warmup 2 > "$out/bench_c3p.json"
+python bench.py --workload c3p --with-pose --steps 5 --warmup 2 --no-pcie --no-cpu-baseline > "$out/bench_c3p_pose.json"
 echo "c3p done"
 python bench.py --workload c4 --steps 20 --warmup 3 > "$out/bench_c4.json"
 echo "c4 done"
@@ -31,6 +34,9 @@ P="--no-cpu-baseline --no-pcie --no-extras"
 rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- python bench.py --steps 10 --warmup 2 $P > "$out/bench_under_rocprof.json"
 rocprofv3 --kernel-trace --stats -d "$out/stats_c3" -o stats --output-format csv -- python bench.py --workload c3 --steps 5 --warmup 2 $P > "$out/bench_c3_under_rocprof.json"
 rocprofv3 --kernel-trace --stats -d "$out/stats_c4" -o stats --output-format csv -- python bench.py --workload c4 --steps 20 --warmup 3 $P > "$out/bench_c4_under_rocprof.json"
+rocprofv3 --kernel-trace --stats -d "$out/stats_c2" -o stats --output-format csv -- python bench.py --workload c2 --steps 10 --warmup 2 $P > "$out/bench_c2_under_rocprof.json"
+rocprofv3 --kernel-trace --stats -d "$out/stats_c3p" -o stats --output-format csv -- python bench.py --workload c3p --steps 4 --warmup 2 $P > "$out/bench_c3p_under_rocprof.json"
+rocprofv3 --kernel-trace --stats -d "$out/stats_c3_pose" -o stats --output-format csv -- python bench.py --workload c3 --with-pose --steps 5 --warmup 2 $P > "$out/bench_c3_pose_under_rocprof.json"
 echo "stats done"
 B="python bench.py --batch 256 --steps 3 --warmup 1 $P"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o fetch --output-format csv -- $B > /dev/null
@@ -44,12 +50,20 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_gn_fetch" -o gnf --output
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_gn_write" -o gnw --output-format csv -- $G > /dev/null
 M="python bench.py --workload c3 --batch 128 --steps 2 --warmup 1 $P"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$out/pmc_match" -o mm --output-format csv -- $M > /dev/null
-echo "pmc mfma done"
-for n in insts busy fetch write gn gn_fetch gn_write match; do
+# the pose stage (c3 --with-pose at 64 frames per launch) and the pyramid (c3p at 64 frames per launch): instruction mix, busy
+# counters and the FP64 matrix-core counters of the refit / slamx_pnp_dlt_batch kernels; HBM traffic of the pyramid
+Q="python bench.py --workload c3 --with-pose --batch 64 --steps 2 --warmup 1 $P"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d "$out/pmc_pose" -o pose --output-format csv -- $Q > /dev/null
+Y="python bench.py --workload c3p --batch 64 --steps 2 --warmup 1 $P"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d "$out/pmc_c3p" -o c3p --output-format csv -- $Y > /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_c3p_fetch" -o c3pf --output-format csv -- $Y > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_c3p_write" -o c3pw --output-format csv -- $Y > /dev/null
+echo "pmc mfma / pose / pyramid done"
+for n in insts busy fetch write gn gn_fetch gn_write match pose c3p c3p_fetch c3p_write; do
     f=$(find "$out/pmc_$n" -name "*counter_collection.csv" | head -1)
     python tools/pmc_summary.py "$f" > "$out/pmc_$n.csv"
 done
-for n in stats stats_c3 stats_c4; do
+for n in stats stats_c3 stats_c4 stats_c2 stats_c3p stats_c3_pose; do
     f=$(find "$out/$n" -name "*kernel_stats.csv" | head -1)
     cp "$f" "$out/${n}_kernel_stats.csv"
 done

@@ -34,6 +34,12 @@ def main():
         "stats_c4_kernel_stats.csv": "bench_c4_kernel_stats.csv", "pmc_insts.csv": "pmc_instruction_mix_b256.csv",
         "pmc_busy.csv": "pmc_busy_b256.csv", "pmc_gn.csv": "pmc_gn_mfma_f64_c4.csv", "pmc_match.csv": "pmc_match_mfma_i8_c3_b128.csv",
         "mfma_f64_peak.txt": "mfma_f64_peak_microbench.txt", "op_rates.txt": "op_rates_microbench.txt",
+        "bench_c3_pose.json": "bench_c3_pose.json", "bench_c3p_pose.json": "bench_c3p_pose.json",
+        "bench_c2_under_rocprof.json": "bench_c2_under_rocprof.json", "bench_c3p_under_rocprof.json": "bench_c3p_under_rocprof.json",
+        "bench_c3_pose_under_rocprof.json": "bench_c3_pose_under_rocprof.json",
+        "stats_c2_kernel_stats.csv": "bench_c2_kernel_stats.csv", "stats_c3p_kernel_stats.csv": "bench_c3p_kernel_stats.csv",
+        "stats_c3_pose_kernel_stats.csv": "bench_c3_pose_kernel_stats.csv",
+        "pmc_pose.csv": "pmc_pose_stage_c3_b64.csv", "pmc_c3p.csv": "pmc_instruction_mix_c3p_b64.csv",
     }
     for a, b in plain.items():
         if os.path.exists(os.path.join(src, a)):
@@ -44,6 +50,9 @@ def main():
                    os.path.join(dst, "%s_pmc_hbm_traffic_b256.csv" % rnd))
     merged_traffic(os.path.join(src, "pmc_gn_fetch.csv"), os.path.join(src, "pmc_gn_write.csv"),
                    os.path.join(dst, "%s_pmc_gn_hbm_traffic_c4.csv" % rnd))
+    if os.path.exists(os.path.join(src, "pmc_c3p_fetch.csv")):
+        merged_traffic(os.path.join(src, "pmc_c3p_fetch.csv"), os.path.join(src, "pmc_c3p_write.csv"),
+                       os.path.join(dst, "%s_pmc_hbm_traffic_c3p_b64.csv" % rnd))
 
 
 if __name__ == "__main__":
