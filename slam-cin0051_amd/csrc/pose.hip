@@ -1029,37 +1029,37 @@ __global__ __launch_bounds__(64) void sampson_score_kernel(PoseWork w, PoseParam
     const double* __restrict__ Eh = w.Eh + static_cast<size_t>(p) * prm.iterations * 9;
     int* counts = w.counts + static_cast<size_t>(p) * prm.iterations;
     const double thr2 = prm.thr2;
-    // the next hypothesis is requested while the current one is evaluated (a scalar load takes ~200 cycles to return)
-    double nxt[9];
-    {
-        const uniform_doubles e = as_uniform(Eh);
+    // Two register sets take turns: while one hypothesis is evaluated the next one's nine doubles are on their way
+    // through the scalar cache (a scalar load takes ~200 cycles to return; a single set would need 18 s_mov per step)
+    const int H = prm.iterations;
+    auto fetch = [&](int h, double* e9) {
+        const uniform_doubles e = as_uniform(Eh + static_cast<size_t>(min(h, H - 1)) * 9);  // wave-uniform address
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            nxt[j] = e[j];
+            e9[j] = e[j];
         }
-    }
-    const int H = prm.iterations;
+    };
+    auto count = [&](const double* e9) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < SCORE_PPT; ++q) {
+            const bool in = live[q] & sampson_inlier(e9, u1[q], v1[q], u2[q], v2[q], thr2);
+            c += __builtin_popcountll(__ballot(in));
+        }
+        return c;
+    };
+    double ea[9], eb[9];
+    fetch(0, ea);
     for (int h0 = 0; h0 < H; h0 += 64) {
         const int nh = min(64, H - h0);
         int mine = 0;
-        for (int k = 0; k < nh; ++k) {
-            double cur[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                cur[j] = nxt[j];
-            }
-            const uniform_doubles e = as_uniform(Eh + static_cast<size_t>(min(h0 + k + 1, H - 1)) * 9);  // wave-uniform
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                nxt[j] = e[j];
-            }
-            int c = 0;
-#pragma unroll
-            for (int q = 0; q < SCORE_PPT; ++q) {
-                const bool in = live[q] & sampson_inlier(cur, u1[q], v1[q], u2[q], v2[q], thr2);
-                c += __builtin_popcountll(__ballot(in));
-            }
-            mine += lane == k ? c : 0;
+        for (int k = 0; k < nh; k += 2) {
+            fetch(h0 + k + 1, eb);
+            const int ca = count(ea);
+            mine += lane == k ? ca : 0;
+            fetch(h0 + k + 2, ea);
+            const int cb = count(eb);
+            mine += ((lane == k + 1) & (k + 1 < nh)) ? cb : 0;
         }
         if (lane < nh && mine != 0) {
             atomicAdd(&counts[h0 + lane], mine);
