@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
 // per 256; 640 x 480 with 1.9k = 79 per region 0.56 against 0.71 ms per 1024).  Both kernels are launched, each leaves the
 // other's frames alone.
 constexpr int RT_MIN_KEYPOINTS_PER_REGION = 28;
-__device__ __forceinline__ bool frame_takes_tiles(int n_kp, int regions) { return n_kp >= RT_MIN_KEYPOINTS_PER_REGION * regions; }
+__device__ __forceinline__ bool frame_takes_tiles(int n_kp, int tile_min) { return n_kp >= tile_min; }
 
 // ---- orientation + BRIEF in ONE pass over the blurred frame (PatchSize <= 31, <= 64 surviving pairs) ----
 // moments_kernel and brief_kernel each read every blurred frame from HBM once (the patches of ~2k
@@ -748,7 +748,7 @@ __device__ __forceinline__ bool frame_takes_tiles(int n_kp, int regions) { retur
 #endif
 template <int FUSED_PER_WAVE, int WPB, int OCC>
 __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
-                                                                      int nframes, int blocks_per_frame, int use_visit, int tile_regions) {
+                                                                      int nframes, int blocks_per_frame, int use_visit, int tile_min) {
     __shared__ uint32_t tiles[WPB][FUSED_PER_WAVE][TILE_ROWS * TILE_DW];
     int f, bx;
     if (!frame_block(nframes, blocks_per_frame, &f, &bx)) {
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void describe_fused_kernel(BatchView
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int n = v.n_kp[f];
-    if (tile_regions > 0 && frame_takes_tiles(n, tile_regions)) {
+    if (frame_takes_tiles(n, tile_min)) {
         return;  // a dense frame: describe_tile_kernel takes it (uniform)
     }
     const int radius = P.patch / 2;
@@ -995,12 +995,12 @@ constexpr int RT_LIST = 512;                    // keypoints held per pass (a pa
 // workgroup per frame: histogram in LDS, prefix, scatter.  regions <= RT_MAX_REGIONS (else the caller keeps the
 // per-keypoint tiles).
 constexpr int RT_MAX_REGIONS = 4096;
-__global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int regions_x, int regions) {
+__global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int regions_x, int regions, int tile_min) {
     __shared__ int hist[RT_MAX_REGIONS];
     __shared__ int wave_tot[16];
     const int f = blockIdx.x;
     const int n = v.n_kp[f];
-    if (!frame_takes_tiles(n, regions)) {
+    if (!frame_takes_tiles(n, tile_min)) {
         return;  // describe_fused_kernel takes this frame
     }
     const int tid = threadIdx.x;
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int reg
 }
 
 __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, DetectorParams P, const int8_t* __restrict__ pattern,
-                                                            int nframes, int regions_x, int regions_per_frame) {
+                                                            int nframes, int regions_x, int regions_per_frame, int tile_min) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[RT_ROWS * RT_DW];
     __shared__ int l_slot[RT_LIST];
     __shared__ uint32_t l_xy[RT_LIST];   // (y - y0 + 21) << 16 | (x - x0 + 24): tile coordinates of the centre
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (!frame_takes_tiles(v.n_kp[f], regions_per_frame)) {
+    if (!frame_takes_tiles(v.n_kp[f], tile_min)) {
         return;  // describe_fused_kernel takes this frame (uniform)
     }
     const int* first = v.region_first + static_cast<size_t>(f) * (regions_per_frame + 1);
@@ -1262,20 +1262,23 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
     dim3 grid(grid_x(v.maxK, 4, nframes), nframes);
     // SLAMX_NO_FUSED_DESCRIBE=1 keeps the three-kernel path (used by the tests to cover it)
     static const bool fused_allowed = getenv("SLAMX_NO_FUSED_DESCRIBE") == nullptr;
-    // SLAMX_DESCRIBE_TILES=0: per-keypoint tiles for every frame (describe_fused_kernel only)
-    static const bool tiles_allowed = getenv("SLAMX_DESCRIBE_TILES") == nullptr || atoi(getenv("SLAMX_DESCRIBE_TILES")) != 0;
+    // SLAMX_DESCRIBE_TILES=0: per-keypoint tiles for every frame (describe_fused_kernel only); =2: shared region tiles for
+    // every frame that has a keypoint (the parity tests run sparse frames through that kernel this way)
+    static const int tiles_mode = getenv("SLAMX_DESCRIBE_TILES") == nullptr ? 1 : atoi(getenv("SLAMX_DESCRIBE_TILES"));
     if (fused_allowed && radius <= 15 && exact_int != 0 && p.moment_weights != nullptr && p.pattern_len <= 64 &&
         v.width % 8 == 0) {
         // keypoints in detection order: dense frames from shared region tiles, the others from per-keypoint tiles -- each
         // kernel checks the frame's keypoint count and leaves the other's frames alone (frame_takes_tiles)
-        int tile_regions = 0;
+        int tile_min = 0x7fffffff;  // keypoints from which a frame takes the shared tiles
         const int regions_x = (v.cols + RT_W - 1) / RT_W;
-        if (tiles_allowed && use_visit && v.region_first != nullptr && regions_x * v.nbands <= RT_MAX_REGIONS &&
-            v.maxK >= RT_MIN_KEYPOINTS_PER_REGION * regions_x * v.nbands) {
-            tile_regions = regions_x * v.nbands;
-            hipLaunchKernelGGL(region_index_kernel, dim3(nframes), dim3(1024), 0, stream, v, regions_x, tile_regions);
+        const int tile_regions = regions_x * v.nbands;
+        const int auto_min = RT_MIN_KEYPOINTS_PER_REGION * tile_regions;
+        if (tiles_mode != 0 && use_visit && v.region_first != nullptr && tile_regions <= RT_MAX_REGIONS &&
+            (tiles_mode == 2 || v.maxK >= auto_min)) {
+            tile_min = tiles_mode == 2 ? 1 : auto_min;
+            hipLaunchKernelGGL(region_index_kernel, dim3(nframes), dim3(1024), 0, stream, v, regions_x, tile_regions, tile_min);
             hipLaunchKernelGGL(describe_tile_kernel, dim3(frame_grid(nframes, tile_regions)), dim3(256), 0, stream, v, p, pattern_dev,
-                               nframes, regions_x, tile_regions);
+                               nframes, regions_x, tile_regions, tile_min);
         }
         const int waves_per_frame = static_cast<int>(grid.x) * 4;
         // Measured alternatives (more waves per SIMD by capping the registers at 96 / 80 / 64 with 4, 3 or 2
@@ -1283,7 +1286,7 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
         const int wpb = 4;
         const int bpf = (waves_per_frame + wpb - 1) / wpb;
         hipLaunchKernelGGL((describe_fused_kernel<4, 4, 4>), dim3(frame_grid(nframes, bpf)), dim3(64 * wpb), 0, stream, v, p,
-                           pattern_dev, nframes, bpf, use_visit ? 1 : 0, tile_regions);
+                           pattern_dev, nframes, bpf, use_visit ? 1 : 0, tile_min);
         if (ev_after_moments != nullptr) {
             (void)hipEventRecord(ev_after_moments, stream);
         }

@@ -48,3 +48,20 @@ def test_single_rank_line_has_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"]
     assert d["n_gpus"] == 1 and d["dtype"] == "u8" and d["vs_baseline"] is None
+
+
+def test_pose_stage_inside_the_timed_step():
+    """--with-pose: BASELINE.json configs[2]'s second half (essential-matrix RANSAC, simpleRecoverPose, triangulatePoints,
+    PnP RANSAC for every frame pair) runs inside the step and is reported per kernel, with its own ceilings."""
+    rc, lines, err = _bench(["--workload", "c2", "--batch", "64", "--steps", "4", "--warmup", "1", "--no-extras",
+                             "--no-cpu-baseline", "--no-pcie", "--with-pose", "--pose-iterations", "64", "--pnp-iterations", "32"])
+    assert rc == 0, err[-2000:]
+    d = lines[-1]
+    p = d["pose"]
+    assert p["hypotheses_per_pair"] == 64 and p["pnp_hypotheses_per_frame"] == 32 and p["pairs_with_a_pose"] == 64
+    assert p["matches_per_pair"] > 300 and p["essential_inliers_per_pair"] > 0.5 * p["matches_per_pair"]
+    assert 0 < p["ms_per_step"] < d["ms_per_step"] and set(p["stage_ms_per_step"]) >= {"hypotheses", "score", "refit", "cheirality", "pnp_solve"}
+    for r in p["rooflines"].values():
+        assert 0 < r["frac"] <= 1.0
+    for r in d["kernel_rooflines"].values():
+        assert 0 < r["frac"] <= 1.0

@@ -21,10 +21,12 @@ def _run(args, env=None):
     return p.stdout.decode()
 
 
-@pytest.mark.parametrize("env", [None, {"SLAMX_NO_FUSED_DESCRIBE": "1"}], ids=["fused-describe", "three-kernel-describe"])
+@pytest.mark.parametrize("env", [None, {"SLAMX_NO_FUSED_DESCRIBE": "1"}, {"SLAMX_DESCRIBE_TILES": "2"}, {"SLAMX_DESCRIBE_TILES": "0"}],
+                         ids=["fused-describe", "three-kernel-describe", "region-tile-describe", "per-keypoint-tiles-only"])
 def test_feature_detector_program(slamx, oracle, ref_data, tmp_path, env):
-    """Both describe paths (the fused orientation + BRIEF kernel and the moments / trig / brief kernels
-    it replaces for the standard pattern) give the oracle's keypoints and descriptors."""
+    """Every describe path (the fused orientation + BRIEF kernel with per-keypoint tiles, the shared region tiles that
+    dense frames take -- forced here for this sparse frame --, and the moments / trig / brief kernels they replace for the
+    standard pattern) gives the oracle's keypoints and descriptors."""
     img_path = os.path.join(ref_data, "images", "0000000000.png")
     out = str(tmp_path / "det.bin")
     text = _run([os.path.join(BIN, "test_feature_detector"), os.path.join(ref_data, "feature_detector.yml"), img_path, out], env)
@@ -268,3 +270,16 @@ def test_mapgather_world_of_one(slamx, gpu_ctx):
     with pytest.raises(slamx.CapacityError):
         g.allgather(big, cap_points=100)
     g.close()
+
+
+def test_facade_latency_program(ref_data):
+    """tools/facade_latency.cpp (what bench.py reports as `facade_latency`): medians of the reference-signature calls."""
+    import json
+
+    imgs = [os.path.join(ref_data, "images", "000000000%d.png" % i) for i in (0, 1)]
+    text = _run([os.path.join(BIN, "facade_latency"), os.path.join(ref_data, "feature_detector.yml"),
+                 os.path.join(ref_data, "feature_matcher.yml")] + imgs + ["5"])
+    d = json.loads(text.strip().splitlines()[-1])
+    assert d["rows"] == 512 and d["cols"] == 1392 and d["keypoints"][0] > 1000 and d["matches"] == 20
+    for k in ("detect", "compute", "detectAndCompute", "match", "match_without_keypoints"):
+        assert 0 < d[k]["min_us"] <= d[k]["median_us"] <= d[k]["max_us"] < 1e6
