@@ -968,17 +968,22 @@ def pose_report(mod, pose, B, args, ms_per_step):
         rl["essential_refit_kernel"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": a / MFMA_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl, "issued_per_launch": issued,
                                         "avg_launch_ms": ms["refit"],
-                                        "note": "one wave per pair: the 9 x 9 normal matrix over all inliers as 16 x 16 x 4 FP64 "
-                                                "MFMAs; latency of one wave per CU, not the matrix cores, bounds it"}
+                                        "note": "one workgroup of four waves per pair: the 9 x 9 normal matrix over all inliers as "
+                                                "16 x 16 x 4 FP64 MFMAs; the latency of its chunk loop and of the 9 x 9 Jacobi "
+                                                "iteration bounds it, not the matrix cores"}
     if ms["pnp_solve"] > 0 and Hp > 0:
         nh = float((res["status"] & mod.POSE_PNP_SKIPPED == 0).sum()) * Hp
-        issued = 36.0 * 2048.0 * nh          # 3 passes x (3 Gram + 4 + 4 update MFMAs) + the final Gram, 16 x 16 x 4 each
-        fl = 4.0 * 576.0 * 6.0 * nh          # 576 n flops per Gram pass of the 2n x 12 DLT system, n = 6
-        a = issued / (ms["pnp_solve"] * 1e-3) / 1e12
-        rl["pnp_hyp_kernel"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": a / MFMA_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl, "issued_per_launch": issued,
-                                "survey_achieved": fl / (ms["pnp_solve"] * 1e-3) / 1e12, "avg_launch_ms": ms["pnp_solve"],
-                                "note": "a wave per hypothesis: the Jacobi rotations between the MFMA passes are the time"}
+        # one lane per hypothesis: Householder QR of the 12 x 12 DLT matrix (4/3 n^3 = 2304 flops) + inverse iteration with
+        # R^T R (2 n^2 = 288 per step, ~4 steps) -- FP64 VECTOR work, no matrix cores (the wave-per-hypothesis MFMA form,
+        # which slamx_pnp_dlt_batch keeps, took 60 x as long); SURVEY 8d's bookkeeping figure is 576 n = 3456 flops per
+        # Gram pass of the 2n x 12 system
+        fl = (2304.0 + 4 * 288.0) * nh
+        a = fl / (ms["pnp_solve"] * 1e-3) / 1e12
+        rl["pnp_hyp_kernel"] = {"bound": "valu-f64 / LDS latency", "achieved": a, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": a / VALU_F64_PEAK_TFLOPS, "algorithmic_per_launch": fl,
+                                "survey_flops_per_launch": 3456.0 * nh, "avg_launch_ms": ms["pnp_solve"],
+                                "note": "a lane per hypothesis, its 12 x 12 matrix in LDS (72 KB per wave: two waves per CU): "
+                                        "400 waves of dependent FP64 chains, bound by their latency"}
     out["rooflines"] = rl
     return out
 
