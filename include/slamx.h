@@ -363,6 +363,7 @@ typedef struct slamx_pose_result {
     int32_t n_matches, n_inliers, front[4], pnp_correspondences, pnp_inliers, status, best_hypothesis;
 } slamx_pose_result;
 typedef struct slamx_pose slamx_pose;
+/* The stage's workspace is sized for the batch's max_frames x max_matches at creation; destroy it BEFORE its batch. */
 int slamx_pose_create(slamx_batch* b, const slamx_pose_config* cfg, slamx_pose** out);
 void slamx_pose_destroy(slamx_pose* p);
 /* Enqueue the stage for frames [0, nframes) on the context stream (async; no allocation, no synchronisation). */
