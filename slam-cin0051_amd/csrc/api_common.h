@@ -80,6 +80,9 @@ struct slamx_ctx {
     // second queue of the context: the blur of a batch beside its sort + NMS (blur_beside_sort), created on first use
     hipStream_t side = nullptr;
     hipEvent_t e_fork = nullptr, e_join = nullptr;
+    // third queue: the uploads of slamx_batch_upload_async (a queue that only ever carries copies), created on first use
+    hipStream_t copy = nullptr;
+    hipEvent_t e_copy_before = nullptr, e_copy_after = nullptr;
     // grow-only device scratch of the host-pointer pose entry points (pose_api.hip): carved per call, re-allocated only
     // when a call needs more than any call before it
     uint8_t* arena = nullptr;

@@ -412,6 +412,16 @@ void slamx_ctx_destroy(slamx_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
     }
+    if (ctx->copy != nullptr) {
+        (void)hipStreamSynchronize(ctx->copy);
+        (void)hipStreamDestroy(ctx->copy);
+    }
+    if (ctx->e_copy_before != nullptr) {
+        (void)hipEventDestroy(ctx->e_copy_before);
+    }
+    if (ctx->e_copy_after != nullptr) {
+        (void)hipEventDestroy(ctx->e_copy_after);
+    }
     if (ctx->e_fork != nullptr) {
         (void)hipEventDestroy(ctx->e_fork);
     }
@@ -804,17 +814,38 @@ int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* ho
         (void)hipGetLastError();
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload_async needs page-locked host memory (slamx_host_alloc)");
     }
-    hipStream_t s = b->det->ctx->stream;
+    // The copy goes on a stream of its own (SLAMX_UPLOAD_STREAM=0: on the compute stream): ordered behind the work already
+    // queued on the context (the frames it overwrites may still be read) and in front of whatever is queued next.  A queue
+    // that only ever carries copies keeps them on the DMA engines beside other contexts' kernels; on the compute stream the
+    // same copy was seen to run serially with those kernels once the stream's history had been copies only
+    // (tools/e2e_breakdown.py: 10.5 against 15.0 ms per 256-frame c3 batch for the same calls, depending on what ran before).
+    slamx_ctx* c = b->det->ctx;
+    static const bool own_stream = std::getenv("SLAMX_UPLOAD_STREAM") == nullptr || std::atoi(std::getenv("SLAMX_UPLOAD_STREAM")) != 0;
+    hipStream_t s = c->stream;
+    if (own_stream) {
+        if (c->copy == nullptr) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->e_copy_before, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->e_copy_after, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(c->e_copy_before, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy, c->e_copy_before, 0));
+        s = c->copy;
+    }
     uint8_t* dst = b->frames + static_cast<size_t>(first) * b->v.frame_stride;
     const bool dense = stride == b->v.pitch && frame_stride == static_cast<ptrdiff_t>(b->v.frame_stride);
     if (dense) {  // rows and frames back to back on both sides: one copy
         HIP_TRY(hipMemcpyAsync(dst, host, static_cast<size_t>(n) * b->v.frame_stride, hipMemcpyHostToDevice, s));
-        return SLAMX_OK;
+    } else {
+        for (int f = 0; f < n; ++f) {
+            HIP_TRY(hipMemcpy2DAsync(dst + static_cast<size_t>(f) * b->v.frame_stride, static_cast<size_t>(b->v.pitch),
+                                     host + static_cast<ptrdiff_t>(f) * frame_stride, static_cast<size_t>(stride),
+                                     static_cast<size_t>(b->v.cols), static_cast<size_t>(b->v.rows), hipMemcpyHostToDevice, s));
+        }
     }
-    for (int f = 0; f < n; ++f) {
-        HIP_TRY(hipMemcpy2DAsync(dst + static_cast<size_t>(f) * b->v.frame_stride, static_cast<size_t>(b->v.pitch),
-                                 host + static_cast<ptrdiff_t>(f) * frame_stride, static_cast<size_t>(stride),
-                                 static_cast<size_t>(b->v.cols), static_cast<size_t>(b->v.rows), hipMemcpyHostToDevice, s));
+    if (own_stream) {
+        HIP_TRY(hipEventRecord(c->e_copy_after, c->copy));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->e_copy_after, 0));
     }
     return SLAMX_OK;
 }
@@ -1059,6 +1090,8 @@ int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, s
     }
     launch_pack_results(b->v, b->matches, b->n_matches, nframes, b->pack, s);
     HIP_TRY(hipGetLastError());
+    // (on the compute stream: a queue of its own for this copy, as the uploads have, was measured and is far worse --
+    // 21.6 against 12.3 ms per 256-frame c3 batch end to end)
     HIP_TRY(hipMemcpyAsync(host, b->pack, std::min(bytes, bound), hipMemcpyDeviceToHost, s));
     return SLAMX_OK;
 }

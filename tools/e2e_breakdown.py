@@ -30,8 +30,11 @@ def main():
         d = mod.FeatureDetector(mod.DetectorConfig(20, 12, 1, wl["window"], 31, 256), c)
         m = mod.FeatureMatcher(mod.MatcherConfig(0, 0, 20, 1, 0.5), c)
         lanes.append((c, mod.Batch(d, wl["rows"], wl["cols"], B, wl["max_cand"], wl["max_kp"]), m))
-    outs = [lane[1].packed_buffer(B) for lane in lanes]
-    for what in ("upload", "upload+detect", "upload+detect+match", "upload+detect+match+download", "detect+match (frames resident)"):
+    outs = [lane[1].packed_buffer(B) for lane in lanes] if os.environ.get("E2E_NO_OUTS") is None else [np.zeros(64, np.uint8)]
+    modes = ("upload", "upload+detect", "upload+detect+match", "upload+detect+match+download", "detect+match (frames resident)")
+    if os.environ.get("E2E_NO_OUTS") is not None:
+        modes = ("upload+detect+match", "upload", "upload+detect+match")
+    for what in modes:
         def step(i, guess):
             c, b, m = lanes[i % n_lanes]
             if what.startswith("upload"):
