@@ -802,6 +802,25 @@ def test_block_ids_spill_into_grid_z():
     assert p.returncode == 0 and " passed" in out, out[-2000:]
 
 
+def test_region_tile_describe_on_every_shape():
+    """describe_tile_kernel (orientation + BRIEF from shared 240 x 64-pixel region tiles) is what dense frames take; in a
+    child process SLAMX_DESCRIBE_TILES=2 sends EVERY frame through it, so that the odd image shapes (narrower than a
+    region, shorter than a band, keypoints within 21 pixels of every border), the reference's frames, the batch path
+    and the pyramid levels exercise its region binning, halo loads and border masks -- bit-exact against the oracle."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SLAMX_DESCRIBE_TILES="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_parity_gpu.py"),
+                        os.path.join(here, "test_pyramid_gpu.py"), "-k",
+                        "batch_equals_single_frame or pipeline_odd_shapes or test_detect_and_compute or pyramid_batch_with_matching or "
+                        "frontend_against_committed_golden_vectors"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and " passed" in out, out[-2000:]
+
+
 def test_batch_equals_single_frame(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     Pp = oracle.det_params(d.cfg)
