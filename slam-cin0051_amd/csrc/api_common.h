@@ -141,5 +141,10 @@ struct slamx_batch {
     bool active = false;  // the current call records
     int last_frames = 0;
     int last_status = 0;  // per-frame status bits seen by the most recent slamx_batch_download
+    // What the host last SAW of the batch's keypoint counts (slamx_batch_counts): -1 nothing yet, 0 no frame reached the
+    // density from which the describe stage uses shared region tiles, 1 some frame did.  A speed hint only: with 0 the
+    // two launches of that path are skipped (25-30 us per 512-frame step of sparse frames) and the per-keypoint kernel
+    // takes every frame, whatever its density.
+    int dense_hint = -1;
 };
 

@@ -1245,8 +1245,13 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
 
 }  // namespace
 
+int describe_tile_min_keypoints(const BatchView& v) {
+    const int regions = ((v.cols + RT_W - 1) / RT_W) * v.nbands;
+    return v.region_first != nullptr && regions <= RT_MAX_REGIONS ? RT_MIN_KEYPOINTS_PER_REGION * regions : 0x7fffffff;
+}
+
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
-                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig) {
+                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig, bool allow_tiles) {
     // float accumulation of integer moments is exact (order-free) iff 255 * sum over the disc
     // of |v| stays below 2^24
     const int radius = p.patch / 2;
@@ -1274,7 +1279,7 @@ void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* 
         const int tile_regions = regions_x * v.nbands;
         const int auto_min = RT_MIN_KEYPOINTS_PER_REGION * tile_regions;
         if (tiles_mode != 0 && use_visit && v.region_first != nullptr && tile_regions <= RT_MAX_REGIONS &&
-            (tiles_mode == 2 || v.maxK >= auto_min)) {
+            (tiles_mode == 2 || (v.maxK >= auto_min && allow_tiles))) {
             tile_min = tiles_mode == 2 ? 1 : auto_min;
             hipLaunchKernelGGL(region_index_kernel, dim3(nframes), dim3(1024), 0, stream, v, regions_x, tile_regions, tile_min);
             hipLaunchKernelGGL(describe_tile_kernel, dim3(frame_grid(nframes, tile_regions)), dim3(256), 0, stream, v, p, pattern_dev,

@@ -232,7 +232,7 @@ void enqueue_compute(slamx_batch* b, int nframes, bool after_nms) {
     record(b, 7);
     hipEvent_t e_mom = event_slot(b, 8);
     hipEvent_t e_trig = event_slot(b, 9);
-    launch_describe(b->v, p, b->det->pattern_dev, nframes, after_nms && p.nms != 0, s, e_mom, e_trig);
+    launch_describe(b->v, p, b->det->pattern_dev, nframes, after_nms && p.nms != 0, s, e_mom, e_trig, b->dense_hint != 0);
     record(b, 10);
 }
 
@@ -875,7 +875,7 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
         launch_sort(b->v, nframes, c->stream, !nms_uses_greedy_path(b->v, p));
         launch_nms(b->v, p, nframes, c->stream, nullptr);
         (void)hipStreamWaitEvent(c->stream, c->e_join, 0);
-        launch_describe(b->v, p, b->det->pattern_dev, nframes, true, c->stream, nullptr, nullptr);
+        launch_describe(b->v, p, b->det->pattern_dev, nframes, true, c->stream, nullptr, nullptr, b->dense_hint != 0);
     } else {
         enqueue_detect(b, nframes);
         enqueue_compute(b, nframes, true);
@@ -959,6 +959,12 @@ int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32
     }
     if (n_keypoints != nullptr) {
         HIP_TRY(hipMemcpy(n_keypoints, b->v.n_kp, sizeof(int) * nframes, hipMemcpyDeviceToHost));
+        const int tile_min = describe_tile_min_keypoints(b->v);
+        int dense = 0;
+        for (int f = 0; f < nframes; ++f) {
+            dense |= n_keypoints[f] >= tile_min ? 1 : 0;
+        }
+        b->dense_hint = dense;
     }
     if (n_matches != nullptr) {
         if (b->n_matches != nullptr) {

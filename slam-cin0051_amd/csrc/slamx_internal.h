@@ -205,8 +205,12 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
 void launch_passthrough_keypoints(const BatchView& v, int nframes, hipStream_t stream);  // NonMaxSuppression: 0
 void launch_blur(const BatchView& v, const double* weights_dev, int nframes, hipStream_t stream);
 // use_visit: walk the keypoints in the raster order left by launch_nms (v.visit) instead of slot order
+// allow_tiles: false when the caller KNOWS that no frame is dense enough for the shared region tiles (their two launches
+// are then skipped; the result is the same either way)
 void launch_describe(const BatchView& v, const DetectorParams& p, const int8_t* pattern_dev, int nframes, bool use_visit,
-                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig);
+                     hipStream_t stream, hipEvent_t ev_after_moments, hipEvent_t ev_after_trig, bool allow_tiles = true);
+// keypoints per frame from which describe.hip sends a frame through the shared region tiles (0x7fffffff: never)
+int describe_tile_min_keypoints(const BatchView& v);
 
 struct MatchView {
     // pair q: query = frame qf[q], train = frame tf[q] of the same batch layout
