@@ -893,21 +893,16 @@ bool nms_uses_greedy_path(const BatchView& v, const DetectorParams& p) {
 }
 
 void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStream_t stream, hipEvent_t ev_mid) {
-    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072),
-                              true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_finish{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(nms_finish_kernel), 131072, lds_finish);
     if (nms_uses_greedy_path(v, p)) {
         const int gx2 = (v.cols + p.window - 1) / p.window + 2;
         const int gy2 = (v.rows + p.window - 1) / p.window + 2;
         const size_t bytes = static_cast<size_t>(gx2) * gy2 * sizeof(uint32_t);
         {
-            static const bool once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel<LOOKAHEAD>),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, GREEDY_LDS_BUDGET),
-                                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel<LOOKAHEAD_MAX>),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, GREEDY_LDS_BUDGET),
-                                       true);
-            (void)once2;
+            static std::atomic<unsigned long long> lds_greedy{0}, lds_greedy_max{0};
+            allow_dynamic_lds(reinterpret_cast<const void*>(nms_greedy_kernel<LOOKAHEAD>), GREEDY_LDS_BUDGET, lds_greedy);
+            allow_dynamic_lds(reinterpret_cast<const void*>(nms_greedy_kernel<LOOKAHEAD_MAX>), GREEDY_LDS_BUDGET, lds_greedy_max);
             const uint32_t magic = static_cast<uint32_t>(((1ull << 32) + p.window - 1) / p.window);
             // the hashed survivor table takes what is left of the LDS budget (a power of two of dwords)
             // (a power of two of dwords), but at most half of a CU's 160 KB when that is within reach, so that

@@ -1072,8 +1072,8 @@ size_t sort_lds_bytes(int lds_keys) {
     // keys + leaf-flag words + segment queue (data, sequence numbers)
     return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + 32 + static_cast<size_t>(SORT_QCAP) * 12;
 }
-void allow_big_lds(const void* fn) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_lds_bytes(SORT_LDS_KEYS_MAX)));
+void allow_big_lds(const void* fn, std::atomic<unsigned long long>& done) {
+    allow_dynamic_lds(fn, sort_lds_bytes(SORT_LDS_KEYS_MAX), done);
 }
 
 }  // namespace
@@ -1096,8 +1096,8 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_
         return true;
     }();
     (void)once_bm;
-    static const bool once = (allow_big_lds(reinterpret_cast<const void*>(sort_kernel)), true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_done{0};
+    allow_big_lds(reinterpret_cast<const void*>(sort_kernel), lds_done);
     const int lds_keys = lds_keys_for(v.maxM);
     hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys,
                        need_rank_of ? 1 : 0);
@@ -1105,8 +1105,8 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream) {
-    static const bool once = (allow_big_lds(reinterpret_cast<const void*>(debug_sort_kernel)), true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_done{0};
+    allow_big_lds(reinterpret_cast<const void*>(debug_sort_kernel), lds_done);
     const int lds_keys = lds_keys_for(n);
     hipLaunchKernelGGL(debug_sort_kernel, dim3(1), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, keys, sorted,
                        segstart, seglist, maxSeg, n, status, lds_keys);

@@ -1933,10 +1933,8 @@ __global__ __launch_bounds__(64) void pnp_select_kernel(PoseWork w, PoseParams p
 void launch_pnp_dlt(const double* p3d, const double* p2d, int n_points, int n_hyp, double* R, double* t, double* nullvec,
                     hipStream_t stream) {
     const size_t lds = 4 * sizeof(PnpWork);
-    static const bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_dlt_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
-                              true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_done{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(pnp_dlt_kernel), lds, lds_done);
     int blocks = (n_hyp + 3) / 4;
     if (blocks > 2048) {
         blocks = 2048;
@@ -1974,8 +1972,8 @@ int pose_blocks(int cap, int per_block) {
     return b < 1 ? 1 : b;
 }
 template <typename Kernel>
-void allow_lds(Kernel k, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+void allow_lds(Kernel k, size_t bytes, std::atomic<unsigned long long>& done) {
+    allow_dynamic_lds(reinterpret_cast<const void*>(k), bytes, done);
 }
 }  // namespace
 
@@ -2003,8 +2001,8 @@ void launch_pose_select(const PoseWork& w, const PoseParams& prm, int npairs, hi
 
 void launch_essential_refit_pairs(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
     const size_t lds = (4 * 64 * LD + 4 * LD * LD) * sizeof(double);  // chunk rows + Gram tiles of the four waves
-    static const bool once = (allow_lds(essential_refit_kernel, lds), true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_done{0};
+    allow_lds(essential_refit_kernel, lds, lds_done);
     hipLaunchKernelGGL(essential_refit_kernel, dim3(npairs), dim3(256), lds, stream, w, prm);
 }
 
@@ -2026,8 +2024,8 @@ void launch_pnp_gather(const PoseSource& src, const PoseWork& w, const PoseParam
 }
 
 void launch_pnp_hypotheses(const PoseWork& w, const PoseParams& prm, int npairs, hipStream_t stream) {
-    static const bool once = (allow_lds(pnp_hyp_kernel, PNP_HYP_LDS), true);
-    (void)once;
+    static std::atomic<unsigned long long> lds_done{0};
+    allow_lds(pnp_hyp_kernel, PNP_HYP_LDS, lds_done);
     hipLaunchKernelGGL(pnp_hyp_kernel, dim3((prm.pnp_iterations + 63) / 64, npairs), dim3(64), PNP_HYP_LDS, stream, w, prm);
 }
 

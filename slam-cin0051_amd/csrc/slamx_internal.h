@@ -2,6 +2,7 @@
 // gfx950 only: wave = 64 lanes everywhere in this code base.
 #pragma once
 
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,6 +142,22 @@ __device__ __forceinline__ int penalised_distance(int dist, float qx, float qy, 
     return penalised_distance_exact(dist, dx, dy);
 }
 #endif
+
+// hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) applies to the CURRENT device, so "once per process" is
+// wrong for a host that drives several GPUs from one process (tools/cli -g N: one thread + one context per GPU): once per
+// (call site, device).  `done` is the call site's bit mask of devices that have been set up.
+inline void allow_dynamic_lds(const void* kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        return;
+    }
+    const unsigned long long bit = 1ull << dev;
+    if ((done.load(std::memory_order_relaxed) & bit) == 0) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+}
 
 // blocks per frame for a grid-stride kernel: enough to cover `items`, capped so that a large
 // batch does not launch millions of empty workgroups (>= 8 per frame, ~8192 in total)
