@@ -113,6 +113,13 @@ struct slamx_matcher {
     int2* best = nullptr;
     int* second = nullptr;
     uint8_t* xdesc = nullptr;  // [2][cap][64]
+    // desc | kps | n_kp above are carved out of ONE device block and matches | n_matches out of another, mirrored by ONE
+    // page-locked host block: a call is one copy in, the kernels, one copy out and one synchronisation (until round 4:
+    // five copies from pageable memory, three synchronisations -- 176 us per call on 1.1k keypoints, mostly those)
+    uint8_t* in_blob = nullptr;
+    uint8_t* out_blob = nullptr;
+    uint8_t* stage = nullptr;  // hipHostMalloc: [in_blob image][out tail image]
+    size_t in_bytes = 0, out_tail_bytes = 0;
 };
 
 struct slamx_batch {

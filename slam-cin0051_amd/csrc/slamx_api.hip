@@ -1494,14 +1494,15 @@ void slamx_matcher_destroy(slamx_matcher* m) {
         return;
     }
     (void)hipSetDevice(m->ctx->device);
-    dev_free(m->desc);
-    dev_free(m->kps);
-    dev_free(m->n_kp);
-    dev_free(m->matches);
-    dev_free(m->n_matches);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    dev_free(m->in_blob);   // desc, kps, n_kp
+    dev_free(m->out_blob);  // matches, n_matches
     dev_free(m->best);
     dev_free(m->second);
     dev_free(m->xdesc);
+    if (m->stage != nullptr) {
+        (void)hipHostFree(m->stage);
+    }
     delete m;
 }
 
@@ -1533,37 +1534,52 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     hipStream_t s = m->ctx->stream;
     const int need = std::max(n1, n2);
     if (need > m->cap || width1 != m->width) {
-        dev_free(m->desc);
-        dev_free(m->kps);
-        dev_free(m->n_kp);
-        dev_free(m->matches);
-        dev_free(m->n_matches);
+        HIP_TRY(hipStreamSynchronize(s));
+        dev_free(m->in_blob);
+        dev_free(m->out_blob);
         dev_free(m->best);
         dev_free(m->second);
         dev_free(m->xdesc);
+        if (m->stage != nullptr) {
+            (void)hipHostFree(m->stage);
+            m->stage = nullptr;
+        }
         m->cap = 0;
         const size_t c = static_cast<size_t>(need);
-        SLAMX_TRY(dev_alloc(&m->desc, 2 * c * width1 + 64));
-        SLAMX_TRY(dev_alloc(&m->kps, 2 * c));
-        SLAMX_TRY(dev_alloc(&m->n_kp, 2));
-        SLAMX_TRY(dev_alloc(&m->matches, 2 * c));
-        SLAMX_TRY(dev_alloc(&m->n_matches, 2));
+        // in:  desc [2][c][width] (padded to 16 bytes) | kps [2][c] | n_kp [2]        out: matches [2][c] | n_matches [2]
+        const size_t desc_bytes = (2 * c * width1 + 64 + 15) / 16 * 16;
+        m->in_bytes = desc_bytes + 2 * c * sizeof(slamx_keypoint) + 16;
+        m->out_tail_bytes = c * sizeof(slamx_match) + 16;  // the query slot's matches and both counts: what a call brings back
+        SLAMX_TRY(dev_alloc(&m->in_blob, m->in_bytes));
+        SLAMX_TRY(dev_alloc(&m->out_blob, 2 * c * sizeof(slamx_match) + 16));
+        m->desc = m->in_blob;
+        m->kps = reinterpret_cast<slamx_keypoint*>(m->in_blob + desc_bytes);
+        m->n_kp = reinterpret_cast<int*>(m->in_blob + desc_bytes + 2 * c * sizeof(slamx_keypoint));
+        m->matches = reinterpret_cast<slamx_match*>(m->out_blob);
+        m->n_matches = reinterpret_cast<int*>(m->out_blob + 2 * c * sizeof(slamx_match));
         SLAMX_TRY(dev_alloc(&m->best, 2 * MATCH_MAX_SPLIT * c));
         SLAMX_TRY(dev_alloc(&m->second, 2 * MATCH_MAX_SPLIT * c));
         SLAMX_TRY(dev_alloc(&m->xdesc, match_scratch_bytes(2, need)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->stage), m->in_bytes + m->out_tail_bytes, hipHostMallocDefault));
+        std::memset(m->stage, 0, m->in_bytes + m->out_tail_bytes);
         m->cap = need;
         m->width = width1;
     }
     const size_t c = static_cast<size_t>(m->cap);
-    const int counts[2] = {n2, n1};  // frame 0 = train, frame 1 = query
-    HIP_TRY(hipMemcpyAsync(m->desc, d2, static_cast<size_t>(n2) * width1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(m->desc + c * width1, d1, static_cast<size_t>(n1) * width1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(m->n_kp, counts, sizeof(counts), hipMemcpyHostToDevice, s));
-    if (use_kp) {
-        HIP_TRY(hipMemcpyAsync(m->kps, kp2, sizeof(slamx_keypoint) * n2, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(m->kps + c, kp1, sizeof(slamx_keypoint) * n1, hipMemcpyHostToDevice, s));
+    {
+        // the inputs into the page-locked image of the device block (frame 0 = train, frame 1 = query), then ONE copy
+        const size_t desc_bytes = (2 * c * width1 + 64 + 15) / 16 * 16;
+        uint8_t* st = m->stage;
+        std::memcpy(st, d2, static_cast<size_t>(n2) * width1);
+        std::memcpy(st + c * width1, d1, static_cast<size_t>(n1) * width1);
+        if (use_kp) {
+            std::memcpy(st + desc_bytes, kp2, sizeof(slamx_keypoint) * n2);
+            std::memcpy(st + desc_bytes + c * sizeof(slamx_keypoint), kp1, sizeof(slamx_keypoint) * n1);
+        }
+        const int counts[2] = {n2, n1};
+        std::memcpy(st + desc_bytes + 2 * c * sizeof(slamx_keypoint), counts, sizeof(counts));
+        HIP_TRY(hipMemcpyAsync(m->in_blob, st, m->in_bytes, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));  // counts[] lives on this stack frame
     MatchView mv{};
     mv.desc = m->desc;
     mv.kps = use_kp ? m->kps : nullptr;
@@ -1629,12 +1645,16 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
     mv.ratio = m->cfg.ratio_test_threshold;
     launch_match_consecutive(mv, 1, 1, -1, s, nullptr);
     HIP_TRY(hipGetLastError());
-    int cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, m->n_matches + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    // the query slot's matches (at most n1) and the counts behind them: ONE copy into the page-locked block, one wait
+    uint8_t* back = m->stage + m->in_bytes;
+    HIP_TRY(hipMemcpyAsync(back, m->matches + c, m->out_tail_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    int cnt = 0;
+    std::memcpy(&cnt, back + c * sizeof(slamx_match) + sizeof(int), sizeof(int));  // n_matches[1]
+    cnt = std::min(std::max(cnt, 0), n1);
     std::vector<slamx_match> v(static_cast<size_t>(cnt));
     if (cnt > 0) {
-        HIP_TRY(hipMemcpy(v.data(), m->matches + c, sizeof(slamx_match) * cnt, hipMemcpyDeviceToHost));
+        std::memcpy(v.data(), back, sizeof(slamx_match) * cnt);
     }
     if (m->cfg.filter_matches != 0) {
         filter_and_sort(v, m->cfg.good_matches_count);
