@@ -722,13 +722,13 @@ __global__ __launch_bounds__(256) void brief_kernel(BatchView v, DetectorParams 
     }
 }
 
-// Which kernel describes a frame is decided per frame, on the device: the shared tiles cost ~5.5 us of latency per
-// region (tile load, list, barriers; 4 workgroups per CU) and 0.22 ns per keypoint, the per-keypoint tiles of
-// describe_fused_kernel 0.36-0.48 ns per keypoint -- the tiles win from ~27 keypoints per region on (measured: 1080p with
-// 2.1k keypoints = 15 per region 0.61 against 0.51 ms per 512 frames; 10.4k keypoints = 77 per region 0.76 against 0.97 ms
-// per 256; 640 x 480 with 1.9k = 79 per region 0.56 against 0.71 ms per 1024).  Both kernels are launched, each leaves the
-// other's frames alone.
-constexpr int RT_MIN_KEYPOINTS_PER_REGION = 28;
+// Which kernel describes a frame is decided per frame, on the device: the shared tiles cost ~4 us of latency per
+// region (tile load with the list fetch under it, barriers; 4 workgroups per CU) and 0.22 ns per keypoint, the
+// per-keypoint tiles of describe_fused_kernel 0.34-0.50 ns per keypoint -- the tiles win from ~14 keypoints per region on
+// (measured: 1080p with 2.1k keypoints = 13 per region 0.53 against 0.51 ms per 512 frames; 10.4k keypoints = 77 per
+// region 0.74 against 0.97 ms per 256; 640 x 480 with 2.0k = 83 per region 0.54 against 0.70 ms per 1024); the threshold
+// keeps a margin above the break-even.  Both kernels are launched, each leaves the other's frames alone.
+constexpr int RT_MIN_KEYPOINTS_PER_REGION = 20;
 __device__ __forceinline__ bool frame_takes_tiles(int n_kp, int tile_min) { return n_kp >= tile_min; }
 
 // ---- orientation + BRIEF in ONE pass over the blurred frame (PatchSize <= 31, <= 64 surviving pairs) ----
@@ -1008,18 +1008,19 @@ __global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int reg
     const slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
     const uint32_t* visit = v.visit + static_cast<size_t>(f) * v.maxK;
     int* first = v.region_first + static_cast<size_t>(f) * (regions + 1);
-    int* list = v.region_list + static_cast<size_t>(f) * v.maxK;
+    int2* list = v.region_list + static_cast<size_t>(f) * v.maxK;  // {slot, y << 16 | x}
     for (int r = tid; r < regions; r += 1024) {
         hist[r] = 0;
     }
     __syncthreads();
-    auto region_of = [&](int slot) {
+    auto coords_of = [&](int slot) {  // clamped into the image: y << 16 | x
         const int x = min(max(kp_coord(kps[slot].x), 0), v.cols - 1);
         const int y = min(max(kp_coord(kps[slot].y), 0), v.rows - 1);
-        return (y >> 6) * regions_x + x / RT_W;
+        return y << 16 | x;
     };
+    auto region_of = [&](int xy) { return ((xy >> 16) >> 6) * regions_x + (xy & 0xffff) / RT_W; };
     for (int i = tid; i < n; i += 1024) {
-        atomicAdd(&hist[region_of(static_cast<int>(visit[i]))], 1);
+        atomicAdd(&hist[region_of(coords_of(static_cast<int>(visit[i])))], 1);
     }
     __syncthreads();
     // exclusive prefix over the regions (block scan in chunks of 1024), in place: hist[r] becomes the region's cursor
@@ -1056,7 +1057,8 @@ __global__ __launch_bounds__(1024) void region_index_kernel(BatchView v, int reg
     }
     for (int i = tid; i < n; i += 1024) {
         const int slot = static_cast<int>(visit[i]);
-        list[atomicAdd(&hist[region_of(slot)], 1)] = slot;
+        const int xy = coords_of(slot);
+        list[atomicAdd(&hist[region_of(xy)], 1)] = make_int2(slot, xy);
     }
 }
 
@@ -1080,14 +1082,34 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
     if (!frame_takes_tiles(v.n_kp[f], tile_min)) {
         return;  // describe_fused_kernel takes this frame (uniform)
     }
+    // The tile's loads go out FIRST (they need only the frame and the region; an empty region of a dense frame wastes
+    // them, which is rare) and are in flight while the region's list is fetched: 16-byte pieces, rows above / below the
+    // frame through an offset beyond the buffer (zero fill by the range check).
+    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
+    constexpr int TILE_LOADS = (RT_PIECES + 255) / 256;
+    uint4 tq[TILE_LOADS];
+    {
+        const __amdgpu_buffer_rsrc_t frame_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
+        const int soff = (y0 - TILE_HALF) * v.pitch + (x0 - RT_XOFF);  // may be negative: such rows read as zero
+#pragma unroll
+        for (int k = 0; k < TILE_LOADS; ++k) {
+            const int p = tid + 256 * k;
+            const int rr = p / (RT_DW / 4);
+            const int cc = p - rr * (RT_DW / 4);
+            const int yy = y0 - TILE_HALF + rr;
+            const int voff = (p < RT_PIECES && yy >= 0 && yy < v.rows) ? rr * v.pitch + cc * 16 + soff : 0x7ffffff0;
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, voff, 0, 0);
+            tq[k] = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+    }
     const int* first = v.region_first + static_cast<size_t>(f) * (regions_per_frame + 1);
     const int lo = first[r], hi = first[r + 1];
     if (lo >= hi) {
         return;  // no keypoint in the region (uniform)
     }
-    const uint8_t* img = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     slamx_keypoint* kps = v.kps + static_cast<size_t>(f) * v.maxK;
-    const int* list = v.region_list + static_cast<size_t>(f) * v.maxK;
+    const int2* list = v.region_list + static_cast<size_t>(f) * v.maxK;
     const int radius = P.patch / 2;
     const int words = v.width / 8;
     // per-lane constants of the phases
@@ -1115,28 +1137,20 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
     for (int base = lo; base < hi; base += RT_LIST) {  // uniform; one pass unless a region holds more than RT_LIST keypoints
         const int nl = min(RT_LIST, hi - base);
         for (int k = tid; k < nl; k += 256) {
-            const int slot = list[base + k];
-            const int kx = min(max(kp_coord(kps[slot].x), 0), v.cols - 1), ky = min(max(kp_coord(kps[slot].y), 0), v.rows - 1);
-            l_slot[k] = slot;
-            l_xy[k] = static_cast<uint32_t>(ky - y0 + TILE_HALF) << 16 | static_cast<uint32_t>(kx - x0 + RT_XOFF);
+            const int2 e = list[base + k];
+            l_slot[k] = e.x;
+            l_xy[k] = static_cast<uint32_t>((e.y >> 16) - y0 + TILE_HALF) << 16 | static_cast<uint32_t>((e.y & 0xffff) - x0 + RT_XOFF);
         }
-        // ---- the tile, once
+        // ---- the tile, once: registers -> LDS
         if (!tile_loaded) {
             tile_loaded = true;
-            const __amdgpu_buffer_rsrc_t frame_rsrc =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
-            const int soff = (y0 - TILE_HALF) * v.pitch + (x0 - RT_XOFF);  // may be negative: such rows read as zero
 #pragma unroll
-            for (int k = 0; k < (RT_PIECES + 255) / 256; ++k) {
+            for (int k = 0; k < TILE_LOADS; ++k) {
                 const int p = tid + 256 * k;
                 if (p < RT_PIECES) {
                     const int rr = p / (RT_DW / 4);
                     const int cc = p - rr * (RT_DW / 4);
-                    // rows above / below the frame: an offset beyond the buffer (zero fill by the range check)
-                    const int yy = y0 - TILE_HALF + rr;
-                    const int voff = (yy >= 0 && yy < v.rows) ? rr * v.pitch + cc * 16 + soff : 0x7ffffff0;
-                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, voff, 0, 0);
-                    *reinterpret_cast<uint4*>(&tile[rr * RT_DW + cc * 4]) = make_uint4(q[0], q[1], q[2], q[3]);
+                    *reinterpret_cast<uint4*>(&tile[rr * RT_DW + cc * 4]) = tq[k];
                 }
             }
         }

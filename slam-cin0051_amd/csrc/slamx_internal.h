@@ -75,7 +75,7 @@ struct BatchView {
     uint8_t* desc;           // [F][maxK][width]
     uint32_t* visit;         // [F][maxK] keypoint slots in raster order (written by the NMS finisher)
     int* region_first;       // [F][regions + 1] first entry of every 240 x 64-pixel region in region_list (describe.hip), or nullptr
-    int* region_list;        // [F][maxK] keypoint slots grouped by region
+    int2* region_list;       // [F][maxK] {keypoint slot, y << 16 | x} grouped by region
     int nbands;              // ceil(rows / 64): regions = ceil(cols / 240) * nbands
     int2* moments;           // [F][maxK] {m01, m10} scratch of the describe stage
     float2* cos_sin;         // [F][maxK] {cos, sin} scratch of the describe stage
