@@ -17,7 +17,7 @@ echo "default done"
 python bench.py --batch 256 --steps 20 --warmup 3 --no-cpu-baseline --no-pcie > "$out/bench_1080p_2k_b256.json"
 python bench.py --workload c1 --steps 20 --warmup 3 --no-pcie > "$out/bench_c1.json"
 python bench.py --workload c2 --steps 20 --warmup 3 --no-pcie > "$out/bench_c2.json"
-python bench.py --workload c3 --steps 10 --warmup 2 --no-pcie > "$out/bench_c3.json"
+python bench.py --workload c3 --steps 10 --warmup 2 > "$out/bench_c3.json"
 echo "c3 done"
 python bench.py --workload c3 --with-pose --steps 10 --warmup 2 --no-pcie --no-cpu-baseline > "$out/bench_c3_pose.json"
 echo "c3 + pose done"
