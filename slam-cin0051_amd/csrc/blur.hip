@@ -37,13 +37,14 @@ constexpr int HALO = 2;
 constexpr int LDS_ROW_DW = 64;               // columns [X0-4, X0+252) as dwords, one per lane
 constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 36
 constexpr int ROWS_PER_WAVE = TILE_H / 4;
-constexpr int FIX_CAP = 2048;                // uncertain pixels listed per tile; beyond: whole tile exact
+constexpr int FIX_PER_WAVE = 512;            // uncertain dwords listed per wave; beyond: whole tile exact
 // |frac(estimate) - 0.5| <= 6e-4 sends a pixel to the exact pass; tested as
 // frac(estimate - UNC_LO) <= UNC_SPAN, widened by 5e-5 for the rounding of that subtraction
 constexpr float UNC_LO = 0.5f - 6.5e-4f;
 constexpr float UNC_SPAN = 1.3e-3f;
 
-// the reference's sum for the pixel whose centre byte is at pc in the LDS tile
+// the reference's sum for the pixel whose centre byte is at pc in the LDS tile (wgt: the kernel argument, so the 25
+// weights are scalar loads -- as an LDS array the compiler kept all of them in 50 vector registers across the pass)
 __device__ __forceinline__ uint32_t exact_pixel(const uint8_t* pc, const double* wgt) {
     double acc = 0.0;
 #pragma unroll
@@ -71,9 +72,10 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
                                                     int tiles_y, uint32_t tiles_x_recip) {
     __shared__ uint32_t tile[LDS_ROWS * LDS_ROW_DW];
     __shared__ uint32_t outt[TILE_H * LDS_ROW_DW];
-    __shared__ uint16_t fix[FIX_CAP];
-    __shared__ int nfix;
-    __shared__ double wgt[25];
+    // Uncertain pixels, one entry per output dword that has any: row << 10 | lane << 4 | mask of its bytes.  Every wave
+    // keeps a list of its own with the count in a scalar register -- no LDS atomic, no round trip in the main loop.
+    __shared__ uint16_t fix[4][FIX_PER_WAVE];
+    __shared__ int nfix[4];
     __shared__ float g[5];
     // all tiles of a frame on ONE XCD (frame_block): its L2 serves the halo rows shared by vertically adjacent
     // tiles AND the 128-byte lines that horizontally adjacent tiles share (a tile row starts at x0 - 4: with a tile
@@ -90,15 +92,9 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
     uint8_t* out = v.blurred + static_cast<size_t>(f) * v.frame_stride;
     const int x = tx * TILE_W - 4 + lane * 4;  // first of this lane's 4 columns
     const int y0 = ty * TILE_H - HALO;
-    if (threadIdx.x < 25) {
-        wgt[threadIdx.x] = weights[threadIdx.x];
-    }
     if (threadIdx.x < 5) {
         // separable factor: w[i][2] / sqrt(w[2][2]) == exp(-i^2/2) / sum(exp(-k^2/2))
         g[threadIdx.x] = static_cast<float>(weights[threadIdx.x * 5 + 2] / sqrt(weights[12]));
-    }
-    if (threadIdx.x == 0) {
-        nfix = 0;
     }
     {
         // a wave stages whole rows, lane -> dword column; all loads are issued before the first LDS store
@@ -134,6 +130,8 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         }
     }
     const bool writer = lane >= 1 && lane <= 62 && x < v.cols;
+    const uint32_t keep4 = (keep & 1u) | (keep >> 7 & 2u) | (keep >> 14 & 4u) | (keep >> 21 & 8u);
+    int listed_here = 0;  // (wave-uniform) entries in this wave's list
     {
         // rolling window of 5 input rows x this lane's 4 columns, converted once per row
         // (v_cvt_f32_ubyte0..3).  Scalar VOP2 float math on purpose: v_add_f32 / v_fmac_f32 issue at
@@ -203,33 +201,44 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
                 packed = (src & keep) | (acc & ~keep);
                 const bool some = writer && fminf(fminf(w[0], w[1]), fminf(w[2], w[3])) <= UNC_SPAN;
                 if (__ballot(some) != 0) {  // about a quarter of the wave-rows
+                    uint32_t m = 0;
                     if (some) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            if (w[p] <= UNC_SPAN && ((keep >> (8 * p)) & 1u) == 0) {
-                                const int pos = atomicAdd(&nfix, 1);
-                                if (pos < FIX_CAP) {
-                                    fix[pos] = static_cast<uint16_t>((ry << 8) | (lane * 4 + p));
-                                }
-                            }
+                        m = ((w[0] <= UNC_SPAN ? 1u : 0u) | (w[1] <= UNC_SPAN ? 2u : 0u) | (w[2] <= UNC_SPAN ? 4u : 0u) |
+                             (w[3] <= UNC_SPAN ? 8u : 0u)) & ~keep4;
+                    }
+                    const unsigned long long b = __ballot(m != 0);
+                    if (m != 0) {
+                        const int pos = listed_here + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+                        if (pos < FIX_PER_WAVE) {
+                            fix[wave][pos] = static_cast<uint16_t>(ry << 10 | lane << 4 | static_cast<int>(m));
                         }
                     }
+                    listed_here += __popcll(b);
                 }
             }
             outt[ry * LDS_ROW_DW + lane] = packed;
         }
     }
+    if (lane == 0) {
+        nfix[wave] = listed_here;
+    }
     __syncthreads();
-    // ---- exact pass on the listed pixels (or on the whole tile when the list overflowed)
+    // ---- exact pass on the listed pixels (or on the whole tile when a list overflowed)
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* o8 = reinterpret_cast<uint8_t*>(outt);
-    const int listed = nfix;
-    if (listed <= FIX_CAP) {
-        for (int s = threadIdx.x; s < listed; s += 256) {
-            const int e = fix[s];
-            const int ry = e >> 8;
-            const int col = e & 255;  // byte column inside the LDS row
-            o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, wgt));
+    const int n0 = nfix[0], n1 = nfix[1], n2 = nfix[2], n3 = nfix[3];
+    if (max(max(n0, n1), max(n2, n3)) <= FIX_PER_WAVE) {
+        const int total = n0 + n1 + n2 + n3;
+        for (int s = threadIdx.x; s < total; s += 256) {
+            const int e = s < n0 ? fix[0][s] : s < n0 + n1 ? fix[1][s - n0] : s < n0 + n1 + n2 ? fix[2][s - n0 - n1] : fix[3][s - n0 - n1 - n2];
+            const int ry = e >> 10;
+            const int col = (e >> 4 & 63) * 4;  // byte column of the dword inside the LDS row
+#pragma nounroll
+            for (int m = e & 15; m != 0; m &= m - 1) {
+                const int c = col + __builtin_ctz(m);
+                o8[ry * (LDS_ROW_DW * 4) + c] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + c, weights));
+            }
         }
     } else {
         for (int s = threadIdx.x; s < TILE_W * TILE_H; s += 256) {
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
             const int yy = ty * TILE_H + ry;
             const int xx = tx * TILE_W - 4 + col;
             if (yy >= HALO && yy < v.rows - HALO && xx >= HALO && xx < v.cols - HALO) {
-                o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, wgt));
+                o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, weights));
             }
         }
     }
