@@ -2,6 +2,8 @@
 // thread-local error slot, the status macros, device allocation helpers and the handle structs.
 #pragma once
 
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -19,6 +21,35 @@ inline int fail(int code, const std::string& msg) {
     slamx::last_error_slot() = msg;
     return code;
 }
+
+// No C++ exception crosses the C ABI: every int-returning entry point is a function-try-block that ends in SLAMX_CATCH
+// (host allocations -- std::vector, std::string, new -- are the only sources; "out of memory" fits the small-string
+// buffer, so reporting it allocates nothing).
+inline int caught_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try {
+            slamx::last_error_slot().assign("out of memory");
+        } catch (...) {
+        }
+    } catch (const std::exception& e) {
+        try {
+            slamx::last_error_slot().assign(e.what());
+        } catch (...) {
+        }
+    } catch (...) {
+        try {
+            slamx::last_error_slot().assign("unknown exception");
+        } catch (...) {
+        }
+    }
+    return SLAMX_ERR_RUNTIME;
+}
+#define SLAMX_CATCH                  \
+    catch (...) {                    \
+        return caught_exception();   \
+    }
 
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
@@ -154,4 +185,38 @@ struct slamx_batch {
     // takes every frame, whatever its density.
     int dense_hint = -1;
 };
+
+namespace {
+// The matcher outputs of a batch, on first use: all four arrays or none (a failed allocation leaves the batch as it was).
+inline int batch_match_arrays(slamx_batch* b, hipStream_t stream) {
+    if (b->matches != nullptr) {
+        return SLAMX_OK;
+    }
+    const size_t F = static_cast<size_t>(b->shape.max_frames), K = static_cast<size_t>(b->v.maxK);
+    slamx_match* matches = nullptr;
+    int* n_matches = nullptr;
+    int2* best = nullptr;
+    int* second = nullptr;
+    int rc = dev_alloc(&matches, F * K);
+    rc = rc != SLAMX_OK ? rc : dev_alloc(&n_matches, F);
+    rc = rc != SLAMX_OK ? rc : dev_alloc(&best, F * slamx::MATCH_MAX_SPLIT * K);
+    rc = rc != SLAMX_OK ? rc : dev_alloc(&second, F * slamx::MATCH_MAX_SPLIT * K);
+    if (rc == SLAMX_OK && hipMemsetAsync(n_matches, 0, F * sizeof(int), stream) != hipSuccess) {
+        rc = fail(SLAMX_ERR_HIP, "hipMemsetAsync(n_matches) failed");
+    }
+    if (rc != SLAMX_OK) {
+        dev_free(matches);
+        dev_free(n_matches);
+        dev_free(best);
+        dev_free(second);
+        return rc;
+    }
+    b->matches = matches;
+    b->n_matches = n_matches;
+    b->best = best;
+    b->second = second;
+    return SLAMX_OK;
+}
+}  // namespace
+
 

@@ -207,7 +207,7 @@ extern "C" {
 
 // ------------------------------------------------------------------ a11 / a12: solvePnP, inlier counts
 int slamx_pnp_dlt_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n_points, int n_hyp, double* R,
-                        double* t, double* nullvec) {
+                        double* t, double* nullvec) try {
     if (n_points < 6) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "solvePnP needs at least 6 points");  // returns false in the reference
     }
@@ -239,11 +239,12 @@ int slamx_pnp_dlt_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, in
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
-                              const double* R, const double* t, int n_hyp, double threshold, int32_t* counts) {
-    if (n < 0 || n_hyp < 0 || K == nullptr || counts == nullptr) {
+                              const double* R, const double* t, int n_hyp, double threshold, int32_t* counts) try {
+    if (n < 0 || n_hyp < 0 || K == nullptr || counts == nullptr || (n > 0 && (p3d == nullptr || p2d == nullptr)) ||
+        (n_hyp > 0 && (R == nullptr || t == nullptr)) || !(threshold >= 0.0)) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "inlier arguments invalid");
     }
     if (n_hyp == 0) {
@@ -272,11 +273,11 @@ int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p
     HIP_TRY(hipMemcpyAsync(counts, dc, H * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ the RANSAC of verifyGeometricConsistency, one frame
 int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, const int32_t* idx,
-                           int iterations, double threshold, double* R, double* t, int32_t* max_inliers) {
+                           int iterations, double threshold, double* R, double* t, int32_t* max_inliers) try {
     if (n < 6 || iterations <= 0 || iterations > 65536 || p3d == nullptr || p2d == nullptr || K == nullptr || R == nullptr ||
         t == nullptr || idx == nullptr || !(threshold > 0.0)) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "ransac arguments invalid (needs >= 6 correspondences)");
@@ -317,10 +318,10 @@ int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d,
         *max_inliers = r.pnp_inliers;
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, int iterations,
-                     double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers) {
+                     double threshold, uint32_t seed, double* R, double* t, int32_t* max_inliers) try {
     if (n < 6 || iterations <= 0 || iterations > 65536) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "ransac arguments invalid (needs >= 6 correspondences)");
     }
@@ -340,12 +341,12 @@ int slamx_pnp_ransac(slamx_ctx* ctx, const double* p3d, const double* p2d, int n
         }
     }
     return slamx_pnp_from_samples(ctx, p3d, p2d, n, K, table.data(), iterations, threshold, R, t, max_inliers);
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ f3: essential matrix by RANSAC, one frame pair
 int slamx_essential_from_samples(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K,
                                  const int32_t* idx, int iterations, double threshold_px, double* E, int32_t* n_inliers,
-                                 uint8_t* inlier_mask) {
+                                 uint8_t* inlier_mask) try {
     if (iterations <= 0 || iterations > 65536 || pts1 == nullptr || pts2 == nullptr || K == nullptr || E == nullptr ||
         idx == nullptr || threshold_px <= 0.0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "essential ransac arguments invalid");
@@ -395,10 +396,10 @@ int slamx_essential_from_samples(slamx_ctx* ctx, const float* pts1, const float*
         *n_inliers = r.n_inliers;
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_essential_ransac(slamx_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K, int iterations,
-                           double threshold_px, uint32_t seed, double* E, int32_t* n_inliers, uint8_t* inlier_mask) {
+                           double threshold_px, uint32_t seed, double* E, int32_t* n_inliers, uint8_t* inlier_mask) try {
     if (iterations <= 0 || iterations > 65536) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "essential ransac arguments invalid");
     }
@@ -422,11 +423,11 @@ int slamx_essential_ransac(slamx_ctx* ctx, const float* pts1, const float* pts2,
         }
     }
     return slamx_essential_from_samples(ctx, pts1, pts2, n, K, table.data(), iterations, threshold_px, E, n_inliers, inlier_mask);
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ a13 / a14 with host pointers
 int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
-                       double* R, double* t, int32_t* front) {
+                       double* R, double* t, int32_t* front) try {
     if (n < 0 || E == nullptr || K == nullptr || R == nullptr || t == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "recover pose arguments invalid");
     }
@@ -470,10 +471,10 @@ int slamx_recover_pose(slamx_ctx* ctx, const double* E, const float* pts1, const
         std::memcpy(front, fr, sizeof(fr));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const float* pts1, const float* pts2, int n,
-                      float* x4, double* xyz) {
+                      float* x4, double* xyz) try {
     if (n < 0 || P1 == nullptr || P2 == nullptr || xyz == nullptr || (n > 0 && (pts1 == nullptr || pts2 == nullptr))) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "triangulate arguments invalid");
     }
@@ -503,10 +504,10 @@ int slamx_triangulate(slamx_ctx* ctx, const double* P1, const double* P2, const 
     HIP_TRY(hipMemcpyAsync(xyz, dxyz, N * 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ the pose stage of a batch
-int slamx_pose_create(slamx_batch* b, const slamx_pose_config* cfg, slamx_pose** out) {
+int slamx_pose_create(slamx_batch* b, const slamx_pose_config* cfg, slamx_pose** out) try {
     if (b == nullptr || cfg == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -524,7 +525,7 @@ int slamx_pose_create(slamx_batch* b, const slamx_pose_config* cfg, slamx_pose**
     SLAMX_TRY(pose_workspace(p.get(), b->shape.max_frames, cap, false));
     *out = p.release();
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_pose_destroy(slamx_pose* p) {
     if (p == nullptr) {
@@ -535,7 +536,7 @@ void slamx_pose_destroy(slamx_pose* p) {
     pose_free(p);
 }
 
-int slamx_batch_pose(slamx_pose* p, int nframes, int first_train_frame) {
+int slamx_batch_pose(slamx_pose* p, int nframes, int first_train_frame) try {
     if (p == nullptr || p->batch == nullptr || nframes < 0 || nframes > p->slots || first_train_frame >= p->slots) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "batch_pose: nframes / first_train_frame out of range");
     }
@@ -594,9 +595,9 @@ int slamx_batch_pose(slamx_pose* p, int nframes, int first_train_frame) {
     }
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download(slamx_pose* p, int nframes, slamx_pose_result* out) {
+int slamx_pose_download(slamx_pose* p, int nframes, slamx_pose_result* out) try {
     if (p == nullptr || out == nullptr || nframes < 0 || nframes > p->slots) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download: arguments invalid");
     }
@@ -605,9 +606,9 @@ int slamx_pose_download(slamx_pose* p, int nframes, slamx_pose_result* out) {
                            p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download_points(slamx_pose* p, int frame, double* xyz, uint8_t* inlier_mask, int cap, int* n) {
+int slamx_pose_download_points(slamx_pose* p, int frame, double* xyz, uint8_t* inlier_mask, int cap, int* n) try {
     if (p == nullptr || frame < 0 || frame >= p->slots || n == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_points: arguments invalid");
     }
@@ -630,9 +631,9 @@ int slamx_pose_download_points(slamx_pose* p, int frame, double* xyz, uint8_t* i
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download_samples(slamx_pose* p, int frame, int32_t* idx, int32_t* pnp_idx) {
+int slamx_pose_download_samples(slamx_pose* p, int frame, int32_t* idx, int32_t* pnp_idx) try {
     if (p == nullptr || frame < 0 || frame >= p->slots) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_samples: arguments invalid");
     }
@@ -648,9 +649,9 @@ int slamx_pose_download_samples(slamx_pose* p, int frame, int32_t* idx, int32_t*
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int32_t* counts) {
+int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int32_t* counts) try {
     if (p == nullptr || frame < 0 || frame >= p->slots) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_hypotheses: arguments invalid");
     }
@@ -665,9 +666,9 @@ int slamx_pose_download_hypotheses(slamx_pose* p, int frame, double* E_all, int3
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download_pnp_hypotheses(slamx_pose* p, int frame, double* Rt_all, double* null_all, int32_t* counts) {
+int slamx_pose_download_pnp_hypotheses(slamx_pose* p, int frame, double* Rt_all, double* null_all, int32_t* counts) try {
     if (p == nullptr || frame < 0 || frame >= p->slots || p->prm.pnp_iterations <= 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_pnp_hypotheses: arguments invalid (or no PnP step configured)");
     }
@@ -685,9 +686,9 @@ int slamx_pose_download_pnp_hypotheses(slamx_pose* p, int frame, double* Rt_all,
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, double* p2d, int cap, int* n) {
+int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, double* p2d, int cap, int* n) try {
     if (p == nullptr || frame < 0 || frame >= p->slots || n == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_download_correspondences: arguments invalid");
     }
@@ -709,9 +710,9 @@ int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, d
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_set_profiling(slamx_pose* p, int on) {
+int slamx_pose_set_profiling(slamx_pose* p, int on) try {
     if (p == nullptr || on < 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_set_profiling: arguments invalid");
     }
@@ -727,9 +728,9 @@ int slamx_pose_set_profiling(slamx_pose* p, int on) {
         p->ev.push_back(e);
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pose_stage_ms(slamx_pose* p, float* avg_ms, int32_t* launches) {
+int slamx_pose_stage_ms(slamx_pose* p, float* avg_ms, int32_t* launches) try {
     if (p == nullptr || avg_ms == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pose_stage_ms: arguments invalid");
     }
@@ -749,10 +750,10 @@ int slamx_pose_stage_ms(slamx_pose* p, float* avg_ms, int32_t* launches) {
         }
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_batch_upload_results(slamx_batch* b, int frame, const slamx_keypoint* kps, int n_kp, const slamx_match* matches,
-                               int n_matches) {
+                               int n_matches) try {
     if (b == nullptr || frame < 0 || frame >= b->shape.max_frames || n_kp < 0 || n_kp > b->v.maxK || n_matches < 0 ||
         n_matches > b->v.maxK || (n_kp > 0 && kps == nullptr) || (n_matches > 0 && matches == nullptr)) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload_results: frame / counts out of range");
@@ -765,14 +766,7 @@ int slamx_batch_upload_results(slamx_batch* b, int frame, const slamx_keypoint* 
     }
     HIP_TRY(hipSetDevice(b->det->ctx->device));
     hipStream_t s = b->det->ctx->stream;
-    const size_t F = static_cast<size_t>(b->shape.max_frames);
-    if (b->matches == nullptr) {
-        SLAMX_TRY(dev_alloc(&b->matches, F * b->v.maxK));
-        SLAMX_TRY(dev_alloc(&b->n_matches, F));
-        SLAMX_TRY(dev_alloc(&b->best, F * MATCH_MAX_SPLIT * b->v.maxK));
-        SLAMX_TRY(dev_alloc(&b->second, F * MATCH_MAX_SPLIT * b->v.maxK));
-        HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), s));
-    }
+    SLAMX_TRY(batch_match_arrays(b, s));
     const size_t base = static_cast<size_t>(frame) * b->v.maxK;
     if (n_kp > 0) {
         HIP_TRY(hipMemcpyAsync(b->v.kps + base, kps, static_cast<size_t>(n_kp) * sizeof(slamx_keypoint), hipMemcpyHostToDevice, s));
@@ -784,6 +778,6 @@ int slamx_batch_upload_results(slamx_batch* b, int frame, const slamx_keypoint* 
     HIP_TRY(hipMemcpyAsync(b->n_matches + frame, &n_matches, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // pageable host memory: consumed when the call returns
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 }  // extern "C"

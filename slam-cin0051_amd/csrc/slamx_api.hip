@@ -343,16 +343,16 @@ const char* slamx_last_error(void) { return slamx::last_error_slot().c_str(); }
 const char* slamx_version(void) { return "slamx 0.2 (gfx950)"; }
 int slamx_matcher_mfma_threshold(void) { return match_mfma_min_keypoints(); }
 
-int slamx_device_count(void) {
+int slamx_device_count(void) try {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     return count;
-}
+} SLAMX_CATCH
 
-int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
+int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) try {
     if (out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "out is null");
     }
@@ -391,7 +391,7 @@ int slamx_ctx_create(int device_ordinal, void* hip_stream, slamx_ctx** out) {
     }
     *out = c;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_ctx_destroy(slamx_ctx* ctx) {
     if (ctx == nullptr) {
@@ -434,30 +434,30 @@ void slamx_ctx_destroy(slamx_ctx* ctx) {
     delete ctx;
 }
 
-int slamx_ctx_synchronize(slamx_ctx* ctx) {
+int slamx_ctx_synchronize(slamx_ctx* ctx) try {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 void* slamx_ctx_stream(slamx_ctx* ctx) { return ctx->stream; }
-int slamx_ctx_device_name(slamx_ctx* ctx, char* buf, int cap) {
+int slamx_ctx_device_name(slamx_ctx* ctx, char* buf, int cap) try {
     if (buf == nullptr || cap <= 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "buffer");
     }
     std::snprintf(buf, static_cast<size_t>(cap), "%s", ctx->name.c_str());
     return SLAMX_OK;
-}
-int slamx_ctx_timer_start(slamx_ctx* ctx) {
+} SLAMX_CATCH
+int slamx_ctx_timer_start(slamx_ctx* ctx) try {
     HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
     return SLAMX_OK;
-}
-int slamx_ctx_timer_stop_ms(slamx_ctx* ctx, float* ms) {
+} SLAMX_CATCH
+int slamx_ctx_timer_stop_ms(slamx_ctx* ctx, float* ms) try {
     HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->t1));
     HIP_TRY(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out) {
+int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out) try {
     YamlFile y;
     if (yaml_path == nullptr || !y.open(yaml_path)) {
         return fail(SLAMX_ERR_RUNTIME,
@@ -470,9 +470,9 @@ int slamx_detector_config_load(const char* yaml_path, slamx_detector_config* out
     out->patch_size = y.get_int("PatchSize");
     out->num_brief_pairs = y.get_int("NumBRIEFPairs");
     return validate_detector_config(*out);
-}
+} SLAMX_CATCH
 
-int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out) {
+int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out) try {
     YamlFile y;
     if (yaml_path == nullptr || !y.open(yaml_path)) {
         return fail(SLAMX_ERR_RUNTIME,
@@ -491,9 +491,9 @@ int slamx_matcher_config_load(const char* yaml_path, slamx_matcher_config* out) 
     out->use_ratio_test = y.get_int("UseRatioTest");
     out->ratio_test_threshold = static_cast<float>(y.get_double("RatioTestThreshold"));
     return SLAMX_OK;  // range checks happen in slamx_matcher_create, as in the constructor
-}
+} SLAMX_CATCH
 
-int slamx_loop_closure_config_load(const char* yaml_path, slamx_loop_closure_config* out) {
+int slamx_loop_closure_config_load(const char* yaml_path, slamx_loop_closure_config* out) try {
     YamlFile y;
     if (yaml_path == nullptr || out == nullptr || !y.open(yaml_path)) {
         return fail(SLAMX_ERR_RUNTIME,
@@ -535,9 +535,9 @@ int slamx_loop_closure_config_load(const char* yaml_path, slamx_loop_closure_con
         return fail(SLAMX_ERR_RUNTIME, "'RansacReprojectionThreshold' must be a positive value.");
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slamx_detector** out) {
+int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slamx_detector** out) try {
     if (ctx == nullptr || cfg == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -582,7 +582,7 @@ int slamx_detector_create(slamx_ctx* ctx, const slamx_detector_config* cfg, slam
     }
     *out = d;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_detector_destroy(slamx_detector* det) {
     if (det == nullptr) {
@@ -597,7 +597,7 @@ void slamx_detector_destroy(slamx_detector* det) {
     delete det;
 }
 
-int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pairs, int* n_pairs) {
+int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pairs, int* n_pairs) try {
     const int n = static_cast<int>(det->pattern.size() / 4);
     if (n_pairs != nullptr) {
         *n_pairs = n;
@@ -607,12 +607,12 @@ int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pair
         std::memcpy(xy4, det->pattern.data(), static_cast<size_t>(m) * 4 * sizeof(int32_t));
     }
     return n <= cap_pairs || xy4 == nullptr ? SLAMX_OK : fail(SLAMX_ERR_CAPACITY, "pattern buffer too small");
-}
+} SLAMX_CATCH
 
 int slamx_detector_descriptor_width(const slamx_detector* det) { return det->cfg.num_brief_pairs / 8; }
 
 // ------------------------------------------------------------------ batches
-int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slamx_batch** out) {
+int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slamx_batch** out) try {
     if (det == nullptr || shape == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -707,7 +707,7 @@ int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slam
     }
     *out = b;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_batch_destroy(slamx_batch* b) {
     if (b == nullptr) {
@@ -769,7 +769,7 @@ uint8_t* slamx_batch_frames(slamx_batch* b, size_t* pitch, size_t* frame_stride)
 }
 
 int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
-                       ptrdiff_t frame_stride) {
+                       ptrdiff_t frame_stride) try {
     if (first < 0 || n < 0 || first + n > b->shape.max_frames || host == nullptr || stride < b->v.cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload range/stride invalid");
     }
@@ -783,16 +783,16 @@ int slamx_batch_upload(slamx_batch* b, int first, int n, const uint8_t* host, pt
     // (measured: a buffer overwritten right after the call corrupts 99 of 100 uploads)
     HIP_TRY(hipStreamSynchronize(b->det->ctx->stream));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_host_alloc(size_t bytes, void** out) {
+int slamx_host_alloc(size_t bytes, void** out) try {
     if (out == nullptr || bytes == 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "host_alloc: out is null or size is 0");
     }
     *out = nullptr;
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_host_free(void* p) {
     if (p != nullptr) {
@@ -801,7 +801,7 @@ void slamx_host_free(void* p) {
 }
 
 int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
-                             ptrdiff_t frame_stride) {
+                             ptrdiff_t frame_stride) try {
     if (first < 0 || n < 0 || first + n > b->shape.max_frames || host == nullptr || stride < b->v.cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload range/stride invalid");
     }
@@ -848,9 +848,9 @@ int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* ho
         HIP_TRY(hipStreamWaitEvent(c->stream, c->e_copy_after, 0));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
+int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) try {
     if (nframes < 0 || nframes > b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
     }
@@ -883,10 +883,10 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) {
     b->last_frames = nframes;
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints,
-                                  int first_train_frame) {
+                                  int first_train_frame) try {
     if (nframes < 0 || nframes > b->shape.max_frames || first_train_frame >= b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes / first_train_frame out of range");
     }
@@ -895,13 +895,7 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     }
     HIP_TRY(hipSetDevice(b->det->ctx->device));
     const size_t F = static_cast<size_t>(b->shape.max_frames);
-    if (b->matches == nullptr) {
-        SLAMX_TRY(dev_alloc(&b->matches, F * b->v.maxK));
-        SLAMX_TRY(dev_alloc(&b->n_matches, F));
-        SLAMX_TRY(dev_alloc(&b->best, F * MATCH_MAX_SPLIT * b->v.maxK));
-        SLAMX_TRY(dev_alloc(&b->second, F * MATCH_MAX_SPLIT * b->v.maxK));
-        HIP_TRY(hipMemsetAsync(b->n_matches, 0, F * sizeof(int), b->det->ctx->stream));
-    }
+    SLAMX_TRY(batch_match_arrays(b, b->det->ctx->stream));
     const int pattern_len = static_cast<int>(b->det->pattern.size() / 4);
     // Two all-pairs scans with identical results (match.hip): int8 matrix cores in spatial order, and xor + popcount.
     // Which is faster depends on the size of the train set and on how far its keypoints spread (slamx_internal.h:
@@ -944,9 +938,9 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
     record(b, 12);
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches) {
+int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches) try {
     if (nframes < 0 || nframes > b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
     }
@@ -977,9 +971,9 @@ int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32
         SLAMX_TRY(status_to_error(status[static_cast<size_t>(f)], f));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t* desc, int cap, int* n) try {
     if (frame < 0 || frame >= b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range");
     }
@@ -1005,10 +999,10 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
                           static_cast<size_t>(cnt) * b->v.width, hipMemcpyDeviceToHost));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoint* kps, uint8_t* desc, slamx_match* matches,
-                                       int32_t* n_keypoints, int32_t* n_matches) {
+                                       int32_t* n_keypoints, int32_t* n_matches) try {
     if (b == nullptr || nframes < 0 || nframes > b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes out of range");
     }
@@ -1049,7 +1043,7 @@ int slamx_batch_download_results_async(slamx_batch* b, int nframes, slamx_keypoi
         HIP_TRY(hipMemcpyAsync(n_matches, b->n_matches, n * sizeof(int), hipMemcpyDeviceToHost, s));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 size_t slamx_batch_packed_bound(slamx_batch* b, int nframes) {
     if (b == nullptr || nframes < 0 || nframes > b->shape.max_frames) {
@@ -1058,7 +1052,7 @@ size_t slamx_batch_packed_bound(slamx_batch* b, int nframes) {
     return packed_bound_bytes(nframes, b->v.maxK, b->v.width, true);
 }
 
-int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, size_t bytes) {
+int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, size_t bytes) try {
     if (b == nullptr || nframes <= 0 || nframes > b->shape.max_frames || host == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_async: nframes out of range or no host buffer");
     }
@@ -1100,9 +1094,9 @@ int slamx_batch_download_packed_async(slamx_batch* b, int nframes, void* host, s
     // 21.6 against 12.3 ms per 256-frame c3 batch end to end)
     HIP_TRY(hipMemcpyAsync(host, b->pack, std::min(bytes, bound), hipMemcpyDeviceToHost, s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, size_t host_capacity) {
+int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, size_t host_capacity) try {
     if (b == nullptr || host == nullptr || b->pack == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "download_packed_tail: nothing has been packed on this batch");
     }
@@ -1119,9 +1113,9 @@ int slamx_batch_download_packed_tail(slamx_batch* b, void* host, size_t from, si
         HIP_TRY(hipMemcpy(static_cast<uint8_t*>(host) + from, b->pack + from, total - from, hipMemcpyDeviceToHost));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride) {
+int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride) try {
     if (frame < 0 || frame >= b->shape.max_frames || out == nullptr || stride < b->v.cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or output buffer invalid");
     }
@@ -1130,10 +1124,10 @@ int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* 
     HIP_TRY(hipMemcpy2D(out, static_cast<size_t>(stride), src, static_cast<size_t>(b->v.pitch),
                         static_cast<size_t>(b->v.cols), static_cast<size_t>(b->v.rows), hipMemcpyDeviceToHost));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
-                                 int cap, int* n) {
+                                 int cap, int* n) try {
     if (frame < 0 || frame >= b->shape.max_frames || b->matches == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "frame out of range or no matches computed");
     }
@@ -1158,13 +1152,13 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
         std::memcpy(out, v.data(), sizeof(slamx_match) * v.size());
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_set_profiling(slamx_batch* b, int n_sets) {
+int slamx_batch_set_profiling(slamx_batch* b, int n_sets) try {
     return slamx_batch_set_profiling_every(b, n_sets, 1);
-}
+} SLAMX_CATCH
 
-int slamx_batch_set_profiling_every(slamx_batch* b, int n_sets, int every) {
+int slamx_batch_set_profiling_every(slamx_batch* b, int n_sets, int every) try {
     if (every < 1) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "profiling stride must be at least 1");
     }
@@ -1189,9 +1183,9 @@ int slamx_batch_set_profiling_every(slamx_batch* b, int n_sets, int every) {
         HIP_TRY(hipEventCreate(&e));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms) {
+int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms) try {
     if (set_index < 0 || set_index >= b->n_sets) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "profiling set out of range");
     }
@@ -1207,11 +1201,11 @@ int slamx_batch_stage_ms(slamx_batch* b, int set_index, float* ms) {
         }
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ single-frame host API
 int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
-                 int cap, int* n) {
+                 int cap, int* n) try {
     SLAMX_TRY(check_image(img, rows, cols, stride));
     for (int attempt = 0;; ++attempt) {
         SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
@@ -1227,10 +1221,10 @@ int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, pt
         }
         return rc;
     }
-}
+} SLAMX_CATCH
 
 int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, slamx_keypoint* kps,
-                  int n, uint8_t* desc) {
+                  int n, uint8_t* desc) try {
     if (n < 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "negative keypoint count");
     }
@@ -1254,10 +1248,10 @@ int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, p
     HIP_TRY(hipGetLastError());
     int cnt = 0;
     return slamx_batch_download(b, 0, kps, desc, n, &cnt);
-}
+} SLAMX_CATCH
 
 int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
-                             slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+                             slamx_keypoint* kps, uint8_t* desc, int cap, int* n) try {
     SLAMX_TRY(check_image(img, rows, cols, stride));
     for (int attempt = 0;; ++attempt) {
         SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
@@ -1271,10 +1265,10 @@ int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, 
         }
         return rc;
     }
-}
+} SLAMX_CATCH
 
 int slamx_fast_candidates(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
-                          slamx_keypoint* kps, int cap, int* n) {
+                          slamx_keypoint* kps, int cap, int* n) try {
     SLAMX_TRY(check_image(img, rows, cols, stride));
     hipStream_t s = det->ctx->stream;
     const DetectorParams p = params_of(det);
@@ -1318,9 +1312,9 @@ int slamx_fast_candidates(slamx_detector* det, const uint8_t* img, int rows, int
         kps[i].response = static_cast<float>(keys[static_cast<size_t>(i)] >> SCORE_SHIFT);
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, uint8_t* out) {
+int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride, uint8_t* out) try {
     SLAMX_TRY(check_image(img, rows, cols, stride));
     SLAMX_TRY(ensure_single(det, rows, cols, 0));
     slamx_batch* b = det->single;
@@ -1332,9 +1326,9 @@ int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int c
                              static_cast<size_t>(cols), static_cast<size_t>(rows), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out) {
+int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out) try {
     if (n < 0 || n > MAX_CANDIDATES_HARD) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "n out of range");
     }
@@ -1389,10 +1383,10 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
         perm_out[i] = keys[static_cast<size_t>(i)] & INDEX_MASK;
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, float* angle_deg, float* cos_out,
-                     float* sin_out) {
+                     float* sin_out) try {
     if (n <= 0) {
         return SLAMX_OK;
     }
@@ -1426,10 +1420,10 @@ int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, 
         return fail(SLAMX_ERR_HIP, std::string("debug trig: ") + hipGetErrorString(e));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_debug_penalty(slamx_ctx* ctx, const int32_t* dist, const float* qx, const float* qy, const float* tx,
-                        const float* ty, int n, int32_t* out) {
+                        const float* ty, int n, int32_t* out) try {
     if (n <= 0) {
         return SLAMX_OK;
     }
@@ -1458,10 +1452,10 @@ int slamx_debug_penalty(slamx_ctx* ctx, const int32_t* dist, const float* qx, co
         return fail(SLAMX_ERR_HIP, std::string("debug penalty: ") + hipGetErrorString(e));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ matcher
-int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out) {
+int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_matcher** out) try {
     if (ctx == nullptr || cfg == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -1487,7 +1481,7 @@ int slamx_matcher_create(slamx_ctx* ctx, const slamx_matcher_config* cfg, slamx_
     m->cfg = *cfg;
     *out = m;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_matcher_destroy(slamx_matcher* m) {
     if (m == nullptr) {
@@ -1508,7 +1502,7 @@ void slamx_matcher_destroy(slamx_matcher* m) {
 
 int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1, const uint8_t* d2, int n2, int width2,
                 const slamx_keypoint* kp1, int nkp1, const slamx_keypoint* kp2, int nkp2, slamx_match* out, int cap,
-                int* n) {
+                int* n) try {
     if (n != nullptr) {
         *n = 0;
     }
@@ -1669,7 +1663,7 @@ int slamx_matcher_match(slamx_matcher* m, const uint8_t* d1, int n1, int width1,
         std::memcpy(out, v.data(), sizeof(slamx_match) * v.size());
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // (the pose solves -- slamx_pnp_* / slamx_essential_ransac / slamx_recover_pose / slamx_triangulate / slamx_pose_* --
 // live in pose_api.hip)
@@ -1710,7 +1704,7 @@ std::vector<uint32_t> scale_table(int dst, int src) {
 extern "C" {
 
 int slamx_pyramid_create(slamx_detector* det, const slamx_batch_shape* shape, int n_levels, double scale_factor,
-                         slamx_pyramid** out) {
+                         slamx_pyramid** out) try {
     if (det == nullptr || shape == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -1779,7 +1773,7 @@ int slamx_pyramid_create(slamx_detector* det, const slamx_batch_shape* shape, in
     }
     *out = p;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_pyramid_destroy(slamx_pyramid* p) {
     if (p == nullptr) {
@@ -1804,7 +1798,7 @@ slamx_batch* slamx_pyramid_batch(slamx_pyramid* p, int level) {
     return p->levels[static_cast<size_t>(level)];
 }
 
-int slamx_pyramid_level_shape(const slamx_pyramid* p, int level, int* rows, int* cols, double* scale) {
+int slamx_pyramid_level_shape(const slamx_pyramid* p, int level, int* rows, int* cols, double* scale) try {
     if (p == nullptr || level < 0 || level >= static_cast<int>(p->levels.size())) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: level out of range");
     }
@@ -1819,9 +1813,9 @@ int slamx_pyramid_level_shape(const slamx_pyramid* p, int level, int* rows, int*
         *scale = p->scale[static_cast<size_t>(level)];
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_pyramid_detect_and_compute(slamx_pyramid* p, int nframes) {
+int slamx_pyramid_detect_and_compute(slamx_pyramid* p, int nframes) try {
     if (p == nullptr || nframes < 0 || nframes > p->levels[0]->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "pyramid: nframes out of range");
     }
@@ -1849,7 +1843,7 @@ int slamx_pyramid_detect_and_compute(slamx_pyramid* p, int nframes) {
     }
     HIP_TRY(hipGetLastError());
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ sliding-window Gauss-Newton (gn.hip)
 }  // extern "C"
@@ -1933,7 +1927,7 @@ int gn_check_step_args(const slamx_gn* g, const double* K, double lambda, int n_
 
 extern "C" {
 
-int slamx_gn_create(slamx_ctx* ctx, int n_windows, int n_cams, int max_landmarks, slamx_gn** out) {
+int slamx_gn_create(slamx_ctx* ctx, int n_windows, int n_cams, int max_landmarks, slamx_gn** out) try {
     if (ctx == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
     }
@@ -1969,7 +1963,7 @@ int slamx_gn_create(slamx_ctx* ctx, int n_windows, int n_cams, int max_landmarks
     }
     *out = g;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_gn_destroy(slamx_gn* g) {
     if (g == nullptr) {
@@ -1994,7 +1988,7 @@ void slamx_gn_destroy(slamx_gn* g) {
     delete g;
 }
 
-int slamx_gn_set_profiling(slamx_gn* g, int on) {
+int slamx_gn_set_profiling(slamx_gn* g, int on) try {
     if (g == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
     }
@@ -2006,9 +2000,9 @@ int slamx_gn_set_profiling(slamx_gn* g, int on) {
         u = 0;
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_gn_stage_ms(slamx_gn* g, float* avg_ms, int32_t* launches) {
+int slamx_gn_stage_ms(slamx_gn* g, float* avg_ms, int32_t* launches) try {
     if (g == nullptr || avg_ms == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
     }
@@ -2029,10 +2023,10 @@ int slamx_gn_stage_ms(slamx_gn* g, float* avg_ms, int32_t* launches) {
         }
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_gn_upload(slamx_gn* g, const double* poses, const double* landmarks, const float* obs,
-                    const int32_t* n_landmarks) {
+                    const int32_t* n_landmarks) try {
     if (g == nullptr || poses == nullptr || landmarks == nullptr || obs == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
     }
@@ -2057,9 +2051,9 @@ int slamx_gn_upload(slamx_gn* g, const double* poses, const double* landmarks, c
     HIP_TRY(hipStreamSynchronize(s));  // pageable sources: the caller may reuse them on return
     g->last_iterations = -1;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_gn_iterate(slamx_gn* g, const double* K, double lambda, int n_fixed, int iterations) {
+int slamx_gn_iterate(slamx_gn* g, const double* K, double lambda, int n_fixed, int iterations) try {
     SLAMX_TRY(gn_check_step_args(g, K, lambda, n_fixed));
     if (iterations < 0 || iterations > SLAMX_GN_MAX_ITERATIONS) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: iterations must be in [0, 64]");
@@ -2086,9 +2080,9 @@ int slamx_gn_iterate(slamx_gn* g, const double* K, double lambda, int n_fixed, i
     HIP_TRY(hipGetLastError());
     g->last_iterations = iterations;
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
-int slamx_gn_download(slamx_gn* g, double* poses, double* landmarks, double* cost, int32_t* status) {
+int slamx_gn_download(slamx_gn* g, double* poses, double* landmarks, double* cost, int32_t* status) try {
     if (g == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "gn: null argument");
     }
@@ -2120,10 +2114,10 @@ int slamx_gn_download(slamx_gn* g, double* poses, double* landmarks, double* cos
         HIP_TRY(hipMemcpy(status, g->status, nw * sizeof(int), hipMemcpyDeviceToHost));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_gn_normal_equations(slamx_gn* g, const double* K, double lambda, int n_fixed, double* S, double* gvec,
-                              double* delta, double* cost) {
+                              double* delta, double* cost) try {
     SLAMX_TRY(gn_check_step_args(g, K, lambda, n_fixed));
     HIP_TRY(hipSetDevice(g->ctx->device));
     hipStream_t s = g->ctx->stream;
@@ -2155,10 +2149,10 @@ int slamx_gn_normal_equations(slamx_gn* g, const double* K, double lambda, int n
         HIP_TRY(hipMemcpy(cost, a.cost, nw * sizeof(double), hipMemcpyDeviceToHost));
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ camera
-int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out) {
+int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out) try {
     YamlFile y;
     if (yaml_path == nullptr || !y.open(yaml_path)) {
         return fail(SLAMX_ERR_RUNTIME, std::string("Could not open calibration file: ") + (yaml_path ? yaml_path : "(null)"));
@@ -2191,10 +2185,10 @@ int slamx_camera_load(const char* yaml_path, int camera_index, slamx_camera* out
         out->height = static_cast<int32_t>(sz->seq[1]);
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_undistort(slamx_ctx* ctx, const slamx_camera* cam, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
-                    double* out) {
+                    double* out) try {
     if (cam == nullptr || out == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "null argument");
     }
@@ -2220,10 +2214,10 @@ int slamx_undistort(slamx_ctx* ctx, const slamx_camera* cam, const uint8_t* img,
     HIP_TRY(hipMemcpyAsync(out, dout.p, static_cast<size_t>(rows) * cols * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 // ------------------------------------------------------------------ synthetic frames (host)
-int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max, uint8_t* out) {
+int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int rect_min, int rect_max, uint8_t* out) try {
     if (rows <= 0 || cols <= 0 || out == nullptr || rect_min <= 0 || rect_max < rect_min || k < 0 || n_rect < 0) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "synthetic frame arguments invalid");
     }
@@ -2257,11 +2251,11 @@ int slamx_synth_frame(uint64_t seed, int k, int rows, int cols, int n_rect, int 
         }
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 
 // ---------------------------------------------------------------- map-point all-gather over RCCL
-int slamx_mapgather_plan(const int32_t* counts, int world, int* padded_cap, int* total) {
+int slamx_mapgather_plan(const int32_t* counts, int world, int* padded_cap, int* total) try {
     if (counts == nullptr || world < 1) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_plan: no counts");
     }
@@ -2284,10 +2278,10 @@ int slamx_mapgather_plan(const int32_t* counts, int world, int* padded_cap, int*
         *total = static_cast<int>(sum);
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_mapgather_unpack(const double* padded, const int32_t* counts, int world, int padded_cap, double* out,
-                           int cap_points) {
+                           int cap_points) try {
     int cap = 0, total = 0;
     SLAMX_TRY(slamx_mapgather_plan(counts, world, &cap, &total));
     if (padded == nullptr || padded_cap < cap) {
@@ -2305,7 +2299,7 @@ int slamx_mapgather_unpack(const double* padded, const int32_t* counts, int worl
         at += n;
     }
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 }  // extern "C" (C++ helpers of the gather follow)
 
@@ -2384,7 +2378,7 @@ struct slamx_mapgather {
 
 extern "C" {
 
-int slamx_mapgather_unique_id(uint8_t id[SLAMX_MAPGATHER_ID_BYTES]) {
+int slamx_mapgather_unique_id(uint8_t id[SLAMX_MAPGATHER_ID_BYTES]) try {
     if (id == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_unique_id: null");
     }
@@ -2395,10 +2389,10 @@ int slamx_mapgather_unique_id(uint8_t id[SLAMX_MAPGATHER_ID_BYTES]) {
     RCCL_TRY(rccl().GetUniqueId(&u));
     std::memcpy(id, u.internal, SLAMX_MAPGATHER_ID_BYTES);
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_BYTES], int rank, int world,
-                           slamx_mapgather** out) {
+                           slamx_mapgather** out) try {
     if (ctx == nullptr || id == nullptr || out == nullptr || world < 1 || rank < 0 || rank >= world) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_create: bad context / id / rank / world");
     }
@@ -2428,7 +2422,7 @@ int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_B
     }
     *out = g.release();
     return SLAMX_OK;
-}
+} SLAMX_CATCH
 
 void slamx_mapgather_destroy(slamx_mapgather* g) {
     if (g == nullptr) {
@@ -2446,7 +2440,7 @@ void slamx_mapgather_destroy(slamx_mapgather* g) {
 }
 
 int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts, double* out,
-                              int cap_points, int* total) {
+                              int cap_points, int* total) try {
     if (g == nullptr || n_points < 0 || (xyz == nullptr && n_points > 0) || counts == nullptr) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_allgather: bad arguments");
     }
@@ -2546,6 +2540,6 @@ int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_point
     HIP_TRY(hipStreamSynchronize(s));
     // 4. unpack (reports a too small `out` only now: no rank may leave before the collectives)
     return slamx_mapgather_unpack(g->h_recv.data(), counts, g->world, cap, out, cap_points);
-}
+} SLAMX_CATCH
 
 }  // extern "C"
