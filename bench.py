@@ -59,7 +59,9 @@ WORKLOADS = {
                desc="1920x1080, ~10k keypoints/frame (SuppressionWindowSize 8), detect+describe+match-to-previous"),
     # configs[2] as BASELINE.json words it: "1920x1080 8-level pyramid, 10k feats/frame" -- the pyramid is a build-side
     # extension (the reference has none), levels >= 1 are parity-unpinned; reported separately from c3
-    "c3p": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=256, max_cand=32768, max_kp=16384,
+    # (512 frames per step since round 4: two NMS workgroups share a CU and the sorts run two full rounds -- 21.1k ->
+    # 22.8k frames/s against 256 frames per step, the packing a single launch over all levels would give)
+    "c3p": dict(rows=1080, cols=1920, window=12, n_rect=6800, rmin=3, rmax=24, batch=512, max_cand=32768, max_kp=16384,
                 levels=8, scale=1.2,
                 desc="1920x1080, 8-level pyramid (scale 1.2), ~12k keypoints/frame over all levels (the default workload's frames, "
                      "shipped YAML), detect+describe on every level + match-to-previous on the merged sets"),
