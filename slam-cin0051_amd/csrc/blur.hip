@@ -37,7 +37,8 @@ constexpr int HALO = 2;
 constexpr int LDS_ROW_DW = 64;               // columns [X0-4, X0+252) as dwords, one per lane
 constexpr int LDS_ROWS = TILE_H + 2 * HALO;  // 36
 constexpr int ROWS_PER_WAVE = TILE_H / 4;
-constexpr int FIX_PER_WAVE = 512;            // uncertain dwords listed per wave; beyond: whole tile exact
+constexpr int FIX_PER_WAVE = 512;            // uncertain dwords listed per wave: at most ROWS_PER_WAVE x 62 = 496, a list cannot overflow
+static_assert(ROWS_PER_WAVE * 62 <= FIX_PER_WAVE, "every output dword of a wave must fit its list");
 // |frac(estimate) - 0.5| <= 6e-4 sends a pixel to the exact pass; tested as
 // frac(estimate - UNC_LO) <= UNC_SPAN, widened by 5e-5 for the rounding of that subtraction
 constexpr float UNC_LO = 0.5f - 6.5e-4f;
@@ -210,9 +211,7 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
                     if (m != 0) {
                         const int pos = listed_here + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
-                        if (pos < FIX_PER_WAVE) {
-                            fix[wave][pos] = static_cast<uint16_t>(ry << 10 | lane << 4 | static_cast<int>(m));
-                        }
+                        fix[wave][pos] = static_cast<uint16_t>(ry << 10 | lane << 4 | static_cast<int>(m));
                     }
                     listed_here += __popcll(b);
                 }
@@ -224,31 +223,19 @@ __global__ __launch_bounds__(256) void blur_kernel(BatchView v, const double* __
         nfix[wave] = listed_here;
     }
     __syncthreads();
-    // ---- exact pass on the listed pixels (or on the whole tile when a list overflowed)
+    // ---- exact pass on the listed pixels (every pixel of the tile when all of them are uncertain: two-level images)
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
     uint8_t* o8 = reinterpret_cast<uint8_t*>(outt);
     const int n0 = nfix[0], n1 = nfix[1], n2 = nfix[2], n3 = nfix[3];
-    if (max(max(n0, n1), max(n2, n3)) <= FIX_PER_WAVE) {
-        const int total = n0 + n1 + n2 + n3;
-        for (int s = threadIdx.x; s < total; s += 256) {
-            const int e = s < n0 ? fix[0][s] : s < n0 + n1 ? fix[1][s - n0] : s < n0 + n1 + n2 ? fix[2][s - n0 - n1] : fix[3][s - n0 - n1 - n2];
-            const int ry = e >> 10;
-            const int col = (e >> 4 & 63) * 4;  // byte column of the dword inside the LDS row
+    const int total = n0 + n1 + n2 + n3;
+    for (int s = threadIdx.x; s < total; s += 256) {
+        const int e = s < n0 ? fix[0][s] : s < n0 + n1 ? fix[1][s - n0] : s < n0 + n1 + n2 ? fix[2][s - n0 - n1] : fix[3][s - n0 - n1 - n2];
+        const int ry = e >> 10;
+        const int col = (e >> 4 & 63) * 4;  // byte column of the dword inside the LDS row
 #pragma nounroll
-            for (int m = e & 15; m != 0; m &= m - 1) {
-                const int c = col + __builtin_ctz(m);
-                o8[ry * (LDS_ROW_DW * 4) + c] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + c, weights));
-            }
-        }
-    } else {
-        for (int s = threadIdx.x; s < TILE_W * TILE_H; s += 256) {
-            const int ry = s / TILE_W;
-            const int col = s - ry * TILE_W + 4;
-            const int yy = ty * TILE_H + ry;
-            const int xx = tx * TILE_W - 4 + col;
-            if (yy >= HALO && yy < v.rows - HALO && xx >= HALO && xx < v.cols - HALO) {
-                o8[ry * (LDS_ROW_DW * 4) + col] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + col, weights));
-            }
+        for (int m = e & 15; m != 0; m &= m - 1) {
+            const int c = col + __builtin_ctz(m);
+            o8[ry * (LDS_ROW_DW * 4) + c] = static_cast<uint8_t>(exact_pixel(t8 + (ry + HALO) * (LDS_ROW_DW * 4) + c, weights));
         }
     }
     __syncthreads();
