@@ -27,8 +27,10 @@ namespace slamx {
 namespace {
 
 // circle offsets {dx,dy}, clockwise from 12 o'clock (feature_detector.hpp:138-153)
-__device__ __constant__ int8_t CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-__device__ __constant__ int8_t CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+// (constexpr, not __constant__: the 16 offsets fold into the immediate fields of the LDS byte reads -- as device
+// constants they were fetched and multiplied by the row stride with ~100 scalar instructions per tested pixel)
+constexpr int CIRC_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+constexpr int CIRC_DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 
 constexpr int TILE_W = FAST_TILE_W;
 constexpr int TILE_H = FAST_TILE_H;
