@@ -129,6 +129,12 @@ struct slamx_detector {
     uint2* moment_weights_dev = nullptr;  // moment_weight_table() for PatchSize / 2 <= 15
     double* weights_dev = nullptr;
     slamx_batch* single = nullptr;  // lazily created 1-frame batch behind the host-buffer API
+    // Page-locked staging of that batch (hipHostMalloc, grown on demand): [packed results | image rows | keypoints in].
+    // A host-buffer call copies its image (and keypoints) here, queues ONE asynchronous upload per array and the
+    // kernels behind it, lets the pack kernel write status, count, keypoints and descriptors back into the block and
+    // synchronises once (until round 4: a synchronous pageable upload and four synchronous copies back).
+    uint8_t* stage = nullptr;
+    size_t stage_bytes = 0;
 };
 
 struct slamx_matcher {

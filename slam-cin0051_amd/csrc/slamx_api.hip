@@ -280,6 +280,96 @@ bool single_can_grow(const slamx_detector* det, int rc, int rows, int cols) {
            b->v.maxM < single_capacity(rows, cols, true);
 }
 
+// The staging block of the one-frame batch (see slamx_detector::stage): out = the packed results (worst case of the
+// batch's capacity), img = rows x cols bytes, kps_in = the keypoints slamx_compute is given.
+struct SingleStage {
+    uint8_t* out = nullptr;
+    size_t out_bytes = 0;
+    uint8_t* img = nullptr;
+    slamx_keypoint* kps_in = nullptr;
+    int* n_in = nullptr;
+};
+int single_stage(slamx_detector* det, SingleStage* st) {
+    const slamx_batch* b = det->single;
+    const auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t out_bytes = up(packed_bound_bytes(1, b->v.maxK, b->v.width, true));
+    const size_t img_bytes = up(static_cast<size_t>(b->v.rows) * b->v.cols);
+    const size_t kps_bytes = up(static_cast<size_t>(b->v.maxK) * sizeof(slamx_keypoint));
+    const size_t want = out_bytes + img_bytes + kps_bytes + 256;
+    if (det->stage_bytes < want) {
+        HIP_TRY(hipStreamSynchronize(det->ctx->stream));
+        if (det->stage != nullptr) {
+            (void)hipHostFree(det->stage);
+            det->stage = nullptr;
+            det->stage_bytes = 0;
+        }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&det->stage), want, hipHostMallocDefault));
+        det->stage_bytes = want;
+    }
+    st->out = det->stage;
+    st->out_bytes = out_bytes;
+    st->img = det->stage + out_bytes;
+    st->kps_in = reinterpret_cast<slamx_keypoint*>(det->stage + out_bytes + img_bytes);
+    st->n_in = reinterpret_cast<int*>(det->stage + out_bytes + img_bytes + kps_bytes);
+    return SLAMX_OK;
+}
+
+// image -> staging block -> frame 0 of the one-frame batch (asynchronous: the block is page-locked and ours)
+int single_upload(slamx_detector* det, const SingleStage& st, const uint8_t* img, ptrdiff_t stride) {
+    slamx_batch* b = det->single;
+    const size_t cols = static_cast<size_t>(b->v.cols);
+    if (static_cast<size_t>(stride) == cols) {
+        std::memcpy(st.img, img, cols * b->v.rows);
+    } else {
+        for (int r = 0; r < b->v.rows; ++r) {
+            std::memcpy(st.img + r * cols, img + static_cast<ptrdiff_t>(r) * stride, cols);
+        }
+    }
+    HIP_TRY(hipMemcpy2DAsync(b->frames, static_cast<size_t>(b->v.pitch), st.img, cols, cols, static_cast<size_t>(b->v.rows),
+                             hipMemcpyHostToDevice, det->ctx->stream));
+    return SLAMX_OK;
+}
+
+// status, count, keypoints and descriptors of frame 0: packed into the staging block by the pack kernel, one
+// synchronisation, then plain copies into the caller's buffers.  Same results and errors as slamx_batch_download.
+int single_download(slamx_detector* det, const SingleStage& st, slamx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    slamx_batch* b = det->single;
+    hipStream_t s = det->ctx->stream;
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, st.out, 0) != hipSuccess || mapped == nullptr) {
+        (void)hipGetLastError();
+        return slamx_batch_download(b, 0, kps, desc, cap, n);  // (page-locked memory the device cannot address: the copies)
+    }
+    if (b->pack == nullptr) {
+        const size_t pcap = packed_bound_bytes(b->shape.max_frames, b->v.maxK, b->v.width, true);
+        SLAMX_TRY(dev_alloc(&b->pack, pcap));
+        b->pack_bytes = pcap;
+    }
+    launch_pack_results(b->v, b->matches, b->n_matches, 1, b->pack, s, static_cast<uint8_t*>(mapped), st.out_bytes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    slamx_packed_header h;
+    std::memcpy(&h, st.out, sizeof(h));
+    int status = 0;
+    std::memcpy(&status, st.out + h.status_off, sizeof(int));
+    b->last_status = status;
+    SLAMX_TRY(status_to_error(status, 0));
+    const int cnt = h.total_keypoints;
+    if (n != nullptr) {
+        *n = cnt;
+    }
+    if (cnt > cap) {
+        return fail(SLAMX_ERR_CAPACITY, "keypoint buffer too small");
+    }
+    if (kps != nullptr && cnt > 0) {
+        std::memcpy(kps, st.out + h.kps_off, sizeof(slamx_keypoint) * static_cast<size_t>(cnt));
+    }
+    if (desc != nullptr && cnt > 0) {
+        std::memcpy(desc, st.out + h.desc_off, static_cast<size_t>(cnt) * b->v.width);
+    }
+    return SLAMX_OK;
+}
+
 int check_image(const uint8_t* img, int rows, int cols, ptrdiff_t stride) {
     if (img == nullptr || rows <= 0 || cols <= 0 || stride < cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "image pointer/shape/stride invalid");
@@ -594,6 +684,9 @@ void slamx_detector_destroy(slamx_detector* det) {
     dev_free(det->pattern_dev);
     dev_free(det->moment_weights_dev);
     dev_free(det->weights_dev);
+    if (det->stage != nullptr) {
+        (void)hipHostFree(det->stage);
+    }
     delete det;
 }
 
@@ -1210,12 +1303,15 @@ int slamx_detect(slamx_detector* det, const uint8_t* img, int rows, int cols, pt
     for (int attempt = 0;; ++attempt) {
         SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
         slamx_batch* b = det->single;
-        SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+        HIP_TRY(hipSetDevice(det->ctx->device));
+        SingleStage st;
+        SLAMX_TRY(single_stage(det, &st));
+        SLAMX_TRY(single_upload(det, st, img, stride));
         HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), det->ctx->stream));
         begin_set(b);
         enqueue_detect(b, 1);
         HIP_TRY(hipGetLastError());
-        const int rc = slamx_batch_download(b, 0, kps, nullptr, cap, n);
+        const int rc = single_download(det, st, kps, nullptr, cap, n);
         if (attempt == 0 && single_can_grow(det, rc, rows, cols)) {
             continue;
         }
@@ -1238,16 +1334,20 @@ int slamx_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, p
     SLAMX_TRY(ensure_single(det, rows, cols, n));
     slamx_batch* b = det->single;
     hipStream_t s = det->ctx->stream;
-    SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
-    HIP_TRY(hipMemcpyAsync(b->v.kps, kps, sizeof(slamx_keypoint) * n, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(b->v.n_kp, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipSetDevice(det->ctx->device));
+    SingleStage st;
+    SLAMX_TRY(single_stage(det, &st));
+    SLAMX_TRY(single_upload(det, st, img, stride));
+    std::memcpy(st.kps_in, kps, sizeof(slamx_keypoint) * static_cast<size_t>(n));
+    *st.n_in = n;
+    HIP_TRY(hipMemcpyAsync(b->v.kps, st.kps_in, sizeof(slamx_keypoint) * static_cast<size_t>(n), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->v.n_kp, st.n_in, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), s));
-    HIP_TRY(hipStreamSynchronize(s));  // &n must stay alive until the copy is done
     begin_set(b);
     enqueue_compute(b, 1, false);
     HIP_TRY(hipGetLastError());
     int cnt = 0;
-    return slamx_batch_download(b, 0, kps, desc, n, &cnt);
+    return single_download(det, st, kps, desc, n, &cnt);
 } SLAMX_CATCH
 
 int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, int cols, ptrdiff_t stride,
@@ -1256,10 +1356,13 @@ int slamx_detect_and_compute(slamx_detector* det, const uint8_t* img, int rows, 
     for (int attempt = 0;; ++attempt) {
         SLAMX_TRY(ensure_single(det, rows, cols, 0, attempt > 0));
         slamx_batch* b = det->single;
-        SLAMX_TRY(slamx_batch_upload(b, 0, 1, img, stride, 0));
+        HIP_TRY(hipSetDevice(det->ctx->device));
+        SingleStage st;
+        SLAMX_TRY(single_stage(det, &st));
+        SLAMX_TRY(single_upload(det, st, img, stride));
         HIP_TRY(hipMemsetAsync(b->v.status, 0, sizeof(int), det->ctx->stream));
         SLAMX_TRY(slamx_batch_detect_and_compute(b, 1));
-        const int rc = slamx_batch_download(b, 0, kps, desc, cap, n);
+        const int rc = single_download(det, st, kps, desc, cap, n);
         if (attempt == 0 && single_can_grow(det, rc, rows, cols)) {
             continue;
         }
