@@ -49,6 +49,9 @@ public:
     FeatureDetector(const FeatureDetector&) = delete;
     FeatureDetector& operator=(const FeatureDetector&) = delete;
 
+    // (extension) the C-ABI handle, for the batch interface (slam::FrameBatch)
+    slamx_detector* handle() const { return m_handle; }
+
     // feature_detector.cpp:8-18
     void detect(const EigenGrayMatrix& image, std::vector<Keypoint>& keypoints) {
         keypoints.clear();

@@ -38,6 +38,9 @@ public:
     FeatureMatcher(const FeatureMatcher&) = delete;
     FeatureMatcher& operator=(const FeatureMatcher&) = delete;
 
+    // (extension) the C-ABI handle, for the batch interface (slam::FrameBatch)
+    slamx_matcher* handle() const { return m_handle; }
+
     // feature_matcher.cpp:71-95.  Throws std::invalid_argument on empty descriptor sets and
     // std::runtime_error on width mismatch / L2, exactly as validateInputs does (:97-111).
     void match(const DescriptorMatrix& descriptors1, const DescriptorMatrix& descriptors2, std::vector<Match>& matches,

@@ -283,3 +283,27 @@ def test_facade_latency_program(ref_data):
     assert d["rows"] == 512 and d["cols"] == 1392 and d["keypoints"][0] > 1000 and d["matches"] == 20
     for k in ("detect", "compute", "detectAndCompute", "match", "match_without_keypoints"):
         assert 0 < d[k]["min_us"] <= d[k]["median_us"] <= d[k]["max_us"] < 1e6
+
+
+@pytest.mark.parametrize("folder,repeat", [("images", 1), ("images_test_loop", 3)])
+def test_frame_batch_program(ref_data, folder, repeat):
+    """slam::FrameBatch (include/slam/frontend/frame_batch.hpp, an extension) hands back, frame by frame, exactly what
+    FeatureDetector::detectAndCompute and FeatureMatcher::match return for the same frames (tools/test_frame_batch.cpp
+    compares keypoints, descriptors and matches byte for byte; a difference makes it exit with 1)."""
+    imgs = sorted(os.path.join(ref_data, folder, n) for n in os.listdir(os.path.join(ref_data, folder)) if n.endswith(".png"))
+    text = _run([os.path.join(BIN, "test_frame_batch"), os.path.join(ref_data, "feature_detector.yml"),
+                 os.path.join(ref_data, "feature_matcher.yml"), str(repeat)] + imgs)
+    assert "batch == frame by frame: yes" in text, text
+    assert ("%d frames of" % (len(imgs) * repeat)) in text
+
+
+@pytest.mark.parametrize("batch", [3, 4, 16])
+def test_cli_batch_mode_prints_the_frame_by_frame_lines(ref_data, batch):
+    """cli -b N: the sequence through slam::FrameBatch N frames at a time (the last frame of a batch recomputed as the
+    first of the next) -- keypoint counts, match counts, poses and map-point counts line for line those of the run that
+    calls detectAndCompute / match once per frame."""
+    args = [os.path.join(BIN, "cli"), "-c", ref_data, "-v", os.path.join(ref_data, "images")]
+    want = _run(args).splitlines()
+    got = _run(args + ["-b", str(batch)]).splitlines()
+    assert len(want) == 10 + 9 + 1 and want[:-1] == got[:-1], "\n".join(got)  # (the last line carries the run time)
+    assert want[-1].split(" in ")[0] == got[-1].split(" in ")[0]

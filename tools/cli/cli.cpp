@@ -3,12 +3,16 @@
 // drives the hot path: frame directory -> detectAndCompute -> match(frame k, frame k-1) and, when the
 // config directory also holds a camera.yml, PoseEstimator::estimate + triangulatePoints on the matches.
 //   cli -c <config dir with feature_detector.yml + feature_matcher.yml [+ camera.yml]> -v <directory of PNG frames>
-//       [-p <levels>] [-g <gpus>]
+//       [-p <levels>] [-g <gpus>] [-b <frames>]
 // -p (an extension: the reference has no pyramid) runs the detector on an image pyramid of that many levels.
 // -g N (an extension: the reference has no multi-GPU code): the sequence is cut into N contiguous
 //    chunks of frames, one host thread + one context per GPU (slam::useDevice), each thread recomputing the frame
 //    before its chunk (a 1-frame halo) -- no traffic between GPUs while frames are processed -- and at the end the
 //    map points triangulated on every GPU are exchanged with ONE all-gather over RCCL (slamx_mapgather_*).
+// -b N (an extension: the reference's detector and matcher take one frame per call): frames go through slam::FrameBatch
+//    N at a time -- one upload, one detectAndCompute over all of them, one match of every frame against its predecessor,
+//    one copy of the results -- and the output is the frame-by-frame run's, line for line (the last frame of a batch is
+//    recomputed as the first of the next one, so that every frame has its predecessor in the same batch).
 #include <getopt.h>
 
 #include <algorithm>
@@ -24,6 +28,7 @@
 
 #include <slam/frontend/feature_detector.hpp>
 #include <slam/frontend/feature_matcher.hpp>
+#include <slam/frontend/frame_batch.hpp>
 #include <slam/frontend/pose_estimator.hpp>
 
 #include <slam/preprocessing/png_gray.hpp>
@@ -31,12 +36,14 @@
 namespace fs = std::filesystem;
 
 static void printHelp() {
-    std::printf("cli -c <config_dir> -v <stream_path> [-p <levels>] [-g <gpus>]\n"
+    std::printf("cli -c <config_dir> -v <stream_path> [-p <levels>] [-g <gpus>] [-b <frames>]\n"
                 "  -c  directory holding feature_detector.yml and feature_matcher.yml\n"
                 "  -v  directory of 8-bit PNG frames (processed in lexical order)\n"
                 "  -p  detect on an image pyramid of this many levels (scale 1.2); default: full resolution only\n"
                 "  -g  shard the frames over this many GPUs (one host thread + context each, RCCL all-gather of the\n"
                 "      map points at the end); default 1\n"
+                "  -b  hand the frames to the GPU this many at a time (slam::FrameBatch; frames of one size, no pyramid);\n"
+                "      default 1: one detectAndCompute and one match call per frame, as the reference's classes work\n"
                 "  -h  this help\n");
 }
 
@@ -51,7 +58,7 @@ struct ChunkResult {
 
 // Frames [lo, hi) of `files` on GPU `rank` (of `world`); frame lo - 1 is recomputed as the predecessor of frame lo.
 static void runChunk(int rank, int world, const uint8_t* gatherId, const std::string& configPath, const std::vector<fs::path>& files,
-                     size_t lo, size_t hi, int pyramidLevels, ChunkResult* out) {
+                     size_t lo, size_t hi, int pyramidLevels, int batchFrames, ChunkResult* out) {
     slamx_mapgather* gather = nullptr;
     try {
         slamx_ctx* ctx = slam::useDevice(rank);  // everything this thread creates below lives on GPU `rank`
@@ -73,18 +80,12 @@ static void runChunk(int rank, int world, const uint8_t* gatherId, const std::st
                 detector.detectAndCompute(image, kps, desc);
             }
         };
-        if (lo > 0 && lo < hi) {
+        if (lo > 0 && lo < hi && batchFrames <= 1) {
             detect(lo - 1, prevKps, prevDesc);  // the halo: owned (and reported) by the previous chunk
         }
         char line[512];
-        for (size_t i = lo; i < hi; ++i) {
-            std::vector<slam::Keypoint> kps;
-            slam::DescriptorMatrix desc;
-            detect(i, kps, desc);
-            std::vector<slam::Match> matches;
-            if (i > 0 && !kps.empty() && !prevKps.empty()) {
-                matcher.match(desc, prevDesc, matches, kps, prevKps);
-            }
+        // what a frame contributes to the output, given its results and its predecessor's
+        auto report = [&](size_t i, const std::vector<slam::Keypoint>& kps, const std::vector<slam::Match>& matches) {
             std::snprintf(line, sizeof(line), "frame %zu %s: %zu keypoints, %zu matches to previous\n", i,
                           files[i].filename().c_str(), kps.size(), matches.size());
             out->log += line;
@@ -111,8 +112,58 @@ static void runChunk(int rank, int world, const uint8_t* gatherId, const std::st
             }
             out->keypoints += kps.size();
             out->matches += matches.size();
-            prevKps = std::move(kps);
-            prevDesc = std::move(desc);
+        };
+        if (batchFrames > 1 && lo < hi) {
+            // slot 0 of every batch is the predecessor of its first new frame (frame lo - 1 for the first batch, the last
+            // frame of the batch before otherwise): recomputed, never reported twice
+            const slam::EigenGrayMatrix first = slamx_tools::read_png_gray(files[lo > 0 ? lo - 1 : lo].string());
+            slam::FrameBatch batch(detector, static_cast<int>(first.rows()), static_cast<int>(first.cols()), batchFrames + 1);
+            slam::EigenGrayMatrix carry = first;  // image of the frame that goes into slot 0
+            bool haveCarry = lo > 0;
+            for (size_t i0 = lo; i0 < hi;) {
+                const int slot0 = haveCarry ? 1 : 0;
+                if (haveCarry) {
+                    batch.setFrame(0, carry);
+                }
+                const size_t count = std::min(hi - i0, static_cast<size_t>(batchFrames));
+                for (size_t k = 0; k < count; ++k) {
+                    carry = slamx_tools::read_png_gray(files[i0 + k].string());
+                    batch.setFrame(slot0 + static_cast<int>(k), carry);
+                }
+                const int n = slot0 + static_cast<int>(count);
+                batch.detectAndCompute(n);
+                batch.matchConsecutive(matcher, n);
+                batch.fetch(n);
+                if (haveCarry) {
+                    batch.keypoints(0, prevKps);
+                }
+                for (size_t k = 0; k < count; ++k) {
+                    const int slot = slot0 + static_cast<int>(k);
+                    std::vector<slam::Keypoint> kps;
+                    std::vector<slam::Match> matches;
+                    batch.keypoints(slot, kps);
+                    if (slot > 0 && !kps.empty() && !prevKps.empty()) {
+                        batch.matches(matcher, slot, matches);
+                    }
+                    report(i0 + k, kps, matches);
+                    prevKps = std::move(kps);
+                }
+                i0 += count;
+                haveCarry = true;
+            }
+        } else {
+            for (size_t i = lo; i < hi; ++i) {
+                std::vector<slam::Keypoint> kps;
+                slam::DescriptorMatrix desc;
+                detect(i, kps, desc);
+                std::vector<slam::Match> matches;
+                if (i > 0 && !kps.empty() && !prevKps.empty()) {
+                    matcher.match(desc, prevDesc, matches, kps, prevKps);
+                }
+                report(i, kps, matches);
+                prevKps = std::move(kps);
+                prevDesc = std::move(desc);
+            }
         }
     } catch (...) {
         out->error = std::current_exception();
@@ -142,8 +193,9 @@ int main(int argc, char** argv) {
     std::string configPath{};
     int pyramidLevels = 0;
     int gpus = 1;
+    int batchFrames = 1;
     bool gpusGiven = false;
-    while ((c = getopt(argc, argv, "hv:c:p:g:")) != -1) {
+    while ((c = getopt(argc, argv, "hv:c:p:g:b:")) != -1) {
         switch (c) {
             case 'h':
                 printHelp();
@@ -161,14 +213,21 @@ int main(int argc, char** argv) {
                 gpus = std::atoi(optarg);
                 gpusGiven = true;
                 break;
+            case 'b':
+                batchFrames = std::atoi(optarg);
+                break;
             default:
                 printHelp();
                 return 0;
         }
     }
-    if (streamPath.empty() || configPath.empty() || gpus < 1) {
+    if (streamPath.empty() || configPath.empty() || gpus < 1 || batchFrames < 1) {
         printHelp();
         return 0;
+    }
+    if (batchFrames > 1 && pyramidLevels > 1) {
+        std::fprintf(stderr, "An error occurred: -b and -p cannot be combined (the batch interface of the facade has no pyramid)\n");
+        return -1;
     }
     try {
         // Preprocessor::prepareDirectory, src/preprocessing/preprocessor.cpp:24-41
@@ -204,10 +263,10 @@ int main(int argc, char** argv) {
             const size_t lo = files.size() * static_cast<size_t>(r) / static_cast<size_t>(world);
             const size_t hi = files.size() * static_cast<size_t>(r + 1) / static_cast<size_t>(world);
             if (world == 1) {
-                runChunk(0, 1, gpusGiven ? id.data() : nullptr, configPath, files, lo, hi, pyramidLevels, &results[0]);
+                runChunk(0, 1, gpusGiven ? id.data() : nullptr, configPath, files, lo, hi, pyramidLevels, batchFrames, &results[0]);
             } else {
                 threads.emplace_back(runChunk, r, world, id.data(), std::cref(configPath), std::cref(files), lo, hi, pyramidLevels,
-                                     &results[static_cast<size_t>(r)]);
+                                     batchFrames, &results[static_cast<size_t>(r)]);
             }
         }
         for (auto& th : threads) {

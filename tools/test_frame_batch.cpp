@@ -1,0 +1,106 @@
+// test_frame_batch -- slam::FrameBatch (include/slam/frontend/frame_batch.hpp, an extension: the reference has no batch
+// interface) against the reference-signature calls on the same frames: every frame's keypoints and descriptors must equal
+// FeatureDetector::detectAndCompute's, every frame's matches FeatureMatcher::match(desc k, desc k-1, matches, kps k, kps k-1)'s,
+// byte for byte.  Prints what a caller gains by handing over the sequence at once.
+//   test_frame_batch <feature_detector.yml> <feature_matcher.yml> <repeat> <img0.png> <img1.png> ...   (images of one size)
+// `repeat` cycles through the images that often (a longer sequence from the reference's ten KITTI frames).
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <slam/frontend/frame_batch.hpp>
+
+#include <slam/preprocessing/png_gray.hpp>
+
+namespace {
+double seconds_since(const std::chrono::steady_clock::time_point& t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: %s <feature_detector.yml> <feature_matcher.yml> <repeat> <img0.png> <img1.png> ...\n", argv[0]);
+        return -1;
+    }
+    try {
+        slam::FeatureDetector detector(argv[1]);
+        slam::FeatureMatcher matcher(argv[2]);
+        const int repeat = std::max(1, std::atoi(argv[3]));
+        std::vector<slam::EigenGrayMatrix> images;
+        for (int i = 4; i < argc; ++i) {
+            images.push_back(slamx_tools::read_png_gray(argv[i]));
+            if (images.back().rows() != images[0].rows() || images.back().cols() != images[0].cols()) {
+                throw std::runtime_error(std::string("image of another size: ") + argv[i]);
+            }
+        }
+        const int n = static_cast<int>(images.size()) * repeat;
+        auto image_of = [&](int k) -> const slam::EigenGrayMatrix& { return images[static_cast<size_t>(k) % images.size()]; };
+
+        // ---- the reference's way: one call per frame, one per frame pair
+        std::vector<std::vector<slam::Keypoint>> kps(static_cast<size_t>(n));
+        std::vector<slam::DescriptorMatrix> desc(static_cast<size_t>(n));
+        std::vector<std::vector<slam::Match>> matches(static_cast<size_t>(n));
+        detector.detectAndCompute(image_of(0), kps[0], desc[0]);  // warm-up: the library's lazy allocations
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < n; ++k) {
+            detector.detectAndCompute(image_of(k), kps[static_cast<size_t>(k)], desc[static_cast<size_t>(k)]);
+            if (k > 0) {
+                matcher.match(desc[static_cast<size_t>(k)], desc[static_cast<size_t>(k) - 1], matches[static_cast<size_t>(k)],
+                              kps[static_cast<size_t>(k)], kps[static_cast<size_t>(k) - 1]);
+            }
+        }
+        const double t_single = seconds_since(t0);
+
+        // ---- the batch
+        slam::FrameBatch batch(detector, static_cast<int>(images[0].rows()), static_cast<int>(images[0].cols()), n);
+        double t_batch = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {  // pass 0 warms up (first-use allocations of the batch)
+            t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < n; ++k) {
+                batch.setFrame(k, image_of(k));
+            }
+            batch.detectAndCompute(n);
+            batch.matchConsecutive(matcher, n);
+            batch.fetch(n);
+            t_batch = seconds_since(t0);
+        }
+        size_t total_kps = 0, total_matches = 0;
+        int bad = 0;
+        for (int k = 0; k < n; ++k) {
+            std::vector<slam::Keypoint> bk;
+            slam::DescriptorMatrix bd;
+            std::vector<slam::Match> bm;
+            batch.keypoints(k, bk);
+            batch.descriptors(k, bd);
+            if (k > 0) {
+                batch.matches(matcher, k, bm);
+            }
+            const auto& rk = kps[static_cast<size_t>(k)];
+            const auto& rd = desc[static_cast<size_t>(k)];
+            const auto& rm = matches[static_cast<size_t>(k)];
+            const bool same_k = bk.size() == rk.size() && (bk.empty() || std::memcmp(bk.data(), rk.data(), bk.size() * sizeof(slam::Keypoint)) == 0);
+            const bool same_d = bd.rows() == rd.rows() && bd.cols() == rd.cols() &&
+                                (bd.size() == 0 || std::memcmp(bd.data(), rd.data(), static_cast<size_t>(bd.size())) == 0);
+            const bool same_m = bm.size() == rm.size() && (bm.empty() || std::memcmp(bm.data(), rm.data(), bm.size() * sizeof(slam::Match)) == 0);
+            if (!same_k || !same_d || !same_m) {
+                std::fprintf(stderr, "frame %d differs: keypoints %s (%zu / %zu), descriptors %s, matches %s (%zu / %zu)\n", k,
+                             same_k ? "equal" : "DIFFER", bk.size(), rk.size(), same_d ? "equal" : "DIFFER", same_m ? "equal" : "DIFFER",
+                             bm.size(), rm.size());
+                ++bad;
+            }
+            total_kps += bk.size();
+            total_matches += bm.size();
+        }
+        std::printf("%d frames of %td x %td: %zu keypoints, %zu matches\n", n, images[0].cols(), images[0].rows(), total_kps, total_matches);
+        std::printf("frame by frame (detectAndCompute + match): %.3f ms, %.0f frames/s\n", t_single * 1e3, n / t_single);
+        std::printf("one FrameBatch (copy in, detectAndCompute, matchConsecutive, fetch): %.3f ms, %.0f frames/s\n", t_batch * 1e3, n / t_batch);
+        std::printf("batch == frame by frame: %s\n", bad == 0 ? "yes" : "NO");
+        return bad == 0 ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "An error occurred: %s\n", e.what());
+        return -1;
+    }
+}
