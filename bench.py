@@ -900,6 +900,22 @@ def facade_latency(reps=50):
         out["gpu_facade"] = json.loads(p.stdout.decode().strip().splitlines()[-1])
     except Exception as e:
         out["gpu_facade"] = {"error": repr(e)[:200]}
+    # the same facade objects over a whole sequence: slam::FrameBatch (include/slam/frontend/frame_batch.hpp) against one
+    # detectAndCompute + one match call per frame, on the reference's ten KITTI frames cycled 25 times; the tool also
+    # compares the two results byte for byte (tools/test_frame_batch.cpp)
+    try:
+        import re
+
+        seq = sorted(os.path.join(ref, "images", n) for n in os.listdir(os.path.join(ref, "images")) if n.endswith(".png"))
+        p = subprocess.run([os.path.join(ROOT, "tools", "bin", "test_frame_batch"), os.path.join(ref, "feature_detector.yml"),
+                            os.path.join(ref, "feature_matcher.yml"), "25"] + seq, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+        text = p.stdout.decode()
+        rates = [float(x) for x in re.findall(r"([0-9.]+) frames/s", text)]
+        out["gpu_facade_sequence"] = {"frames": 25 * len(seq), "frame_by_frame_fps": rates[0], "frame_batch_fps": rates[1],
+                                      "results_identical": "batch == frame by frame: yes" in text,
+                                      "note": "host images in, keypoints + descriptors + matches of every frame out, both ways"}
+    except Exception as e:
+        out["gpu_facade_sequence"] = {"error": repr(e)[:200]}
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding
