@@ -1102,6 +1102,19 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
             const auto q = __builtin_amdgcn_raw_buffer_load_b128(frame_rsrc, voff, 0, 0);
             tq[k] = make_uint4(q[0], q[1], q[2], q[3]);
         }
+        // A tile row starts RT_XOFF = 24 bytes left of the region, so in the frame's leftmost regions the 16-byte piece
+        // of columns -8 .. 7 straddles x = 0.  In image rows >= 1 its offset is still inside the buffer (the bytes for
+        // x < 0 come from the end of the row above: never sampled), but in IMAGE ROW 0 the offset is negative, the range
+        // check zero-fills the whole piece, and columns 0 .. 7 of row 0 -- which BRIEF pairs and the moments of keypoints
+        // near the top-left corner do sample -- read as 0.  Found by tools/fuzz_detector.py (one descriptor bit of one
+        // keypoint at (17, 18) on a 37 x 553 frame).  The thread that owns that piece of region 0 loads the eight valid
+        // bytes on their own.
+        constexpr int STRADDLE_PIECE = TILE_HALF * (RT_DW / 4) + RT_XOFF / 16;  // tile row of image row 0, piece of x = -8 .. 7
+        static_assert(RT_XOFF % 16 == 8 && RT_XOFF / 16 == 1, "the straddling piece is the second one, half inside the frame");
+        if (r == 0 && tid == STRADDLE_PIECE % 256) {  // (region 0: x0 == 0 and y0 == 0)
+            const uint2 head = *reinterpret_cast<const uint2*>(img);
+            tq[STRADDLE_PIECE / 256] = make_uint4(0u, 0u, head.x, head.y);
+        }
     }
     const int* first = v.region_first + static_cast<size_t>(f) * (regions_per_frame + 1);
     const int lo = first[r], hi = first[r + 1];

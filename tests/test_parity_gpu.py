@@ -814,11 +814,37 @@ def test_region_tile_describe_on_every_shape():
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_parity_gpu.py"),
                         os.path.join(here, "test_pyramid_gpu.py"), "-k",
-                        "batch_equals_single_frame or pipeline_odd_shapes or test_detect_and_compute or pyramid_batch_with_matching or "
+                        "batch_equals_single_frame or pipeline_odd_shapes or test_detect_and_compute or pyramid_batch_with_matching or dense_small_frames or "
                         "frontend_against_committed_golden_vectors"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0 and " passed" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("rows,cols,window,t", [(37, 553, 5, 15), (40, 300, 2, 10), (64, 240, 3, 8), (100, 100, 2, 12), (22, 700, 2, 5)])
+def test_dense_small_frames_through_the_region_tiles(slamx, oracle, rows, cols, window, t):
+    """Dense frames take describe_tile_kernel by themselves (>= 20 keypoints per 240 x 64-pixel region).  Small noisy
+    frames put keypoints within 21 pixels of EVERY border and of the top-left corner, where the tile's 16-byte pieces
+    straddle x = 0: in image row 0 such a piece starts at a negative buffer offset and used to be zero-filled as a whole,
+    columns 0..7 of row 0 included (tools/fuzz_detector.py seed 404 case 158: one descriptor bit of the keypoint at
+    (17, 18) on a 37 x 553 frame).  Keypoints, angles and descriptors must be the oracle's."""
+    rng = np.random.default_rng(rows * 1000 + cols)
+    d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=5, window=window))
+    Pp = oracle.det_params(d.cfg)
+    for k in range(4):
+        if k % 2 == 0:
+            img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        else:  # blocks with small noise: corners at block boundaries, including the first rows and columns
+            b = int(rng.integers(3, 9))
+            lvl = rng.integers(0, 256, (rows // b + 1, cols // b + 1)).repeat(b, 0).repeat(b, 1)[:rows, :cols]
+            img = np.clip(lvl + rng.integers(-6, 7, (rows, cols)), 0, 255).astype(np.uint8)
+        img = np.ascontiguousarray(img)
+        k_ref, d_ref = oracle.detect_and_compute(img, Pp)
+        k_got, d_got = d.detectAndCompute(img)
+        assert len(k_ref) >= 20 * ((cols + 239) // 240) * ((rows + 63) // 64), "the frame must be dense enough for the region tiles"
+        assert_records_equal(k_got, k_ref, "%dx%d frame %d keypoints" % (rows, cols, k))
+        assert np.array_equal(d_got, d_ref), "%dx%d frame %d: %d descriptor rows differ" % (
+            rows, cols, k, int((d_got != d_ref).any(axis=1).sum()))
 
 
 def test_batch_equals_single_frame(slamx, oracle):
