@@ -62,6 +62,20 @@ def main():
             k_got, d_got = det.detectAndCompute(img)
             assert len(k_got) == len(k_ref) and np.array_equal(k_got, k_ref), "keypoints differ, " + tag
             assert np.array_equal(d_got, d_ref), "descriptors differ, " + tag
+            if case % 2 == 1:
+                # the two halves on their own: detect, then compute on keypoints the caller hands over -- in another order,
+                # some with fractional coordinates, some on the border (angle 0, skipped pairs)
+                k_d = det.detect(img)
+                assert len(k_d) == len(k_ref) and k_d["x"].tobytes() == k_ref["x"].tobytes() and k_d["y"].tobytes() == k_ref["y"].tobytes(), "detect differs, " + tag
+                extra = np.zeros(6, k_ref.dtype)
+                extra["x"] = [0.0, cols - 1.0, rng.uniform(0, cols - 1), rng.uniform(0, cols - 1), 3.25, cols - 2.5]
+                extra["y"] = [0.0, rows - 1.0, rng.uniform(0, rows - 1), 0.5, rows - 1.0, rng.uniform(0, rows - 1)]
+                extra["size"] = 6.0
+                k_in = np.concatenate([k_d[rng.permutation(len(k_d))], extra])
+                k_c, d_c = det.compute(img, k_in)
+                k_o, d_o = oracle.compute(img, k_in, P)
+                assert k_c.tobytes() == k_o.tobytes(), "compute: angles differ, " + tag
+                assert np.array_equal(d_c, d_o), "compute: descriptors differ, " + tag
             if case % 3 == 0:  # the same frame twice through a batch whose capacity selects the 1 + 7-wave greedy NMS
                 b = slamx.Batch(det, rows, cols, 2, max_candidates=65536, max_keypoints=max(16, len(k_ref) + 8))
                 b.upload(np.stack([img, img]))
