@@ -85,6 +85,25 @@ def main():
                     assert len(k_b) == len(k_ref) and np.array_equal(k_b, k_ref), "batch keypoints differ, " + tag
                     assert len(k_ref) == 0 or np.array_equal(d_b, d_ref), "batch descriptors differ, " + tag
                 del b
+            if case % 5 == 2 and len(k_ref) > 0:
+                # a batch that mixes this frame with sparse ones (flat, and a few corners only): which describe kernel takes a
+                # frame is decided per frame on the device; run twice -- the second time after counts() has told the host
+                # whether any frame is dense (the hint that skips the region-tile launches)
+                flat = np.full((rows, cols), 90, np.uint8)
+                few = flat.copy()
+                few[rows // 3: rows // 3 + 9, cols // 4: cols // 4 + 11] = 200
+                mix = [img, flat, few, img]
+                refs = [(k_ref, d_ref)] + [oracle.detect_and_compute(f, P) for f in (flat, few)] + [(k_ref, d_ref)]
+                b = slamx.Batch(det, rows, cols, 4, max_candidates=rows * cols, max_keypoints=max(16, len(k_ref) + 8))
+                b.upload(np.stack(mix))
+                for rnd in range(2):
+                    b.detect_and_compute(4)
+                    b.counts(4)
+                    for f in range(4):
+                        k_b, d_b = b.download(f)
+                        assert len(k_b) == len(refs[f][0]) and np.array_equal(k_b, refs[f][0]), "mixed batch keypoints differ (frame %d, run %d), %s" % (f, rnd, tag)
+                        assert len(refs[f][0]) == 0 or np.array_equal(d_b, refs[f][1]), "mixed batch descriptors differ (frame %d, run %d), %s" % (f, rnd, tag)
+                del b
         det.close() if hasattr(det, "close") else None
     print("fuzz_detector: %d cases identical (seed %d)" % (cases, seed))
 
