@@ -1,6 +1,11 @@
+#!/usr/bin/env python3
+"""Replays ONE case of tools/fuzz_detector.py (same generator, same seed, the draws of the cases before it consumed on the CPU
+only) and says which keypoints' descriptors differ from the oracle's -- how the one-bit difference of seed 404 / case 158 was
+pinned to the keypoint at (17, 18) and, with SLAMX_DESCRIBE_TILES=0 / SLAMX_NO_FUSED_DESCRIBE=1, to describe_tile_kernel.
+Test infrastructure.  usage: tools/replay_fuzz_case.py <seed> <case>"""
 import importlib, os, sys
 import numpy as np
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"tests")); sys.path.insert(0, os.path.join(ROOT,"tools"))
 import oracle_binding
 import fuzz_detector as fz
@@ -29,4 +34,5 @@ for i in bad[:12]:
 xs = np.array([k_ref[i][0] for i in bad]); ys = np.array([k_ref[i][1] for i in bad])
 if len(bad):
     print("x range", xs.min(), xs.max(), "y range", ys.min(), ys.max())
-np.save("/root/repo/gpurun_out/fuzz_case_img.npy", img)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.save(os.path.join(ROOT, "gpurun_out", "fuzz_case_img.npy"), img)
