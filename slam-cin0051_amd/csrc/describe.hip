@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
         // of columns -8 .. 7 straddles x = 0.  In image rows >= 1 its offset is still inside the buffer (the bytes for
         // x < 0 come from the end of the row above: never sampled), but in IMAGE ROW 0 the offset is negative, the range
         // check zero-fills the whole piece, and columns 0 .. 7 of row 0 -- which BRIEF pairs and the moments of keypoints
-        // near the top-left corner do sample -- read as 0.  Found by tools/fuzz_detector.py (one descriptor bit of one
+        // near the top-left corner do sample -- read as 0.  Found by tests/fuzz/fuzz_detector.py (one descriptor bit of one
         // keypoint at (17, 18) on a 37 x 553 frame).  The thread that owns that piece of region 0 loads the eight valid
         // bytes on their own.
         constexpr int STRADDLE_PIECE = TILE_HALF * (RT_DW / 4) + RT_XOFF / 16;  // tile row of image row 0, piece of x = -8 .. 7

@@ -2,13 +2,13 @@
 """Differential fuzz of the detector against the CPU restatement (oracle/): random shapes, thresholds, arc
 lengths and image statistics through FAST candidates, and detect + compute on the smaller ones (every third of those
 also through a batch with a large candidate capacity: the other instantiation of the greedy NMS).
-Test infrastructure (uses oracle/ as the checker).  usage: tools/fuzz_detector.py [cases] [seed]"""
+Test infrastructure (uses oracle/ as the checker).  usage: tests/fuzz/fuzz_detector.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib

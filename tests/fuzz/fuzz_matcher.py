@@ -3,14 +3,14 @@
 live-bit prefixes, clusters of duplicates and near-duplicates (ties in best and second), integer / fractional /
 far-apart keypoints (jump penalty), every filter / ratio configuration, both all-pairs scans (xor + popcount and
 the int8 matrix cores).  Test infrastructure (uses oracle/ as the checker).
-usage: tools/fuzz_matcher.py [cases] [seed]"""
+usage: tests/fuzz/fuzz_matcher.py [cases] [seed]"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding

@@ -4,14 +4,14 @@
 pure rotations (degenerate for the 8-point solve), random hypothesis counts and thresholds -- through tests/
 test_pose_batch_gpu.py's own checks: every pair of the batch against the ONE-PAIR entry points on the device's sample tables
 (bit for bit) and, for the well-conditioned scenes, against the oracle (its tolerances).  Test infrastructure.
-usage: tools/fuzz_pose.py [cases] [seed]"""
+usage: tests/fuzz/fuzz_pose.py [cases] [seed]"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding

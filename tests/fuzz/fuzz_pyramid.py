@@ -2,17 +2,17 @@
 """Differential fuzz of the image pyramid (slamx_pyramid_*: integer bilinear downscale, the unchanged detector on every
 level, results merged into level 0's arrays) against the CPU restatement: random frame shapes, level counts (1..8), scale
 factors (1.05..2.5), thresholds, windows and image statistics, two or three frames per batch.  Test infrastructure.
-usage: tools/fuzz_pyramid.py [cases] [seed]"""
+usage: tests/fuzz/fuzz_pyramid.py [cases] [seed]"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 import oracle_binding
 from fuzz_detector import image
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Replays ONE case of tools/fuzz_detector.py (same generator, same seed, the draws of the cases before it consumed on the CPU
+"""Replays ONE case of tests/fuzz/fuzz_detector.py (same generator, same seed, the draws of the cases before it consumed on the CPU
 only) and says which keypoints' descriptors differ from the oracle's -- how the one-bit difference of seed 404 / case 158 was
 pinned to the keypoint at (17, 18) and, with SLAMX_DESCRIBE_TILES=0 / SLAMX_NO_FUSED_DESCRIBE=1, to describe_tile_kernel.
-Test infrastructure.  usage: tools/replay_fuzz_case.py <seed> <case>"""
+Test infrastructure.  usage: tests/fuzz/replay_fuzz_case.py <seed> <case>"""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"tests")); sys.path.insert(0, os.path.join(ROOT,"tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 import oracle_binding
 import fuzz_detector as fz
 slamx = importlib.import_module("slam-cin0051_amd")

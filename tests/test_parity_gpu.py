@@ -826,7 +826,7 @@ def test_dense_small_frames_through_the_region_tiles(slamx, oracle, rows, cols, 
     """Dense frames take describe_tile_kernel by themselves (>= 20 keypoints per 240 x 64-pixel region).  Small noisy
     frames put keypoints within 21 pixels of EVERY border and of the top-left corner, where the tile's 16-byte pieces
     straddle x = 0: in image row 0 such a piece starts at a negative buffer offset and used to be zero-filled as a whole,
-    columns 0..7 of row 0 included (tools/fuzz_detector.py seed 404 case 158: one descriptor bit of the keypoint at
+    columns 0..7 of row 0 included (tests/fuzz/fuzz_detector.py seed 404 case 158: one descriptor bit of the keypoint at
     (17, 18) on a 37 x 553 frame).  Keypoints, angles and descriptors must be the oracle's."""
     rng = np.random.default_rng(rows * 1000 + cols)
     d = slamx.FeatureDetector(cfg_of(slamx, t=t, arc=5, window=window))
