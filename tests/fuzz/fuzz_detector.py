@@ -51,11 +51,12 @@ def main():
         arc = int(rng.integers(0, 17))
         window = int(rng.integers(1, 16))
         img = np.ascontiguousarray(image(rng, rows, cols).astype(np.uint8))
-        cfg = slamx.DetectorConfig(t, arc, 1, window, 31, 256)
+        nms = 0 if rng.integers(0, 10) == 0 else 1  # NonMaxSuppression off: every candidate is a keypoint, in raster order
+        cfg = slamx.DetectorConfig(t, arc, nms, window, 31, 256)
         det = slamx.FeatureDetector(cfg)
         P = oracle.det_params(cfg)
         got, ref = det.fast_candidates(img), oracle.fast_candidates(img, P)
-        tag = "case %d: %dx%d t=%d arc=%d window=%d" % (case, rows, cols, t, arc, window)
+        tag = "case %d: %dx%d t=%d arc=%d window=%d nms=%d" % (case, rows, cols, t, arc, window, nms)
         assert len(got) == len(ref) and np.array_equal(got, ref), "candidates differ, " + tag
         if len(ref) < 4000:  # the oracle's greedy loop is quadratic
             k_ref, d_ref = oracle.detect_and_compute(img, P)
