@@ -424,11 +424,20 @@ __global__ __launch_bounds__(256) void moments_kernel(BatchView v, DetectorParam
     auto is_inside = [&](int x, int y) {
         return !(x - radius < 0 || x + radius >= v.cols || y - radius < 0 || y + radius >= v.rows);
     };
-    auto issue = [&](int x, int y, uint32_t* px) {  // the tile of an inside keypoint never leaves the padded frame
-        const uint8_t* base = img + static_cast<size_t>(y - MOM_HALF) * v.pitch + ((x - MOM_HALF) & ~3);
+    // The tile is ALWAYS 31 rows x 36 bytes around the keypoint (the weights outside the patch's disc are zero), whatever
+    // PatchSize is: "inside" only keeps the PATCH in the image, so with a small patch (PatchSize 5: keypoints 3 pixels from
+    // the border are inside) the tile's first rows lie ABOVE the frame and its last ones below it.  Until round 4 the loads
+    // were plain pointer reads -- before the first frame of a batch or behind its last one that is memory the batch does
+    // not own (found by tests/fuzz/fuzz_detector.py as a GPU memory fault: 72 x 525, PatchSize 5, NumBRIEFPairs 24).  Buffer
+    // loads with the whole offset in the lane: what lies before the frame (a negative offset, i.e. a huge unsigned one)
+    // or behind it reads as zero.
+    const __amdgpu_buffer_rsrc_t frame_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, v.rows * v.pitch, 0x00020000);
+    auto issue = [&](int x, int y, uint32_t* px) {
+        const int base = (y - MOM_HALF) * v.pitch + ((x - MOM_HALF) & ~3);  // may be negative
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
-            px[k] = *reinterpret_cast<const uint32_t*>(base + off[k]);
+            px[k] = __builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, base + off[k], 0, 0);
         }
     };
     for (int chunk = 0; i0 + chunk * stride < n; chunk += 64) {  // wave-uniform

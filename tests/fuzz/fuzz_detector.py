@@ -38,6 +38,16 @@ def image(rng, rows, cols):
     return np.clip(base + rng.integers(-amp, amp + 1, (rows, cols)), 0, 255)
 
 
+_trace = open(os.environ["FUZZ_TRACE"], "w") if os.environ.get("FUZZ_TRACE") else None
+
+
+def step(what):  # FUZZ_TRACE=<file>: the case and the call about to run, flushed -- names the case when the GPU faults
+    if _trace is not None:
+        _trace.write(what + "\n")
+        _trace.flush()
+        os.fsync(_trace.fileno())
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -52,20 +62,27 @@ def main():
         window = int(rng.integers(1, 16))
         img = np.ascontiguousarray(image(rng, rows, cols).astype(np.uint8))
         nms = 0 if rng.integers(0, 10) == 0 else 1  # NonMaxSuppression off: every candidate is a keypoint, in raster order
-        cfg = slamx.DetectorConfig(t, arc, nms, window, 31, 256)
+        patch, pairs = 31, 256
+        if rng.integers(0, 5) == 0:  # other patch sizes and descriptor widths: the other describe kernels
+            patch = int(rng.choice([5, 9, 15, 21, 25, 31, 33, 41, 63]))
+            pairs = int(rng.choice([8, 24, 64, 128, 256, 512, 1024]))
+        cfg = slamx.DetectorConfig(t, arc, nms, window, patch, pairs)
         det = slamx.FeatureDetector(cfg)
         P = oracle.det_params(cfg)
+        step("case %d: %dx%d t=%d arc=%d window=%d nms=%d patch=%d pairs=%d: fast_candidates" % (case, rows, cols, t, arc, window, nms, patch, pairs))
         got, ref = det.fast_candidates(img), oracle.fast_candidates(img, P)
-        tag = "case %d: %dx%d t=%d arc=%d window=%d nms=%d" % (case, rows, cols, t, arc, window, nms)
+        tag = "case %d: %dx%d t=%d arc=%d window=%d nms=%d patch=%d pairs=%d" % (case, rows, cols, t, arc, window, nms, patch, pairs)
         assert len(got) == len(ref) and np.array_equal(got, ref), "candidates differ, " + tag
         if len(ref) < 4000:  # the oracle's greedy loop is quadratic
             k_ref, d_ref = oracle.detect_and_compute(img, P)
+            step("  detectAndCompute")
             k_got, d_got = det.detectAndCompute(img)
             assert len(k_got) == len(k_ref) and np.array_equal(k_got, k_ref), "keypoints differ, " + tag
             assert np.array_equal(d_got, d_ref), "descriptors differ, " + tag
             if case % 2 == 1:
                 # the two halves on their own: detect, then compute on keypoints the caller hands over -- in another order,
                 # some with fractional coordinates, some on the border (angle 0, skipped pairs)
+                step("  detect")
                 k_d = det.detect(img)
                 assert len(k_d) == len(k_ref) and k_d["x"].tobytes() == k_ref["x"].tobytes() and k_d["y"].tobytes() == k_ref["y"].tobytes(), "detect differs, " + tag
                 extra = np.zeros(6, k_ref.dtype)
@@ -73,6 +90,7 @@ def main():
                 extra["y"] = [0.0, rows - 1.0, rng.uniform(0, rows - 1), 0.5, rows - 1.0, rng.uniform(0, rows - 1)]
                 extra["size"] = 6.0
                 k_in = np.concatenate([k_d[rng.permutation(len(k_d))], extra])
+                step("  compute, %d keypoints" % len(k_in))
                 k_c, d_c = det.compute(img, k_in)
                 k_o, d_o = oracle.compute(img, k_in, P)
                 assert k_c.tobytes() == k_o.tobytes(), "compute: angles differ, " + tag
@@ -80,6 +98,7 @@ def main():
             if case % 3 == 0:  # the same frame twice through a batch whose capacity selects the 1 + 7-wave greedy NMS
                 b = slamx.Batch(det, rows, cols, 2, max_candidates=65536, max_keypoints=max(16, len(k_ref) + 8))
                 b.upload(np.stack([img, img]))
+                step("  batch of 2")
                 b.detect_and_compute(2)
                 for f in range(2):
                     k_b, d_b = b.download(f)
@@ -98,6 +117,7 @@ def main():
                 b = slamx.Batch(det, rows, cols, 4, max_candidates=rows * cols, max_keypoints=max(16, len(k_ref) + 8))
                 b.upload(np.stack(mix))
                 for rnd in range(2):
+                    step("  mixed batch, run %d" % rnd)
                     b.detect_and_compute(4)
                     b.counts(4)
                     for f in range(4):

@@ -847,6 +847,36 @@ def test_dense_small_frames_through_the_region_tiles(slamx, oracle, rows, cols, 
             rows, cols, k, int((d_got != d_ref).any(axis=1).sum()))
 
 
+@pytest.mark.parametrize("patch,pairs", [(5, 24), (9, 8), (15, 64), (21, 512), (25, 1024), (33, 256), (63, 128)])
+def test_other_patch_sizes_and_descriptor_widths_in_a_batch(slamx, oracle, patch, pairs):
+    """Every describe path on keypoints 3 pixels from the border: PatchSize 5 ... 63 and NumBRIEFPairs 8 ... 1024 select
+    the fused kernels (radius <= 15, <= 64 surviving pairs, width a multiple of 8), the three-kernel path (other widths
+    or more pairs) or the generic kernel (radius > 15).  moments_kernel used to read its fixed 31-row tile through plain
+    pointers: with a small patch the tile of an "inside" keypoint starts above the frame -- before the batch's first
+    frame that is memory the batch does not own (tests/fuzz/fuzz_detector.py seed 81 case 52 faulted there)."""
+    rng = np.random.default_rng(patch * 10000 + pairs)
+    rows, cols = 72, 525
+    d = slamx.FeatureDetector(cfg_of(slamx, t=30, arc=9, window=4, patch=patch, pairs=pairs))
+    Pp = oracle.det_params(d.cfg)
+    noise = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    flat = np.full((rows, cols), 90, np.uint8)
+    few = flat.copy()
+    few[20:31, 100:113] = 200
+    frames = [noise, flat, few, noise]
+    refs = [oracle.detect_and_compute(f, Pp) for f in frames]
+    assert len(refs[0][0]) > 50 and len(refs[1][0]) == 0
+    b = slamx.Batch(d, rows, cols, 4, max_candidates=rows * cols, max_keypoints=len(refs[0][0]) + 8)
+    b.upload(np.stack(frames))
+    b.detect_and_compute(4)
+    for f in range(4):
+        k_b, d_b = b.download(f)
+        assert_records_equal(k_b, refs[f][0], "patch %d pairs %d frame %d" % (patch, pairs, f))
+        assert len(refs[f][0]) == 0 or np.array_equal(d_b, refs[f][1])
+    k1, d1 = d.detectAndCompute(noise)
+    assert_records_equal(k1, refs[0][0], "single frame")
+    assert np.array_equal(d1, refs[0][1])
+
+
 def test_batch_equals_single_frame(slamx, oracle):
     d = slamx.FeatureDetector(cfg_of(slamx, window=6))
     Pp = oracle.det_params(d.cfg)
