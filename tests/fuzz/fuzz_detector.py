@@ -2,7 +2,9 @@
 """Differential fuzz of the detector against the CPU restatement (oracle/): random shapes, thresholds, arc
 lengths and image statistics through FAST candidates, and detect + compute on the smaller ones (every third of those
 also through a batch with a large candidate capacity: the other instantiation of the greedy NMS).
-Test infrastructure (uses oracle/ as the checker).  usage: tests/fuzz/fuzz_detector.py [cases] [seed]"""
+Test infrastructure (uses oracle/ as the checker).  usage: tests/fuzz/fuzz_detector.py [cases] [seed]
+FUZZ_TRACE=<file> writes the case and the call about to run (flushed: names the case when the GPU faults);
+FUZZ_ONLY=<case> replays one case of the seed."""
 import os
 import sys
 
@@ -53,13 +55,16 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     slamx = importlib.import_module("slam-cin0051_amd")
     oracle = oracle_binding.load()
-    rng = np.random.default_rng(seed)
-    for case in range(cases):
+    only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None  # replay ONE case (they are independent)
+    for case in range(cases) if only is None else [only]:
+        rng = np.random.default_rng([seed, case])  # a generator per case: case N can be replayed on its own
         rows = int(rng.integers(7, 140))
         cols = int(rng.choice([rng.integers(7, 80), rng.integers(200, 300), rng.integers(500, 560)]))
         t = int(rng.choice([rng.integers(0, 8), rng.integers(8, 64), rng.integers(64, 256)]))
         arc = int(rng.integers(0, 17))
         window = int(rng.integers(1, 16))
+        if rng.integers(0, 10) == 0:  # beyond the greedy kernel's largest window (24): the dependency-round NMS
+            window = int(rng.integers(16, 48))
         img = np.ascontiguousarray(image(rng, rows, cols).astype(np.uint8))
         nms = 0 if rng.integers(0, 10) == 0 else 1  # NonMaxSuppression off: every candidate is a keypoint, in raster order
         patch, pairs = 31, 256
