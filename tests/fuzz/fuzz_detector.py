@@ -66,6 +66,10 @@ def main():
         if rng.integers(0, 10) == 0:  # beyond the greedy kernel's largest window (24): the dependency-round NMS
             window = int(rng.integers(16, 48))
         img = np.ascontiguousarray(image(rng, rows, cols).astype(np.uint8))
+        if rng.integers(0, 4) == 0:  # a view into a wider buffer: rows that are not back to back (stride > cols)
+            wide = rng.integers(0, 256, (rows, cols + int(rng.integers(1, 70))), dtype=np.uint8)
+            wide[:, :cols] = img
+            img = wide[:, :cols]
         nms = 0 if rng.integers(0, 10) == 0 else 1  # NonMaxSuppression off: every candidate is a keypoint, in raster order
         patch, pairs = 31, 256
         if rng.integers(0, 5) == 0:  # other patch sizes and descriptor widths: the other describe kernels
