@@ -22,3 +22,7 @@ for seed in $(seq 500 509); do
   timeout -k 10 200 python tests/fuzz/fuzz_pyramid.py 400 $seed > $out/pyr_$seed.log 2>&1 || { echo "PYRAMID seed $seed FAILED"; tail -4 $out/pyr_$seed.log; exit 1; }
 done
 echo "pyramid: 10 x 400 cases identical"
+for seed in $(seq 600 604); do
+  timeout -k 10 250 python tests/fuzz/fuzz_batch.py 400 $seed > $out/batch_$seed.log 2>&1 || { echo "BATCH seed $seed FAILED"; tail -4 $out/batch_$seed.log; exit 1; }
+  tail -1 $out/batch_$seed.log
+done
