@@ -27,7 +27,7 @@ public:
     // maxCandidates / maxKeypoints: per-frame capacities (0 = the library's defaults: a quarter / a sixteenth of the
     // pixels); a frame that exceeds them makes fetch() throw std::runtime_error, as an overflow of the C ABI does.
     FrameBatch(FeatureDetector& detector, int rows, int cols, int maxFrames, int maxCandidates = 0, int maxKeypoints = 0)
-        : m_rows(rows), m_cols(cols), m_maxFrames(maxFrames), m_ctx(detail::default_context()) {
+        : m_rows(rows), m_cols(cols), m_maxFrames(maxFrames), m_ctx(slamx_detector_context(detector.handle())) {
         slamx_batch_shape shape{};
         shape.rows = rows;
         shape.cols = cols;
@@ -86,7 +86,7 @@ public:
     // Every result of frames 0 .. nframes - 1 in one copy; waits for the batch.  Throws on a capacity overflow.
     void fetch(int nframes) {
         detail::check(slamx_batch_download_packed_async(m_batch, nframes, m_results, m_resultBytes));
-        detail::check(slamx_ctx_synchronize(m_ctx));  // (the detector's context: the calling thread's at construction)
+        detail::check(slamx_ctx_synchronize(m_ctx));  // (the detector's context)
         std::memcpy(&m_header, m_results, sizeof(m_header));
         if (static_cast<size_t>(m_header.total_bytes) > m_resultBytes) {
             throw std::runtime_error("FrameBatch::fetch: packed results larger than their bound");

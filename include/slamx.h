@@ -128,6 +128,8 @@ void slamx_detector_destroy(slamx_detector* det);
 /* generateBRIEFPattern, feature_detector.cpp:286-313: xy4 receives {x1,y1,x2,y2} per pair. */
 int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pairs, int* n_pairs);
 int slamx_detector_descriptor_width(const slamx_detector* det); /* NumBRIEFPairs / 8 */
+/* The context a detector was created on (what its batches run on and what slamx_ctx_synchronize must be given). */
+slamx_ctx* slamx_detector_context(const slamx_detector* det);
 
 /* FeatureDetector::detect, feature_detector.cpp:8-18.  img: row-major uint8, host memory.
  * Writes up to cap keypoints; *n is the true count (SLAMX_ERR_CAPACITY if *n > cap). */

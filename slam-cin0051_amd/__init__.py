@@ -104,7 +104,7 @@ class BatchShape(C.Structure):
 EXPORTS = [
     "slamx_last_error", "slamx_version", "slamx_matcher_mfma_threshold", "slamx_device_count", "slamx_ctx_create", "slamx_ctx_destroy", "slamx_ctx_synchronize",
     "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
-    "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
+    "slamx_detector_context", "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
     "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
@@ -143,12 +143,14 @@ def load_library():
     lib.slamx_last_error.restype = C.c_char_p
     lib.slamx_version.restype = C.c_char_p
     lib.slamx_ctx_stream.restype = C.c_void_p
+    lib.slamx_detector_context.restype = C.c_void_p
     lib.slamx_batch_frames.restype = C.c_void_p
     vp = C.c_void_p
     lib.slamx_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.slamx_ctx_destroy.argtypes = [vp]
     lib.slamx_ctx_synchronize.argtypes = [vp]
     lib.slamx_ctx_stream.argtypes = [vp]
+    lib.slamx_detector_context.argtypes = [vp]
     lib.slamx_ctx_device_name.argtypes = [vp, C.c_char_p, C.c_int]
     lib.slamx_ctx_timer_start.argtypes = [vp]
     lib.slamx_ctx_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]

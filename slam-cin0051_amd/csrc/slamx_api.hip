@@ -703,6 +703,7 @@ int slamx_detector_pattern(const slamx_detector* det, int32_t* xy4, int cap_pair
 } SLAMX_CATCH
 
 int slamx_detector_descriptor_width(const slamx_detector* det) { return det->cfg.num_brief_pairs / 8; }
+slamx_ctx* slamx_detector_context(const slamx_detector* det) { return det != nullptr ? det->ctx : nullptr; }
 
 // ------------------------------------------------------------------ batches
 int slamx_batch_create(slamx_detector* det, const slamx_batch_shape* shape, slamx_batch** out) try {
