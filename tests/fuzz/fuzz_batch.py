@@ -47,7 +47,11 @@ def main():
                 f = np.roll(f, (int(rng.integers(-3, 4)), int(rng.integers(-5, 6))), (0, 1)) + rng.integers(-2, 3, (rows, cols))
                 frames.append(np.clip(f, 0, 255).astype(np.uint8))
         frames = np.stack(frames)
-        cfg = slamx.DetectorConfig(t, arc, 1, window, 31, 256)
+        patch, pairs = 31, 256
+        if rng.integers(0, 4) == 0:  # other descriptor widths through the batch's matcher (1 ... 128 bytes), other patches
+            patch = int(rng.choice([5, 9, 15, 21, 31, 33, 63]))
+            pairs = int(rng.choice([8, 24, 64, 128, 256, 512, 1024]))
+        cfg = slamx.DetectorConfig(t, arc, 1, window, patch, pairs)
         det = slamx.FeatureDetector(cfg)
         P = oracle.det_params(cfg)
         refs = [oracle.detect_and_compute(frames[k], P) for k in range(n)]
@@ -64,8 +68,8 @@ def main():
             os.environ.pop("SLAMX_MATCH_MFMA_MIN_KEYPOINTS", None)
         m = slamx.FeatureMatcher(slamx.MatcherConfig(0, filt, good, ratio_on, ratio))
         mp = oracle.match_params(m.cfg)
-        tag = "case %d: %d frames of %dx%d, t=%d arc=%d window=%d, matcher filter %d/%d ratio %d/%.1f, keypoints %d, first_train_frame %d, mfma %s" % (
-            case, n, rows, cols, t, arc, window, filt, good, ratio_on, ratio, use_kp, ftf, os.environ.get("SLAMX_MATCH_MFMA_MIN_KEYPOINTS"))
+        tag = "case %d: %d frames of %dx%d, t=%d arc=%d window=%d patch=%d pairs=%d, matcher filter %d/%d ratio %d/%.1f, keypoints %d, first_train_frame %d, mfma %s" % (
+            case, n, rows, cols, t, arc, window, patch, pairs, filt, good, ratio_on, ratio, use_kp, ftf, os.environ.get("SLAMX_MATCH_MFMA_MIN_KEYPOINTS"))
         b = slamx.Batch(det, rows, cols, n, max_candidates=rows * cols, max_keypoints=max(64, max(len(r[0]) for r in refs) + 8))
         b.upload(frames)
         for rnd in range(2):  # the second run: the host knows the batch's density (hint), the matcher's scratch exists
