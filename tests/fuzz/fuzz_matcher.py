@@ -63,7 +63,7 @@ def main():
                          rng.integers(3000, 7000)]  # (the last class: the matrix-core scan by the default rule)
         n1 = int(rng.choice(sizes()))
         n2 = int(rng.choice(sizes()))
-        width = int(rng.choice([4, 8, 12, 16, 20, 32, 33, 64]))
+        width = int(rng.choice([1, 3, 4, 8, 12, 16, 20, 32, 33, 64, 96, 128]))
         bits = int(rng.choice([rng.integers(1, 16), 31, 32, 33, 46, 62, 63, 64]))
         bits = min(bits, 8 * min(width, 8))
         d1 = descriptors(rng, n1, width, bits, None)
