@@ -61,6 +61,10 @@ def main():
         rows = int(rng.integers(7, 140))
         cols = int(rng.choice([rng.integers(7, 80), rng.integers(200, 300), rng.integers(500, 560)]))
         t = int(rng.choice([rng.integers(0, 8), rng.integers(8, 64), rng.integers(64, 256)]))
+        if rng.integers(0, 25) == 0:  # a large frame of an odd size: tile and region edges far from the origin (few corners: high threshold)
+            rows = int(rng.integers(300, 1300))
+            cols = int(rng.choice([rng.integers(600, 2100), 1920, 2048, 4096 + int(rng.integers(-3, 4))]))
+            t = int(rng.integers(40, 120))
         arc = int(rng.integers(0, 17))
         window = int(rng.integers(1, 16))
         if rng.integers(0, 10) == 0:  # beyond the greedy kernel's largest window (24): the dependency-round NMS
