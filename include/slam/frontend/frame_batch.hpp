@@ -11,16 +11,39 @@
 //   batch.matchConsecutive(matcher, n);        // frame k against frame k - 1, k = 1 .. n - 1
 //   batch.fetch(n);                            // ONE copy of every result into page-locked memory
 //   batch.keypoints(k, kps); batch.descriptors(k, desc); batch.matches(matcher, k, m);
+//   batch.estimatePoses(camera.intrinsics(), n, options, poses);   // the pose stage of every frame pair, still in HBM
 #pragma once
 
 #include <algorithm>
 #include <cstring>
 #include <vector>
 
+#include <slam/common/camera.hpp>
+
 #include <slam/frontend/feature_detector.hpp>
 #include <slam/frontend/feature_matcher.hpp>
 
 namespace slam {
+
+// Options and results of FrameBatch::estimatePoses (slamx_pose_config / slamx_pose_result, include/slamx.h)
+struct PoseStageOptions {
+    int iterations = 256;            // essential-matrix hypotheses per frame pair
+    double thresholdPx = 1.0;        // Sampson threshold in pixels
+    uint32_t seed = 1;               // the hypotheses' samples are drawn on the device from this seed
+    int pnpIterations = 100;         // RansacMaxIterations (loop_closure.yml); 0 = no PnP step
+    double pnpThreshold = 8.0;       // RansacReprojectionThreshold
+    int pnpMinCorrespondences = 6;   // MinMatchesForPnP
+};
+struct FramePose {
+    bool valid{};                    // false: fewer than 8 matches, or no train frame
+    Mat3d R{1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Vec3d t{0, 0, 0};                // pose of the frame's camera relative to its train frame (|t| = 1)
+    int matches{}, inliers{};
+    bool pnpValid{};                 // the PnP step had enough 3D-2D correspondences and a hypothesis scored
+    Mat3d pnpR{1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Vec3d pnpT{0, 0, 0};
+    int pnpCorrespondences{}, pnpInliers{};
+};
 
 class FrameBatch {
 public:
@@ -133,6 +156,78 @@ public:
         out.resize(static_cast<size_t>(n));
     }
 
+    // The pose stage of the batch (slamx_batch_pose), after matchConsecutive: for every frame its pose
+    // relative to the frame it was matched against -- essential-matrix RANSAC (PoseEstimator::estimate,
+    // pose_estimator.cpp:18-67), the cheirality vote of simpleRecoverPose, triangulated map points -- and the PnP RANSAC of
+    // LoopClosure::verifyGeometricConsistency (loop_closure.cpp:166-222) against the points triangulated one pair earlier;
+    // all pairs in twelve launches, from the keypoints and matches where they are.  Waits for the results.
+    void estimatePoses(const Mat3d& K, int nframes, const PoseStageOptions& opt, std::vector<FramePose>& out, int firstTrainFrame = -1) {
+        if (!m_matched) {
+            throw std::runtime_error("FrameBatch::estimatePoses: matchConsecutive has not run on this batch");
+        }
+        slamx_pose_config cfg{};
+        for (int i = 0; i < 9; ++i) {
+            cfg.K[i] = K[static_cast<size_t>(i)];
+        }
+        cfg.iterations = opt.iterations;
+        cfg.threshold_px = opt.thresholdPx;
+        cfg.seed = opt.seed;
+        cfg.pnp_iterations = opt.pnpIterations;
+        cfg.pnp_threshold = opt.pnpThreshold;
+        cfg.pnp_min_correspondences = opt.pnpMinCorrespondences;
+        if (m_pose == nullptr || std::memcmp(&cfg, &m_poseCfg, sizeof(cfg)) != 0) {
+            slamx_pose_destroy(m_pose);
+            m_pose = nullptr;
+            detail::check(slamx_pose_create(m_batch, &cfg, &m_pose));
+            m_poseCfg = cfg;
+        }
+        detail::check(slamx_batch_pose(m_pose, nframes, firstTrainFrame));
+        std::vector<slamx_pose_result> res(static_cast<size_t>(nframes));
+        detail::check(slamx_pose_download(m_pose, nframes, res.data()));
+        out.assign(static_cast<size_t>(nframes), FramePose{});
+        for (int f = 0; f < nframes; ++f) {
+            const slamx_pose_result& r = res[static_cast<size_t>(f)];
+            FramePose& p = out[static_cast<size_t>(f)];
+            p.valid = (r.status & (SLAMX_POSE_TOO_FEW_MATCHES | SLAMX_POSE_NO_TRAIN_FRAME)) == 0;
+            p.matches = r.n_matches;
+            p.inliers = r.n_inliers;
+            p.pnpCorrespondences = r.pnp_correspondences;
+            p.pnpInliers = r.pnp_inliers;
+            p.pnpValid = (r.status & SLAMX_POSE_PNP_SKIPPED) == 0 && r.pnp_inliers > 0;
+            for (int i = 0; i < 9; ++i) {
+                p.R[static_cast<size_t>(i)] = r.R[i];
+                p.pnpR[static_cast<size_t>(i)] = r.pnp_R[i];
+            }
+            for (int i = 0; i < 3; ++i) {
+                p.t[static_cast<size_t>(i)] = r.t[i];
+                p.pnpT[static_cast<size_t>(i)] = r.pnp_t[i];
+            }
+        }
+    }
+    // The map points estimatePoses triangulated for one frame's pair, parallel to its (unfiltered) match list; inlierMask
+    // (optional): the essential matrix's inlier flag of every match.
+    void mapPoints(int frame, std::vector<Point3d>& points, std::vector<uint8_t>* inlierMask = nullptr) const {
+        if (m_pose == nullptr) {
+            throw std::runtime_error("FrameBatch::mapPoints: estimatePoses has not run on this batch");
+        }
+        int n = 0;
+        const int rc = slamx_pose_download_points(m_pose, frame, nullptr, nullptr, 0, &n);
+        if (rc != SLAMX_OK && rc != SLAMX_ERR_CAPACITY) {
+            detail::check(rc);
+        }
+        std::vector<double> xyz(static_cast<size_t>(n) * 3);
+        if (inlierMask != nullptr) {
+            inlierMask->assign(static_cast<size_t>(n), 0);
+        }
+        if (n > 0) {
+            detail::check(slamx_pose_download_points(m_pose, frame, xyz.data(), inlierMask != nullptr ? inlierMask->data() : nullptr, n, &n));
+        }
+        points.resize(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            points[static_cast<size_t>(i)] = Point3d{xyz[3 * static_cast<size_t>(i)], xyz[3 * static_cast<size_t>(i) + 1], xyz[3 * static_cast<size_t>(i) + 2]};
+        }
+    }
+
 private:
     const int32_t* kpFirst(int frame) const {
         if (frame < 0 || frame >= m_fetched) {
@@ -141,6 +236,8 @@ private:
         return reinterpret_cast<const int32_t*>(m_results + m_header.first_off) + frame;
     }
     void release() {
+        slamx_pose_destroy(m_pose);  // (before its batch)
+        m_pose = nullptr;
         slamx_batch_destroy(m_batch);
         m_batch = nullptr;
         slamx_host_free(m_frames);
@@ -153,6 +250,8 @@ private:
     slamx_ctx* m_ctx;
     int m_width{};
     slamx_batch* m_batch{};
+    slamx_pose* m_pose{};        // created by the first estimatePoses, rebuilt when its options change
+    slamx_pose_config m_poseCfg{};
     uint8_t* m_frames{};   // page-locked: [maxFrames][rows][cols]
     uint8_t* m_results{};  // page-locked: the packed results of the last fetch (slamx_packed_header + arrays)
     size_t m_resultBytes{};

@@ -396,7 +396,7 @@ int slamx_pose_download_correspondences(slamx_pose* p, int frame, double* p3d, d
 #define SLAMX_POSE_STAGE_CHEIRALITY 6  /* cheirality_kernel (4 candidates x every correspondence)             */
 #define SLAMX_POSE_STAGE_TRIANGULATE 7 /* triangulate_pairs_kernel                                            */
 #define SLAMX_POSE_STAGE_PNP_GATHER 8  /* pnp_gather_kernel                                                   */
-#define SLAMX_POSE_STAGE_PNP_SOLVE 9   /* pnp_hyp_kernel (sampling + DLT on FP64 MFMA, wave per hypothesis)   */
+#define SLAMX_POSE_STAGE_PNP_SOLVE 9   /* pnp_hyp_kernel (sampling + 12 x 12 DLT, lane per hypothesis)        */
 #define SLAMX_POSE_STAGE_PNP_SCORE 10  /* pnp_score_kernel + pnp_select_kernel                                */
 #define SLAMX_POSE_STAGE_COUNT 11
 int slamx_pose_set_profiling(slamx_pose* p, int on);

@@ -295,6 +295,14 @@ def test_frame_batch_program(ref_data, folder, repeat):
                  os.path.join(ref_data, "feature_matcher.yml"), str(repeat)] + imgs)
     assert "batch == frame by frame: yes" in text, text
     assert ("%d frames of" % (len(imgs) * repeat)) in text
+    # the pose stage of the same batch through FrameBatch::estimatePoses (camera.yml sits beside the detector's YAML): every
+    # pair that has a pose is consistent, and on the KITTI frames (a car driving forward) every pair has one along z
+    line = [l for l in text.splitlines() if l.startswith("pose stage")]
+    assert len(line) == 1, text
+    nums = [int(x) for x in __import__("re").findall(r"(\d+) with a pose, (\d+) consistent .*?, (\d+) with", line[0])[0]]
+    assert nums[0] == nums[1] and nums[0] > 0
+    if folder == "images":
+        assert nums[0] == len(imgs) - 1 and nums[2] == nums[0], line[0]
 
 
 @pytest.mark.parametrize("batch", [3, 4, 16])

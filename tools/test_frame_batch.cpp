@@ -5,8 +5,10 @@
 //   test_frame_batch <feature_detector.yml> <feature_matcher.yml> <repeat> <img0.png> <img1.png> ...   (images of one size)
 // `repeat` cycles through the images that often (a longer sequence from the reference's ten KITTI frames).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <filesystem>
 #include <string>
 #include <vector>
 
@@ -98,6 +100,57 @@ int main(int argc, char** argv) {
         std::printf("frame by frame (detectAndCompute + match): %.3f ms, %.0f frames/s\n", t_single * 1e3, n / t_single);
         std::printf("one FrameBatch (copy in, detectAndCompute, matchConsecutive, fetch): %.3f ms, %.0f frames/s\n", t_batch * 1e3, n / t_batch);
         std::printf("batch == frame by frame: %s\n", bad == 0 ? "yes" : "NO");
+        // ---- the pose stage of the same batch, when the configuration directory holds a camera.yml: every frame pair's
+        //      essential-matrix RANSAC, cheirality vote, map points and PnP in twelve launches, from the arrays in HBM
+        const std::filesystem::path cam = std::filesystem::path(argv[1]).parent_path() / "camera.yml";
+        if (std::filesystem::exists(cam)) {
+            const slam::Camera camera(cam);
+            slam::PoseStageOptions opt;
+            std::vector<slam::FramePose> poses;
+            t0 = std::chrono::steady_clock::now();
+            batch.estimatePoses(camera.intrinsics(), n, opt, poses);
+            const double t_pose = seconds_since(t0);
+            int valid = 0, sane = 0, forward = 0;
+            size_t points = 0;
+            for (int k = 1; k < n; ++k) {
+                const slam::FramePose& p = poses[static_cast<size_t>(k)];
+                if (!p.valid) {
+                    continue;
+                }
+                ++valid;
+                double ortho = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) {
+                        double d = 0.0;
+                        for (int q = 0; q < 3; ++q) {
+                            d += p.R[static_cast<size_t>(3 * q + i)] * p.R[static_cast<size_t>(3 * q + j)];
+                        }
+                        ortho = std::max(ortho, std::fabs(d - (i == j ? 1.0 : 0.0)));
+                    }
+                }
+                const double tn = std::sqrt(p.t[0] * p.t[0] + p.t[1] * p.t[1] + p.t[2] * p.t[2]);
+                std::vector<slam::Point3d> pts;
+                std::vector<uint8_t> mask;
+                batch.mapPoints(k, pts, &mask);
+                int flagged = 0;
+                for (uint8_t m : mask) {
+                    flagged += m != 0 ? 1 : 0;
+                }
+                if (ortho < 1e-9 && std::fabs(tn - 1.0) < 1e-9 && p.inliers <= p.matches && static_cast<int>(pts.size()) == p.matches && flagged == p.inliers) {
+                    ++sane;
+                }
+                if (std::fabs(p.t[2]) > 0.9) {
+                    ++forward;  // (the KITTI car drives forward; a repeated frame pair has no motion to find)
+                }
+                points += pts.size();
+            }
+            std::printf("pose stage (%d + %d hypotheses per pair): %.3f ms for %d pairs, %d with a pose, %d consistent (R orthonormal, |t| = 1, "
+                        "inlier flags = inlier count, a map point per match), %d with |t_z| > 0.9, %zu map points\n",
+                        opt.iterations, opt.pnpIterations, t_pose * 1e3, n - 1, valid, sane, forward, points);
+            if (sane != valid) {
+                ++bad;
+            }
+        }
         return bad == 0 ? 0 : 1;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "An error occurred: %s\n", e.what());
