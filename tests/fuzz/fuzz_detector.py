@@ -66,6 +66,8 @@ def main():
             cols = int(rng.choice([rng.integers(600, 2100), 1920, 2048, 4096 + int(rng.integers(-3, 4))]))
             t = int(rng.integers(40, 120))
         arc = int(rng.integers(0, 17))
+        if rows * cols > 200000:
+            arc = max(arc, 9)  # (a short arc on megapixels of noise passes 2^20 candidates: the build's documented limit)
         window = int(rng.integers(1, 16))
         if rng.integers(0, 10) == 0:  # beyond the greedy kernel's largest window (24): the dependency-round NMS
             window = int(rng.integers(16, 48))
