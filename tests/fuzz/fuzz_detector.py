@@ -85,7 +85,14 @@ def main():
         det = slamx.FeatureDetector(cfg)
         P = oracle.det_params(cfg)
         step("case %d: %dx%d t=%d arc=%d window=%d nms=%d patch=%d pairs=%d: fast_candidates" % (case, rows, cols, t, arc, window, nms, patch, pairs))
-        got, ref = det.fast_candidates(img), oracle.fast_candidates(img, P)
+        ref = oracle.fast_candidates(img, P)
+        try:
+            got = det.fast_candidates(img)
+        except slamx.CapacityError:
+            # the build's documented limit: 2^20 FAST candidates per frame -- megapixels of noise pass it
+            assert len(ref) > (1 << 20), "capacity error with %d candidates" % len(ref)
+            det.close() if hasattr(det, "close") else None
+            continue
         tag = "case %d: %dx%d t=%d arc=%d window=%d nms=%d patch=%d pairs=%d" % (case, rows, cols, t, arc, window, nms, patch, pairs)
         assert len(got) == len(ref) and np.array_equal(got, ref), "candidates differ, " + tag
         if len(ref) < 4000:  # the oracle's greedy loop is quadratic
