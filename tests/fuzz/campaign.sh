@@ -3,13 +3,13 @@
 out=gpurun_out/campaign
 mkdir -p $out
 n=0
-for seed in $(seq ${DET0:-200} $(( ${DET0:-200} + 29 ))); do
+for seed in $(seq ${DET0:-200} $(( ${DET0:-200} + 11 ))); do
   FUZZ_TRACE=$out/trace_det_$seed.txt timeout -k 10 200 python tests/fuzz/fuzz_detector.py 1500 $seed > $out/det_$seed.log 2>&1 || { echo "DETECTOR seed $seed FAILED"; tail -4 $out/det_$seed.log; tail -3 $out/trace_det_$seed.txt; exit 1; }
   rm -f $out/trace_det_$seed.txt; n=$((n+1500))
 done
 echo "detector: $n cases identical"
 m=0
-for seed in $(seq ${MAT0:-300} $(( ${MAT0:-300} + 7 ))); do
+for seed in $(seq ${MAT0:-300} $(( ${MAT0:-300} + 5 ))); do
   timeout -k 10 300 python tests/fuzz/fuzz_matcher.py 2500 $seed > $out/match_$seed.log 2>&1 || { echo "MATCHER seed $seed FAILED"; tail -4 $out/match_$seed.log; exit 1; }
   m=$((m+2500))
 done
