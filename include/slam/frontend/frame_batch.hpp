@@ -33,6 +33,7 @@ struct PoseStageOptions {
     int pnpIterations = 100;         // RansacMaxIterations (loop_closure.yml); 0 = no PnP step
     double pnpThreshold = 8.0;       // RansacReprojectionThreshold
     int pnpMinCorrespondences = 6;   // MinMatchesForPnP
+    int geometryMode = SLAMX_GEOMETRY_REFERENCE;  // SLAMX_GEOMETRY_CALIBRATED: the build-defined corrected solve (include/slamx.h)
 };
 struct FramePose {
     bool valid{};                    // false: fewer than 8 matches, or no train frame
@@ -104,6 +105,7 @@ public:
     void matchConsecutive(const FeatureMatcher& matcher, int nframes, bool useKeypoints = true, int firstTrainFrame = -1) {
         detail::check(slamx_batch_match_consecutive(m_batch, matcher.handle(), nframes, useKeypoints ? 1 : 0, firstTrainFrame));
         m_matched = true;
+        m_firstTrainFrame = firstTrainFrame;
     }
 
     // Every result of frames 0 .. nframes - 1 in one copy; waits for the batch.  Throws on a capacity overflow.
@@ -161,9 +163,14 @@ public:
     // pose_estimator.cpp:18-67), the cheirality vote of simpleRecoverPose, triangulated map points -- and the PnP RANSAC of
     // LoopClosure::verifyGeometricConsistency (loop_closure.cpp:166-222) against the points triangulated one pair earlier;
     // all pairs in twelve launches, from the keypoints and matches where they are.  Waits for the results.
-    void estimatePoses(const Mat3d& K, int nframes, const PoseStageOptions& opt, std::vector<FramePose>& out, int firstTrainFrame = -1) {
+    // firstTrainFrame: the slot frame 0 was matched against; by default the one matchConsecutive was given.
+    static constexpr int kAsMatched = -2;
+    void estimatePoses(const Mat3d& K, int nframes, const PoseStageOptions& opt, std::vector<FramePose>& out, int firstTrainFrame = kAsMatched) {
         if (!m_matched) {
             throw std::runtime_error("FrameBatch::estimatePoses: matchConsecutive has not run on this batch");
+        }
+        if (firstTrainFrame == kAsMatched) {
+            firstTrainFrame = m_firstTrainFrame;
         }
         slamx_pose_config cfg{};
         for (int i = 0; i < 9; ++i) {
@@ -175,7 +182,8 @@ public:
         cfg.pnp_iterations = opt.pnpIterations;
         cfg.pnp_threshold = opt.pnpThreshold;
         cfg.pnp_min_correspondences = opt.pnpMinCorrespondences;
-        if (m_pose == nullptr || std::memcmp(&cfg, &m_poseCfg, sizeof(cfg)) != 0) {
+        cfg.geometry_mode = opt.geometryMode;
+        if (m_pose == nullptr || !sameConfig(cfg, m_poseCfg)) {
             slamx_pose_destroy(m_pose);
             m_pose = nullptr;
             detail::check(slamx_pose_create(m_batch, &cfg, &m_pose));
@@ -229,6 +237,12 @@ public:
     }
 
 private:
+    // field by field: the struct has padding, which a copy need not preserve
+    static bool sameConfig(const slamx_pose_config& a, const slamx_pose_config& b) {
+        return std::equal(a.K, a.K + 9, b.K) && a.iterations == b.iterations && a.threshold_px == b.threshold_px && a.seed == b.seed &&
+               a.pnp_iterations == b.pnp_iterations && a.pnp_threshold == b.pnp_threshold &&
+               a.pnp_min_correspondences == b.pnp_min_correspondences && a.max_matches == b.max_matches && a.geometry_mode == b.geometry_mode;
+    }
     const int32_t* kpFirst(int frame) const {
         if (frame < 0 || frame >= m_fetched) {
             throw std::invalid_argument("FrameBatch: frame not fetched");
@@ -258,6 +272,7 @@ private:
     slamx_packed_header m_header{};
     int m_fetched{};
     bool m_matched{};
+    int m_firstTrainFrame{-1};
 };
 
 }  // namespace slam

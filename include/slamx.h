@@ -324,6 +324,12 @@ int slamx_essential_from_samples(slamx_ctx* ctx, const float* pts1, const float*
                                  uint8_t* inlier_mask);
 int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, const int32_t* idx,
                            int iterations, double threshold, double* R, double* t, int32_t* max_inliers);
+/* ... with the hypothesis form named (geometry_mode: SLAMX_GEOMETRY_REFERENCE = the call above,
+ * SLAMX_GEOMETRY_CALIBRATED: see slamx_pose_config below); Rt_all (optional) [iterations][12] and counts (optional) [iterations] receive every
+ * hypothesis' pose (R row-major, then t) and inlier count. */
+int slamx_pnp_from_samples_mode(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
+                                const int32_t* idx, int iterations, double threshold, int geometry_mode, double* R, double* t,
+                                int32_t* max_inliers, double* Rt_all, int32_t* counts);
 
 /* ---- the pose stage of a device-resident batch (BASELINE.json configs[2]: "+ 2-view essential-matrix / PnP pose") ----
  * For every frame f of the batch whose matches against its predecessor are on the device (slamx_batch_match_consecutive:
@@ -341,7 +347,8 @@ int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d,
  *      QUERY frame the train frame is): 3D point of match.trainIdx, 2D keypoint of match.queryIdx, for every match whose
  *      train keypoint has a map point; 6-point DLT solvePnP hypotheses (loop_closure.cpp:238-274), reprojection inlier
  *      count, first maximum from maxInliers = 0 (identity / zero when nothing scores).  Fewer than
- *      max(6, pnp_min_correspondences) correspondences: SLAMX_POSE_PNP_SKIPPED.
+ *      max(6, pnp_min_correspondences) correspondences: SLAMX_POSE_PNP_SKIPPED -- also for frame 0 when its train
+ *      slot first_train_frame is not one of this call's frames [0, nframes): that slot's map points are not this call's.
  * Samples are drawn on the device by a counter-based generator (splitmix64 of (seed, frame slot, hypothesis, draw),
  * indices redrawn until distinct as loop_closure.cpp:185-193 does); slamx_pose_download_samples returns the tables.
  * The match lists are taken as slamx_batch_match_consecutive left them (query order, before filterAndSortMatches). */
@@ -354,7 +361,27 @@ typedef struct slamx_pose_config {
     double pnp_threshold;      /* RansacReprojectionThreshold                                                */
     int32_t pnp_min_correspondences; /* MinMatchesForPnP; values below 6 mean 6                              */
     int32_t max_matches;       /* capacity per frame pair; 0 = the batch's max_keypoints                     */
+    int32_t geometry_mode;     /* SLAMX_GEOMETRY_REFERENCE (0, default) or SLAMX_GEOMETRY_CALIBRATED         */
 } slamx_pose_config;
+/* Two steps of the reference's pose code mix units, so that on a scene with real depth and a real K they return
+ * something else than the motion (hard part 6).  geometry_mode says which form the stage runs:
+ * SLAMX_GEOMETRY_REFERENCE -- both steps exactly as the reference writes them:
+ *   - simpleRecoverPose triangulates the K^-1-NORMALISED points it is handed (pose_estimator.cpp:53-66) against
+ *     K [I|0] and K [R|t] (simple_pose_recover.cpp:61-82): the cheirality vote then gives all correspondences to one
+ *     candidate whatever the geometry, R comes out right and the SIGN of t is arbitrary;
+ *   - LoopClosure::solvePnP (loop_closure.cpp:238-274): the DLT on PIXEL coordinates, the COLUMN-major 3x4 map of the
+ *     row-major DLT vector (:260), t = t0 / ||R0||_F (:271: sqrt(3) times the scale of a scaled rotation) -- no
+ *     hypothesis of this form reprojects a real scene within the threshold.
+ *   This mode reproduces the reference, arbitrary sign and zero inliers included; the parity tests use it.
+ * SLAMX_GEOMETRY_CALIBRATED (build-defined, NO reference counterpart, parity unpinned) -- the unit-consistent forms:
+ *   - the cheirality vote triangulates the normalised points against [I|0] and [R|t] (= simpleRecoverPose called with
+ *     K = identity; slamx_recover_pose with an identity K is the one-pair form);
+ *   - the PnP DLT runs on K^-1-normalised image points (K upper triangular with K[8] = 1), the ROW-major 3x4 map, the sign
+ *     of the null vector chosen so that det(R0) > 0, the same orthonormalisation R = U diag(1, 1, det(U V^T)) V^T,
+ *     t = t0 / mean singular value of R0.  The inlier test (loop_closure.cpp:201-215) is the reference's in both modes.
+ * Everything else of the stage (gather, essential-matrix RANSAC, decomposeEssential, triangulatePoints) is common. */
+#define SLAMX_GEOMETRY_REFERENCE 0
+#define SLAMX_GEOMETRY_CALIBRATED 1
 #define SLAMX_POSE_TOO_FEW_MATCHES 1 /* fewer than 8 matches: no essential matrix, no map points             */
 #define SLAMX_POSE_PNP_SKIPPED 2     /* fewer correspondences than the PnP step needs                        */
 #define SLAMX_POSE_MATCH_OVERFLOW 4  /* more matches than max_matches: the first max_matches were used        */

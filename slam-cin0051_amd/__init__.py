@@ -78,9 +78,10 @@ class PoseConfig(C.Structure):
     """slamx_pose_config (include/slamx.h): the pose stage of a batch."""
     _fields_ = [("K", C.c_double * 9), ("iterations", C.c_int32), ("threshold_px", C.c_double), ("seed", C.c_uint32),
                 ("pnp_iterations", C.c_int32), ("pnp_threshold", C.c_double), ("pnp_min_correspondences", C.c_int32),
-                ("max_matches", C.c_int32)]
+                ("max_matches", C.c_int32), ("geometry_mode", C.c_int32)]
 
 
+GEOMETRY_REFERENCE, GEOMETRY_CALIBRATED = 0, 1  # SLAMX_PNP_* (include/slamx.h)
 POSE_RESULT_DTYPE = np.dtype([("E", "<f8", (3, 3)), ("R", "<f8", (3, 3)), ("t", "<f8", (3,)), ("pnp_R", "<f8", (3, 3)),
                               ("pnp_t", "<f8", (3,)), ("n_matches", "<i4"), ("n_inliers", "<i4"), ("front", "<i4", (4,)),
                               ("pnp_correspondences", "<i4"), ("pnp_inliers", "<i4"), ("status", "<i4"),
@@ -114,7 +115,7 @@ EXPORTS = [
     "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_packed_bound", "slamx_batch_download_packed_async",
     "slamx_batch_download_packed_tail", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
-    "slamx_essential_from_samples", "slamx_pnp_from_samples", "slamx_pose_create", "slamx_pose_destroy", "slamx_batch_pose",
+    "slamx_essential_from_samples", "slamx_pnp_from_samples", "slamx_pnp_from_samples_mode", "slamx_pose_create", "slamx_pose_destroy", "slamx_batch_pose",
     "slamx_pose_download", "slamx_pose_download_points", "slamx_pose_download_samples", "slamx_pose_download_correspondences", "slamx_pose_download_hypotheses", "slamx_pose_download_pnp_hypotheses",
     "slamx_pose_set_profiling", "slamx_pose_stage_ms", "slamx_batch_upload_results",
     "slamx_undistort",
@@ -207,6 +208,8 @@ def load_library():
     lib.slamx_essential_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp]
     lib.slamx_essential_from_samples.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp, vp]
     lib.slamx_pnp_from_samples.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, vp, vp, C.POINTER(C.c_int32)]
+    lib.slamx_pnp_from_samples_mode.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp,
+                                                C.POINTER(C.c_int32), vp, vp]
     lib.slamx_pose_create.argtypes = [vp, C.POINTER(PoseConfig), C.POINTER(vp)]
     lib.slamx_pose_destroy.argtypes = [vp]
     lib.slamx_pose_destroy.restype = None
@@ -492,7 +495,9 @@ class Context(_Owner):
                                                      float(threshold_px), _ptr(E), C.byref(cnt), _ptr(mask)))
         return E, cnt.value, mask
 
-    def pnp_from_samples(self, p3d, p2d, K, table, threshold):
+    def pnp_from_samples(self, p3d, p2d, K, table, threshold, geometry_mode=None, all_hypotheses=False):
+        """-> (R, t, max_inliers); with all_hypotheses also (R_all [H, 3, 3], t_all [H, 3], counts [H]).  geometry_mode None =
+        the reference-signature call, GEOMETRY_REFERENCE / GEOMETRY_CALIBRATED = slamx_pnp_from_samples_mode."""
         a = np.ascontiguousarray(p3d, dtype=np.float64)
         b = np.ascontiguousarray(p2d, dtype=np.float64)
         Kc = np.ascontiguousarray(K, dtype=np.float64)
@@ -500,9 +505,17 @@ class Context(_Owner):
         R = np.empty((3, 3))
         t = np.empty(3)
         best = C.c_int32()
-        _check(self.lib.slamx_pnp_from_samples(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(tb), tb.shape[0],
-                                               float(threshold), _ptr(R), _ptr(t), C.byref(best)))
-        return R, t, best.value
+        if geometry_mode is None and not all_hypotheses:
+            _check(self.lib.slamx_pnp_from_samples(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(tb), tb.shape[0],
+                                                   float(threshold), _ptr(R), _ptr(t), C.byref(best)))
+            return R, t, best.value
+        H = tb.shape[0]
+        Rt, cnt = np.empty((H, 12)), np.zeros(H, np.int32)
+        _check(self.lib.slamx_pnp_from_samples_mode(self.h, _ptr(a), _ptr(b), a.shape[0], _ptr(Kc), _ptr(tb), H, float(threshold),
+                                                    int(geometry_mode or 0), _ptr(R), _ptr(t), C.byref(best), _ptr(Rt), _ptr(cnt)))
+        if not all_hypotheses:
+            return R, t, best.value
+        return R, t, best.value, Rt[:, :9].reshape(H, 3, 3).copy(), Rt[:, 9:].copy(), cnt
 
     def recover_pose(self, E, pts1, pts2, K):
         Ec = np.ascontiguousarray(E, dtype=np.float64)
@@ -795,7 +808,7 @@ class PoseStage(_Owner):
     every frame pair of a batch, device-resident, a fixed number of launches per call."""
 
     def __init__(self, batch, K, iterations=256, threshold_px=1.0, seed=0, pnp_iterations=0, pnp_threshold=2.0,
-                 pnp_min_correspondences=6, max_matches=0):
+                 pnp_min_correspondences=6, max_matches=0, geometry_mode=GEOMETRY_REFERENCE):
         self.batch = batch
         self.lib = batch.lib
         cfg = PoseConfig()
@@ -805,6 +818,7 @@ class PoseStage(_Owner):
         cfg.iterations, cfg.threshold_px, cfg.seed = int(iterations), float(threshold_px), int(seed)
         cfg.pnp_iterations, cfg.pnp_threshold = int(pnp_iterations), float(pnp_threshold)
         cfg.pnp_min_correspondences, cfg.max_matches = int(pnp_min_correspondences), int(max_matches)
+        cfg.geometry_mode = int(geometry_mode)
         self.cfg = cfg
         self._hd = _Handle(self.lib.slamx_pose_destroy, batch._hd)
         _check(self.lib.slamx_pose_create(batch.h, C.byref(cfg), C.byref(self._hd.value)))

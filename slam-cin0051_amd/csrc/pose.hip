@@ -795,6 +795,22 @@ __device__ __forceinline__ bool sampson_inlier(Ptr e, double u1, double v1, doub
     return (den > 0.0) & (r * r < thr2 * den);  // (no short circuit: straight-line code)
 }
 
+// The same test, and the correspondence's term of the MSAC cost of the model: its squared Sampson distance when it is an
+// inlier, the squared threshold otherwise (pose_final_kernel compares the refit with the winning sample on that cost).
+template <typename Ptr>
+__device__ __forceinline__ bool sampson_inlier_cost(Ptr e, double u1, double v1, double u2, double v2, double thr2, double* cost) {
+    const double ex0 = __builtin_fma(e[0], u1, __builtin_fma(e[1], v1, e[2]));
+    const double ex1 = __builtin_fma(e[3], u1, __builtin_fma(e[4], v1, e[5]));
+    const double ex2 = __builtin_fma(e[6], u1, __builtin_fma(e[7], v1, e[8]));
+    const double et0 = __builtin_fma(e[0], u2, __builtin_fma(e[3], v2, e[6]));
+    const double et1 = __builtin_fma(e[1], u2, __builtin_fma(e[4], v2, e[7]));
+    const double r = __builtin_fma(u2, ex0, __builtin_fma(v2, ex1, ex2));
+    const double den = __builtin_fma(ex0, ex0, __builtin_fma(ex1, ex1, __builtin_fma(et0, et0, et1 * et1)));
+    const bool in = (den > 0.0) & (r * r < thr2 * den);
+    *cost = in ? (r * r) / den : thr2;
+    return in;
+}
+
 // En (conditioned null vector, row-major 3 x 3) -> essential matrix: undo the conditioning (E = T2^T En T1,
 // T = [s 0 -s cx; 0 s -s cy; 0 0 1]) and project onto singular values (1, 1, 0).
 __device__ void essential_from_null_vector(const double* En, double s1, double c1x, double c1y, double s2, double c2x,
@@ -1296,10 +1312,16 @@ __device__ void decompose_essential(const double* E, const double* K, double* po
     }
 }
 
-// ---- does the refit explain at least as many correspondences?  Then the result's matrix, flags and the four
-//      candidate poses; one workgroup per pair ----
+// ---- is the refit the better model?  Then the result's matrix, flags and the four candidate poses; one workgroup per
+//      pair.  "Better" is the MSAC cost (sum over the correspondences of min(d^2, thr^2), d = Sampson distance): until round
+//      5 the refit was kept only if it had at least as many INLIERS as the winning sample -- but the winner of a count
+//      contest among near-equal models is the one that also collects a few wrong matches lying near its epipolar lines,
+//      so an accurate refit lost to it by a handful of counts and the stage returned a minimal-sample model (rotation
+//      error 0.04 deg, translation direction 1.6 deg on bench.py's scene; with the cost rule 0.001 / 0.02 deg).
+//      Sums in a fixed order (thread-strided partial sums, shuffles, four waves in wave order): no floating-point atomics.
 __global__ __launch_bounds__(256) void pose_final_kernel(PoseWork w, PoseParams prm) {
     __shared__ int total;
+    __shared__ double wave_part[4];
     const int p = blockIdx.x;
     const int n = w.n[p];
     if (n < 8) {
@@ -1309,46 +1331,68 @@ __global__ __launch_bounds__(256) void pose_final_kernel(PoseWork w, PoseParams 
         total = 0;
     }
     __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double2* X1 = w.x1 + static_cast<size_t>(p) * prm.cap;
     const double2* X2 = w.x2 + static_cast<size_t>(p) * prm.cap;
     const uint8_t* fa = w.flags_a + static_cast<size_t>(p) * prm.cap;
     uint8_t* fb = w.flags_b + static_cast<size_t>(p) * prm.cap;
-    double e[9];
+    double e[9], eb[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         e[k] = w.Efit[static_cast<size_t>(p) * 9 + k];
+        eb[k] = w.Ebest[static_cast<size_t>(p) * 9 + k];
     }
     int mine = 0;
+    double cost_fit = 0.0, cost_best = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) {
         const double2 a = X1[i], b = X2[i];
-        const bool in = sampson_inlier(e, a.x, a.y, b.x, b.y, prm.thr2);
+        double cf, cb;
+        const bool in = sampson_inlier_cost(e, a.x, a.y, b.x, b.y, prm.thr2, &cf);
+        (void)sampson_inlier_cost(eb, a.x, a.y, b.x, b.y, prm.thr2, &cb);
         fb[i] = in ? 1 : 0;
         mine += in ? 1 : 0;
+        cost_fit += cf;
+        cost_best += cb;
     }
     if (mine != 0) {
         atomicAdd(&total, mine);
     }
+    const double sum_fit = block_sum4(cost_fit, wave_part, wave);
+    const double sum_best = block_sum4(cost_best, wave_part, wave);
     __syncthreads();
-    const int count_best = w.sel[p * 4 + 1];
-    const bool use_fit = total >= count_best;  // kept only if it explains at least as many correspondences
-    if (!use_fit) {
-        for (int i = threadIdx.x; i < n; i += 256) {
+    const bool use_fit = sum_fit <= sum_best;  // the refit is kept iff its MSAC cost is not higher
+    // whichever model is kept becomes the pair's current one -- matrix, flags and count -- so that the next (refit, final)
+    // round (POSE_REFIT_ROUNDS of them) refits on ITS inliers: a local-optimisation loop, each round either improves the
+    // cost or leaves everything as it was
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (use_fit) {
+            const_cast<uint8_t*>(fa)[i] = fb[i];
+        } else {
             fb[i] = fa[i];
         }
     }
     if (threadIdx.x == 0) {
+        const int count_best = w.sel[p * 4 + 1];
         w.sel[p * 4 + 2] = total;
         w.sel[p * 4 + 3] = use_fit ? 1 : 0;
-        const double* src = (use_fit ? w.Efit : w.Ebest) + static_cast<size_t>(p) * 9;
         slamx_pose_result& r = w.res[p];
         double E[9];
         for (int k = 0; k < 9; ++k) {
-            E[k] = src[k];
+            E[k] = use_fit ? e[k] : eb[k];
             r.E[k] = E[k];
+        }
+        if (use_fit) {
+            for (int k = 0; k < 9; ++k) {
+                w.Ebest[static_cast<size_t>(p) * 9 + k] = E[k];
+            }
+            w.sel[p * 4 + 1] = total;
         }
         r.n_inliers = use_fit ? total : count_best;
         r.best_hypothesis = w.sel[p * 4 + 0];
-        decompose_essential(E, prm.K, w.poses4 + static_cast<size_t>(p) * 48, w.KP + static_cast<size_t>(p) * 48);
+        // SLAMX_GEOMETRY_CALIBRATED: the vote's projection matrices are [R|t] themselves (K = identity), see slamx.h
+        const double Kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        decompose_essential(E, prm.geometry_mode == SLAMX_GEOMETRY_CALIBRATED ? Kid : prm.K, w.poses4 + static_cast<size_t>(p) * 48,
+                            w.KP + static_cast<size_t>(p) * 48);
         for (int i = 0; i < 4; ++i) {
             w.front[p * 4 + i] = 0;
         }
@@ -1369,7 +1413,7 @@ __global__ __launch_bounds__(256) void cheirality_pairs_kernel(PoseWork w, PoseP
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            KP0[r * 4 + c] = c < 3 ? prm.K[r * 3 + c] : 0.0;
+            KP0[r * 4 + c] = c < 3 ? (prm.geometry_mode == SLAMX_GEOMETRY_CALIBRATED ? (r == c ? 1.0 : 0.0) : prm.K[r * 3 + c]) : 0.0;
         }
     }
     double kp[12];
@@ -1506,7 +1550,10 @@ __global__ __launch_bounds__(1024) void pnp_gather_kernel(PoseSource src, PoseWo
     const int p = blockIdx.x;
     const int tf = p > 0 ? p - 1 : first_train_frame;
     const int n = w.n[p];
-    const int nt = tf >= 0 ? w.n[tf] : 0;  // map points of the train frame (none when its pair had fewer than 8 matches)
+    // map points of the train frame (none when its pair had fewer than 8 matches).  A train slot outside this call's
+    // frames (frame 0 against first_train_frame >= nframes) was not triangulated by this call: whatever an earlier call
+    // left there belongs to other match lists, so frame 0 then has no PnP step (SLAMX_POSE_PNP_SKIPPED)
+    const int nt = tf >= 0 && tf < static_cast<int>(gridDim.x) ? w.n[tf] : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int carry = 0;
     if (tf >= 0 && nt >= 8) {
@@ -1621,7 +1668,11 @@ __global__ __launch_bounds__(64) void pnp_hyp_kernel(PoseWork w, PoseParams prm)
     for (int i = 0; i < 6; ++i) {
         const double X = c3[3 * static_cast<size_t>(idx[i])], Y = c3[3 * static_cast<size_t>(idx[i]) + 1],
                      Z = c3[3 * static_cast<size_t>(idx[i]) + 2];
-        const double u = c2[2 * static_cast<size_t>(idx[i])], v = c2[2 * static_cast<size_t>(idx[i]) + 1];
+        double u = c2[2 * static_cast<size_t>(idx[i])], v = c2[2 * static_cast<size_t>(idx[i]) + 1];
+        if (prm.geometry_mode == SLAMX_GEOMETRY_CALIBRATED) {  // (uniform) K^-1 of an upper-triangular K with K[8] = 1
+            v = (v - prm.K[5]) / prm.K[4];
+            u = (u - prm.K[2] - prm.K[1] * v) / prm.K[0];
+        }
         const double r0[12] = {X, Y, Z, 1.0, 0.0, 0.0, 0.0, 0.0, -u * X, -u * Y, -u * Z, -u};
         const double r1[12] = {0.0, 0.0, 0.0, 0.0, X, Y, Z, 1.0, -v * X, -v * Y, -v * Z, -v};
 #pragma unroll
@@ -1733,16 +1784,27 @@ __global__ __launch_bounds__(64) void pnp_hyp_kernel(PoseWork w, PoseParams prm)
     }
     // :260 column-major 3x4 map of the row-major DLT vector (reference behaviour, kept), :262-271 orthonormalisation
     double R0[9], t0[3];
+    const bool calibrated = prm.geometry_mode == SLAMX_GEOMETRY_CALIBRATED;  // uniform
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            R0[r * 3 + c] = x[c * 3 + r];
+            R0[r * 3 + c] = calibrated ? x[r * 4 + c] : x[c * 3 + r];
         }
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        t0[r] = x[9 + r];
+        t0[r] = calibrated ? x[r * 4 + 3] : x[9 + r];
+    }
+    if (calibrated && det3(R0) < 0.0) {  // the null vector's sign: the one whose left 3 x 3 block is orientation-preserving
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            R0[k] = -R0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t0[k] = -t0[k];
+        }
     }
     double Ur[9], Sr[3], Vr[9], Vrt[9], UVt[9], UD[9], Rm[9];
     svd3(R0, Ur, Sr, Vr);
@@ -1761,6 +1823,9 @@ __global__ __launch_bounds__(64) void pnp_hyp_kernel(PoseWork w, PoseParams prm)
         fro += R0[k] * R0[k];
     }
     fro = sqrt(fro);
+    if (calibrated) {
+        fro = (Sr[0] + Sr[1] + Sr[2]) / 3.0;  // the scale of a scaled rotation (||.||_F is sqrt(3) times that)
+    }
     double* out = w.pRt + hh * 12;
     for (int k = 0; k < 9; ++k) {
         out[k] = Rm[k];

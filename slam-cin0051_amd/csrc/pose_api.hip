@@ -58,6 +58,18 @@ void pose_free(slamx_pose* p) {
     delete p;
 }
 
+// SLAMX_GEOMETRY_CALIBRATED normalises image points with the closed-form inverse of an upper-triangular K
+int check_geometry_mode(int mode, const double* K) {
+    if (mode != SLAMX_GEOMETRY_REFERENCE && mode != SLAMX_GEOMETRY_CALIBRATED) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "geometry_mode: SLAMX_GEOMETRY_REFERENCE or SLAMX_GEOMETRY_CALIBRATED");
+    }
+    if (mode == SLAMX_GEOMETRY_CALIBRATED &&
+        !(K[0] > 0.0 && K[4] > 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0)) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "SLAMX_GEOMETRY_CALIBRATED needs an upper-triangular K with K[8] = 1 and positive focal lengths");
+    }
+    return SLAMX_OK;
+}
+
 int fill_params(const slamx_pose_config& c, int cap, PoseParams* prm) {
     if (c.iterations < 1 || c.iterations > 65536 || !(c.threshold_px > 0.0) || c.pnp_iterations < 0 || c.pnp_iterations > 65536 ||
         (c.pnp_iterations > 0 && !(c.pnp_threshold > 0.0))) {
@@ -81,6 +93,8 @@ int fill_params(const slamx_pose_config& c, int cap, PoseParams* prm) {
     prm->seed = c.seed;
     prm->cap = cap;
     prm->device_sampling = 1;
+    SLAMX_TRY(check_geometry_mode(c.geometry_mode, c.K));
+    prm->geometry_mode = c.geometry_mode;
     return SLAMX_OK;
 }
 
@@ -277,11 +291,19 @@ int slamx_count_inliers_batch(slamx_ctx* ctx, const double* p3d, const double* p
 
 // ------------------------------------------------------------------ the RANSAC of verifyGeometricConsistency, one frame
 int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K, const int32_t* idx,
-                           int iterations, double threshold, double* R, double* t, int32_t* max_inliers) try {
+                           int iterations, double threshold, double* R, double* t, int32_t* max_inliers) {
+    return slamx_pnp_from_samples_mode(ctx, p3d, p2d, n, K, idx, iterations, threshold, SLAMX_GEOMETRY_REFERENCE, R, t, max_inliers,
+                                       nullptr, nullptr);
+}
+
+int slamx_pnp_from_samples_mode(slamx_ctx* ctx, const double* p3d, const double* p2d, int n, const double* K,
+                                const int32_t* idx, int iterations, double threshold, int geometry_mode, double* R, double* t,
+                                int32_t* max_inliers, double* Rt_all, int32_t* counts) try {
     if (n < 6 || iterations <= 0 || iterations > 65536 || p3d == nullptr || p2d == nullptr || K == nullptr || R == nullptr ||
         t == nullptr || idx == nullptr || !(threshold > 0.0)) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "ransac arguments invalid (needs >= 6 correspondences)");
     }
+    SLAMX_TRY(check_geometry_mode(geometry_mode, K));
     for (size_t i = 0; i < static_cast<size_t>(iterations) * 6; ++i) {
         if (idx[i] < 0 || idx[i] >= n) {
             return fail(SLAMX_ERR_INVALID_ARGUMENT, "pnp sample table: index out of range");
@@ -297,6 +319,7 @@ int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d,
     prm.pnp_threshold = threshold;
     prm.pnp_min = 6;
     prm.device_sampling = 0;
+    prm.geometry_mode = geometry_mode;
     const PoseWork& w = sp->w;
     slamx_pose_result init{};
     init.pnp_R[0] = init.pnp_R[4] = init.pnp_R[8] = 1.0;  // :173-175 identity / zero until a hypothesis scores
@@ -311,6 +334,12 @@ int slamx_pnp_from_samples(slamx_ctx* ctx, const double* p3d, const double* p2d,
     HIP_TRY(hipGetLastError());
     slamx_pose_result r{};
     HIP_TRY(hipMemcpyAsync(&r, w.res, sizeof(r), hipMemcpyDeviceToHost, s));
+    if (Rt_all != nullptr) {
+        HIP_TRY(hipMemcpyAsync(Rt_all, w.pRt, static_cast<size_t>(iterations) * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (counts != nullptr) {
+        HIP_TRY(hipMemcpyAsync(counts, w.pcounts, static_cast<size_t>(iterations) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(R, r.pnp_R, 72);
     std::memcpy(t, r.pnp_t, 24);
@@ -382,8 +411,10 @@ int slamx_essential_from_samples(slamx_ctx* ctx, const float* pts1, const float*
     launch_essential_hypotheses(w, prm, 1, s);
     launch_sampson_score(w, prm, 1, s);
     launch_pose_select(w, prm, 1, s);
-    launch_essential_refit_pairs(w, prm, 1, s);
-    launch_pose_final(w, prm, 1, s);
+    for (int round = 0; round < POSE_REFIT_ROUNDS; ++round) {
+        launch_essential_refit_pairs(w, prm, 1, s);
+        launch_pose_final(w, prm, 1, s);
+    }
     HIP_TRY(hipGetLastError());
     slamx_pose_result r{};
     HIP_TRY(hipMemcpyAsync(&r, w.res, sizeof(r), hipMemcpyDeviceToHost, s));
@@ -572,7 +603,14 @@ int slamx_batch_pose(slamx_pose* p, int nframes, int first_train_frame) try {
     rec(p, set, 3);
     launch_pose_select(w, prm, nframes, s);
     rec(p, set, 4);
-    launch_essential_refit_pairs(w, prm, nframes, s);
+    // POSE_REFIT_ROUNDS x (refit on the current model's inliers, keep it iff its MSAC cost is not higher); the "refit"
+    // bracket holds every launch of the loop but the last pose_final_kernel
+    for (int round = 0; round < POSE_REFIT_ROUNDS; ++round) {
+        launch_essential_refit_pairs(w, prm, nframes, s);
+        if (round + 1 < POSE_REFIT_ROUNDS) {
+            launch_pose_final(w, prm, nframes, s);
+        }
+    }
     rec(p, set, 5);
     launch_pose_final(w, prm, nframes, s);
     rec(p, set, 6);

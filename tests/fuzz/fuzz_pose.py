@@ -66,12 +66,13 @@ def main():
         batch = slamx.Batch(det, 64, 64, F, 1024, max(n_points, 256))
         for k, (kps, m) in enumerate(frames):
             batch.upload_results(k, kps, m)
+        mode = int(rng.integers(0, 2))  # SLAMX_GEOMETRY_REFERENCE / _CALIBRATED (the vote and the PnP form, include/slamx.h)
         pose = slamx.PoseStage(batch, T.K, iterations=iterations, threshold_px=thr, seed=int(rng.integers(0, 2**31)),
-                               pnp_iterations=pnp_iterations, pnp_threshold=pnp_thr)
+                               pnp_iterations=pnp_iterations, pnp_threshold=pnp_thr, geometry_mode=mode)
         pose.run(F, -1)
         res = pose.download(F)
-        tag = "case %d: kind %d, %d points, %d frames, outliers %.2f, noise %.2f, keep %.2f, %d + %d hypotheses, thresholds %.2f / %g" % (
-            case, kind, n_points, F, outliers, noise, keep, iterations, pnp_iterations, thr, pnp_thr)
+        tag = "case %d: kind %d, %d points, %d frames, outliers %.2f, noise %.2f, keep %.2f, %d + %d hypotheses, thresholds %.2f / %g, geometry mode %d" % (
+            case, kind, n_points, F, outliers, noise, keep, iterations, pnp_iterations, thr, pnp_thr, mode)
         # the oracle's comparison needs a scene the 8-point solve is conditioned on, and enough hypotheses for a consensus
         well = kind < 2 and n_points >= 40 and outliers <= 0.3 and noise <= 0.3 and iterations >= 16
         try:
@@ -79,7 +80,7 @@ def main():
                 if len(frames[k][1]) < 8:
                     assert res[k]["status"] & slamx.POSE_TOO_FEW_MATCHES, "fewer than 8 matches must be refused"
                     continue
-                T.check_pair(slamx, ctx, oracle, pose, res, frames, k, thr, pnp_thr, check_oracle=well)
+                T.check_pair(slamx, ctx, oracle, pose, res, frames, k, thr, pnp_thr, check_oracle=well, geometry_mode=mode)
                 checked += 1
                 with_oracle += 1 if well else 0
             pose.run(F, -1)

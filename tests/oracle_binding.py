@@ -145,6 +145,28 @@ class Oracle:
         ok = self.lib.oracle_solve_pnp(a.shape[0], _p(a), _p(b), _p(R), _p(t), _p(nv))
         return ok, R, t, nv
 
+    def pnp_calibrated_from_null_vector(self, nullvec):
+        """SLAMX_GEOMETRY_CALIBRATED (build-defined): row-major map, det(R0) > 0, t0 / mean singular value."""
+        p = np.ascontiguousarray(nullvec, np.float64)
+        R, t = np.empty((3, 3)), np.empty(3)
+        self.lib.oracle_pnp_calibrated_from_null_vector(_p(p), _p(R), _p(t))
+        return R, t
+
+    def solve_pnp_calibrated(self, p3d, p2d, K):
+        a = np.ascontiguousarray(p3d, np.float64)
+        b = np.ascontiguousarray(p2d, np.float64)
+        R, t, nv = np.empty((3, 3)), np.empty(3), np.empty(12)
+        ok = self.lib.oracle_solve_pnp_calibrated(a.shape[0], _p(a), _p(b), _p(np.ascontiguousarray(K, np.float64)), _p(R), _p(t), _p(nv))
+        return ok, R, t, nv
+
+    def sampson_count_plain(self, E, pts1, pts2, K, threshold_px):
+        """Sampson inlier count of one E in ordinary (unfused) arithmetic: the independent check of the fused chains."""
+        a = np.ascontiguousarray(pts1, np.float32)
+        b = np.ascontiguousarray(pts2, np.float32)
+        self.lib.oracle_sampson_count_plain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double]
+        return self.lib.oracle_sampson_count_plain(_p(np.ascontiguousarray(E, np.float64)), _p(a), _p(b), a.shape[0],
+                                                   _p(np.ascontiguousarray(K, np.float64)), float(threshold_px))
+
     def count_inliers(self, p3d, p2d, K, R, t, thr):
         a = np.ascontiguousarray(p3d, np.float64)
         b = np.ascontiguousarray(p2d, np.float64)

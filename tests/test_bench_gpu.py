@@ -65,3 +65,34 @@ def test_pose_stage_inside_the_timed_step():
         assert 0 < r["frac"] <= 1.0
     for r in d["kernel_rooflines"].values():
         assert 0 < r["frac"] <= 1.0
+
+
+def test_c3_pose_leg_runs_on_a_scene_with_depth():
+    """the pose stage of `--workload c3 --with-pose` (the driver line's other_workloads.c3_pose) is timed
+    on keypoint / match arrays of a scene WITH DEPTH at c3's size (10,000 keypoints per frame, a fifth of the matches
+    wrong) -- not on the c3 frames' own match lists, where E is degenerate and every PnP hypothesis fails: every pair has
+    a pose, the essential step finds the correct matches, the (calibrated) PnP step more than half of its correspondences,
+    the recovered motion is the generating one; and the reference-form PnP hypotheses, measured beside it, score nothing
+    (the reference's behaviour on real geometry).  The same arrays are compared with the oracle pair by pair in
+    tests/test_pose_batch_gpu.py::test_bench_pose_leg_against_the_oracle."""
+    rc, lines, err = _bench(["--workload", "c3", "--batch", "16", "--steps", "2", "--warmup", "1", "--no-extras",
+                             "--no-cpu-baseline", "--no-pcie", "--with-pose"])
+    assert rc == 0, err[-2000:]
+    d = lines[-1]
+    p = d["pose"]
+    assert "scene with depth" in d["config"]["pose_input"]
+    assert p["pairs_with_a_pose"] == 16 and p["all_pairs_have_a_pose"] and p["pnp_frames_skipped"] == 0
+    assert 8000 < p["matches_per_pair"] < 9000
+    assert 0.80 * p["matches_per_pair"] < p["essential_inliers_per_pair"] < 0.90 * p["matches_per_pair"]
+    assert p["geometry_mode"] == "calibrated"
+    assert p["pnp_inliers_per_frame"] > 0.5 * p["pnp_correspondences_per_frame"] > 2000
+    m = p["recovered_motion"]
+    # (what a 1 px Sampson threshold leaves of 0.02 px keypoints: the handful of wrong matches within the threshold of the
+    # epipolar lines weigh as much in the refit as all correct ones together; and none of the translations is mirrored)
+    assert m["essential"]["pairs"] == 16 and m["essential"]["rotation_error_deg_max"] < 1.0
+    assert m["essential"]["translation_direction_error_deg_median"] < 3.0 and m["essential"]["translation_direction_error_deg_max"] < 45.0
+    assert m["pnp"]["frames"] >= 14 and m["pnp"]["rotation_error_deg_median"] < 0.5 and m["pnp"]["translation_relative_error_median"] < 0.1
+    o = p["other_geometry_mode"]
+    assert o["geometry_mode"] == "reference" and o["pnp_inlier_share_of_correspondences"] < 0.01
+    assert p["stage_ms_per_step"]["pnp_score"] > 0 and p["stage_ms_per_step"]["score"] > 0
+    assert d["roofline_over_1"] == {}

@@ -34,10 +34,21 @@ def _worker(rank, world, port, out_dir):
     summary = [float(sum(int(f.sum()) for f in frames)), float(rank + 1), float(seed)]
     rows = bench.gather_summary(dist, summary, "cpu")
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(rows))
-    # variable-length map-point gather: rank r contributes 3 + 2r points
+    # variable-length map-point gather as ONE collective (count in row 0 of a fixed-capacity payload): rank r
+    # contributes 3 + 2r points; then ragged counts with a rank that has NO points, and a full payload
     pts = np.arange((3 + 2 * rank) * 3, dtype=np.float64).reshape(-1, 3) + 100 * rank
-    parts = bench.gather_map_points(dist, pts, "cpu")
+    parts = bench.gather_map_points(dist, pts, "cpu", 8)
     np.save(os.path.join(out_dir, "points%d.npy" % rank), np.concatenate(parts))
+    empty = np.zeros((0, 3)) if rank == 0 else np.full((4, 3), 7.0)
+    parts = bench.gather_map_points(dist, empty, "cpu", 4)
+    assert [p.shape for p in parts] == [(0, 3), (4, 3)] and (parts[1] == 7.0).all()
+    parts = bench.gather_map_points(dist, np.zeros((0, 3)), "cpu", 0)  # nobody has a point, capacity 0
+    assert [p.shape for p in parts] == [(0, 3), (0, 3)]
+    try:
+        bench.gather_map_points(dist, np.zeros((5, 3)), "cpu", 4)  # more points than the agreed capacity: loud, before
+        raise AssertionError("an over-full payload must be refused")  # any rank enters the collective
+    except RuntimeError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,7 +99,7 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert [r["seed"] for r in ranks] == [bench.shard_seed(0), bench.shard_seed(1)]
     assert ranks[0]["stream_checksum"] != ranks[1]["stream_checksum"]  # two different streams
     assert [r["map_points"] for r in ranks] == [5, 8]
-    assert d["map_points_gathered"] == 13  # counts all_gather + padded payload all_gather over both ranks
+    assert d["map_points_gathered"] == 13  # one all_gather of the count-prefixed payloads of both ranks
 
 
 def test_bench_under_a_launcher_keeps_its_world_size():

@@ -23,15 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-K = np.array([[984.2439, 0.0, 690.0], [0.0, 980.8141, 233.1966], [0.0, 0.0, 1.0]])  # test/data/camera.yml K0
-
-
-def rot(rx, ry, rz):
-    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
-    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
-    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-    return Rz @ Ry @ Rx
+from pose_scene import K_KITTI as K, rot, sequence, loop_sequence, relative_pose, rotation_angle_deg, direction_angle_deg  # noqa: E402,F401
 
 
 def fix_sign(E):
@@ -41,35 +33,6 @@ def fix_sign(E):
 
 def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
-
-
-def sequence(slamx, rng, n_frames, n_points, outliers=0.2, noise=0.15, keep=0.85):
-    """Keypoints and match lists of a camera moving through a point cloud.  -> per frame (kps, matches)."""
-    X = rng.uniform(-4, 4, (n_points, 3)) + np.array([0, 0, 11.0])
-    frames = []
-    prev_slot = None
-    for k in range(n_frames):
-        R = rot(*(0.02 * k * rng.uniform(0.5, 1.5, 3)))
-        t = np.array([0.25 * k, 0.03 * k, 0.05 * k]) + rng.uniform(-0.02, 0.02, 3)
-        x = (K @ (R @ X.T + t[:, None])).T
-        uv = x[:, :2] / x[:, 2:] + rng.normal(0, noise, (n_points, 2))
-        order = rng.permutation(n_points)          # keypoint slot i of this frame shows world point order[i]
-        slot = np.empty(n_points, np.int64)
-        slot[order] = np.arange(n_points)
-        kps = np.zeros(n_points, slamx.KEYPOINT_DTYPE)
-        kps["x"], kps["y"] = uv[order, 0].astype(np.float32), uv[order, 1].astype(np.float32)
-        kps["size"] = 6.0
-        matches = np.zeros(0, slamx.MATCH_DTYPE)
-        if prev_slot is not None:
-            q = np.sort(rng.choice(n_points, int(keep * n_points), replace=False))  # query keypoints that found a match
-            tr = prev_slot[order[q]]                                              # the same world point in the train frame
-            bad = rng.random(len(q)) < outliers
-            tr[bad] = rng.integers(0, n_points, int(bad.sum()))
-            matches = np.zeros(len(q), slamx.MATCH_DTYPE)
-            matches["queryIdx"], matches["trainIdx"], matches["distance"] = q, tr, 3.0
-        frames.append((kps, matches))
-        prev_slot = slot
-    return frames
 
 
 def host_samples(seed, stream, slot, hyp, n, k):
@@ -94,7 +57,9 @@ def host_samples(seed, stream, slot, hyp, n, k):
     return out
 
 
-def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_oracle=True):
+def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_oracle=True, K=K, geometry_mode=None, closed=False):
+    """Frame k of `frames` against frame k - 1; closed: the sequence's frame 0 was matched against its last frame
+    (pose.run(F, F - 1)), so every frame has a train pair with map points."""
     kq, m = frames[k]
     kt = frames[k - 1][0]
     p1 = np.stack([kt["x"][m["trainIdx"]], kt["y"][m["trainIdx"]]], 1).astype(np.float32)
@@ -112,7 +77,9 @@ def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     n1 = np.stack([(p1[:, 0].astype(np.float64) - cx) / fx, (p1[:, 1].astype(np.float64) - cy) / fy], 1).astype(np.float32)
     n2 = np.stack([(p2[:, 0].astype(np.float64) - cx) / fx, (p2[:, 1].astype(np.float64) - cy) / fy], 1).astype(np.float32)
-    Rs, ts, fs = ctx.recover_pose(r["E"], n1, n2, K)
+    # the vote of simpleRecoverPose: with K as the reference passes it, or -- SLAMX_GEOMETRY_CALIBRATED -- with the identity
+    Kv = np.eye(3) if geometry_mode == slamx.GEOMETRY_CALIBRATED else K
+    Rs, ts, fs = ctx.recover_pose(r["E"], n1, n2, Kv)
     assert np.array_equal(fs, r["front"]) and np.array_equal(Rs, r["R"]) and np.array_equal(ts, r["t"])
     assert np.abs(r["R"].T @ r["R"] - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(r["R"]) - 1) < 1e-9
     assert abs(np.linalg.norm(r["t"]) - 1) < 1e-9
@@ -135,7 +102,13 @@ def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_
         assert abs(co - r["n_inliers"]) <= 2 and (mo != mask).sum() <= 2
         assert np.abs(fix_sign(Eo) - fix_sign(r["E"])).max() < 1e-6
         assert best == r["best_hypothesis"] or counts[best] == counts[r["best_hypothesis"]]
-        Ro, to, fo = oracle.recover_pose(r["E"], n1, n2, K)
+        # ... and the Sampson counts in ORDINARY arithmetic (the oracle above shares the kernel's fused evaluation order;
+        # this one does not: ADVICE r4), equal up to correspondences within rounding of the threshold
+        E_all, c_all = pose.hypotheses(k)
+        for h in sorted({0, 1, len(c_all) // 2, int(r["best_hypothesis"])}):
+            assert abs(int(c_all[h]) - oracle.sampson_count_plain(E_all[h], p1, p2, K, thr_px)) <= 2, h
+        assert abs(int(r["n_inliers"]) - oracle.sampson_count_plain(r["E"], p1, p2, K, thr_px)) <= 2
+        Ro, to, fo = oracle.recover_pose(r["E"], n1, n2, Kv)
         assert sorted(fo.tolist()) == sorted(r["front"].tolist())
         if sorted(fo.tolist())[-1] != sorted(fo.tolist())[-2]:
             assert rel(r["R"], Ro) < 1e-7 and rel(r["t"], to) < 1e-7
@@ -146,8 +119,8 @@ def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_
     # --- the PnP step: correspondences of loop_closure.cpp:166-171, restated
     if pose.cfg.pnp_iterations > 0:
         c3, c2 = pose.correspondences(k)
-        if k >= 2 and len(frames[k - 1][1]) >= 8:
-            prev_pts, _ = pose.points(k - 1)
+        if (k >= 2 or closed) and len(frames[k - 1][1]) >= 8:
+            prev_pts, _ = pose.points((k - 1) % len(frames))
             pm = frames[k - 1][1]
             where = {int(q): i for i, q in enumerate(pm["queryIdx"])}  # map point of the train frame's keypoint
             rows = [(where[int(t)], int(q)) for q, t in zip(m["queryIdx"], m["trainIdx"]) if int(t) in where]
@@ -159,7 +132,7 @@ def check_pair(slamx, ctx, oracle, pose, res, frames, k, thr_px, pnp_thr, check_
         assert r["pnp_correspondences"] == len(c3)
         if len(c3) >= max(6, pose.cfg.pnp_min_correspondences):
             assert r["status"] & slamx.POSE_PNP_SKIPPED == 0
-            Rp, tp, bp = ctx.pnp_from_samples(c3, c2, K, ptable, pnp_thr)
+            Rp, tp, bp = ctx.pnp_from_samples(c3, c2, K, ptable, pnp_thr, geometry_mode)
             assert bp == r["pnp_inliers"] and np.array_equal(Rp, r["pnp_R"]) and np.array_equal(tp, r["pnp_t"])
             fin = np.isfinite(c3).all(1)
             if bp > 0:  # (with no hypothesis scoring, R, t stay the initial identity / zero, whose own count is not what bp reports)
@@ -378,3 +351,113 @@ def test_essential_one_pair_call_allocates_nothing_in_steady_state(slamx, gpu_ct
     free1 = ctypes.c_size_t()
     hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total))
     assert free1.value == free0.value
+
+
+def test_calibrated_pnp_hypotheses_against_the_oracle(slamx, gpu_ctx, oracle):
+    """SLAMX_GEOMETRY_CALIBRATED (build-defined, include/slamx.h): every hypothesis of the batched stage against the oracle's
+    restatement of the same steps -- from the device's own null vector (R, t to 1e-7), from the 6-point sample through the
+    oracle's Jacobi SVD where the null vector is defined, per-hypothesis inlier counts against oracle_count_inliers -- and
+    against the one-pair call in that mode, bit for bit.  On a scene with depth the form finds the correct correspondences;
+    the reference form on the same arrays finds none (and the oracle agrees on those counts too)."""
+    rng = np.random.default_rng(31)
+    F = 4
+    Kc = np.array([[1728.0, 0, 960.0], [0, 1728.0, 540.0], [0, 0, 1.0]])
+    frames, Rw, tw = loop_sequence(slamx, rng, F, 1500, Kc, outliers=0.15, noise=0.01)
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 12, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, 2048)
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    kw = dict(iterations=128, threshold_px=1.0, seed=8, pnp_iterations=120, pnp_threshold=2.0)
+    pose = slamx.PoseStage(batch, Kc, geometry_mode=slamx.GEOMETRY_CALIBRATED, **kw)
+    pose.run(F, F - 1)
+    res = pose.download(F)
+    ref = slamx.PoseStage(batch, Kc, geometry_mode=slamx.GEOMETRY_REFERENCE, **kw)
+    ref.run(F, F - 1)
+    res_ref = ref.download(F)
+    for k in range(F):
+        c3, c2 = pose.correspondences(k)
+        fin = np.isfinite(c3).all(1)
+        assert len(c3) > 800 and res[k]["pnp_correspondences"] == len(c3)
+        _, ptable = pose.samples(k)
+        R, t, nv, counts = pose.pnp_hypotheses(k)
+        Rs, ts, best, Ra, ta, ca = gpu_ctx.pnp_from_samples(c3, c2, Kc, ptable, 2.0, slamx.GEOMETRY_CALIBRATED, all_hypotheses=True)
+        assert np.array_equal(Ra, R) and np.array_equal(ta, t) and np.array_equal(ca, counts)
+        assert best == res[k]["pnp_inliers"] == counts.max() and np.array_equal(Rs, res[k]["pnp_R"]) and np.array_equal(ts, res[k]["pnp_t"])
+        checked = 0
+        for h in range(len(ptable)):
+            Ro, to = oracle.pnp_calibrated_from_null_vector(nv[h])
+            assert rel(R[h], Ro) < 1e-7 and rel(t[h], to) < 1e-7 * max(1.0, np.abs(to).max() / max(np.abs(t[h]).max(), 1e-300)), h
+            assert counts[h] == oracle.count_inliers(c3[fin], c2[fin], Kc, R[h], t[h], 2.0), h
+            p3, p2 = c3[ptable[h]], c2[ptable[h]]
+            if not (np.isfinite(p3).all() and np.abs(p3).max() < 1e3):
+                continue
+            ok, Rf, tf, nvo = oracle.solve_pnp_calibrated(p3, p2, Kc)
+            A = np.zeros((12, 12))
+            for i in range(6):
+                X, Y, Z = p3[i]
+                v = (p2[i, 1] - Kc[1, 2]) / Kc[1, 1]
+                u = (p2[i, 0] - Kc[0, 2] - Kc[0, 1] * v) / Kc[0, 0]
+                A[2 * i] = [X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u]
+                A[2 * i + 1] = [0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v]
+            sv = np.linalg.svd(A, compute_uv=False)
+            if sv[-1] > 0.05 * sv[-2]:
+                continue  # (the null direction is barely separated: two iterations may disagree in the sixth digit)
+            assert ok and rel(R[h], Rf) < 1e-5 and np.abs(t[h] - tf).max() < 1e-5 * max(1.0, np.abs(tf).max()), (k, h)
+            checked += 1
+        assert checked > 25
+        # the form works where the reference's does not
+        assert res[k]["pnp_inliers"] > 0.6 * len(c3), (k, res[k]["pnp_inliers"], len(c3))
+        R2, t2 = relative_pose(Rw, tw, (k - 2) % F, k)
+        base = np.linalg.norm(relative_pose(Rw, tw, (k - 2) % F, (k - 1) % F)[1])
+        assert rotation_angle_deg(res[k]["pnp_R"], R2) < 0.1
+        assert np.linalg.norm(res[k]["pnp_t"] - t2 / base) < 0.02 * np.linalg.norm(t2 / base)
+        Rr, tr, nvr, cr = ref.pnp_hypotheses(k)
+        c3r, c2r = ref.correspondences(k)  # (its own map points: the reference form's vote may have turned t around)
+        finr = np.isfinite(c3r).all(1)
+        assert len(c3r) == len(c3) and res_ref[k]["pnp_inliers"] == cr.max() < 0.01 * len(c3)
+        for h in (0, 1, 2, 50, 119):
+            assert cr[h] == oracle.count_inliers(c3r[finr], c2r[finr], Kc, Rr[h], tr[h], 2.0)
+        # the calibrated vote finds the generating translation, not its mirror image
+        Rq, tq = relative_pose(Rw, tw, (k - 1) % F, k)
+        assert rotation_angle_deg(res[k]["R"], Rq) < 0.1 and direction_angle_deg(res[k]["t"], tq) < 2.0
+        assert res[k]["front"].max() > 0.8 * res[k]["n_matches"]
+    with pytest.raises(ValueError):
+        slamx.PoseStage(batch, np.array([[1000.0, 0, 500], [0.1, 1000.0, 300], [0, 0, 1.0]]), pnp_iterations=10, geometry_mode=slamx.GEOMETRY_CALIBRATED)
+    with pytest.raises(ValueError):
+        slamx.PoseStage(batch, Kc, pnp_iterations=10, geometry_mode=7)
+
+
+def test_bench_pose_leg_against_the_oracle(slamx, gpu_ctx, oracle):
+    """The exact arrays `bench.py --workload c3 --with-pose` times its pose stage on (bench.POSE_SCENE, 10,000 keypoints per
+    frame, the bench's camera, seed and stage parameters, frame 0 matched against the batch's last frame), eight frames of
+    them: every pair against the one-pair calls (bit for bit) and the oracle -- E to 1e-6, R, t of simpleRecoverPose to
+    1e-7, map points to 1e-5 relative (north_star's tolerance), PnP counts against oracle_count_inliers -- and against
+    the generating motion."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    F = 8
+    Kc = np.array([[0.9 * 1920, 0, 960.0], [0, 0.9 * 1920, 540.0], [0, 0, 1.0]])
+    sc = bench.POSE_SCENE
+    frames, Rw, tw = loop_sequence(slamx, np.random.default_rng(bench.shard_seed(0)), F, 10000, Kc, outliers=sc["outliers"],
+                                   noise=sc["noise_px"], keep=sc["keep"])
+    det = slamx.FeatureDetector(slamx.DetectorConfig(20, 12, 1, 8, 31, 256), gpu_ctx)
+    batch = slamx.Batch(det, 64, 64, F, 1024, 16384)
+    for k, (kps, m) in enumerate(frames):
+        batch.upload_results(k, kps, m)
+    pose = slamx.PoseStage(batch, Kc, iterations=256, threshold_px=1.0, seed=bench.SEED & 0xFFFFFFFF, pnp_iterations=100,
+                           pnp_threshold=2.0, pnp_min_correspondences=20, geometry_mode=slamx.GEOMETRY_CALIBRATED)
+    pose.run(F, F - 1)
+    res = pose.download(F)
+    for k in range(F):
+        check_pair(slamx, gpu_ctx, oracle, pose, res, frames, k, 1.0, 2.0, K=Kc, geometry_mode=slamx.GEOMETRY_CALIBRATED, closed=True)
+        Rr, tr = relative_pose(Rw, tw, (k - 1) % F, k)
+        assert rotation_angle_deg(res[k]["R"], Rr) < 1.0 and direction_angle_deg(res[k]["t"], tr) < 45.0  # (not mirrored)
+        assert 0.80 * res[k]["n_matches"] < res[k]["n_inliers"] < 0.90 * res[k]["n_matches"]
+        assert res[k]["pnp_correspondences"] > 2000
+    assert res["pnp_inliers"].sum() > 0.5 * res["pnp_correspondences"].sum()
+    assert np.median([direction_angle_deg(res[k]["t"], relative_pose(Rw, tw, (k - 1) % F, k)[1]) for k in range(F)]) < 3.0
