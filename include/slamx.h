@@ -195,6 +195,13 @@ int slamx_host_alloc(size_t bytes, void** out);
 void slamx_host_free(void* p);
 int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
                              ptrdiff_t frame_stride);
+/* The same with flags.  SLAMX_UPLOAD_SLOTS_IDLE: the caller guarantees that no work queued earlier on the batch's context
+ * reads or writes the slots [first, first + n) -- the copy is then NOT ordered behind that work and runs beside it on the
+ * context's copy queue (a caller that fills a batch chunk by chunk while earlier chunks are being processed:
+ * slam::FrameBatch::processSequence).  Work queued AFTER the call still waits for the copy. */
+#define SLAMX_UPLOAD_SLOTS_IDLE 1
+int slamx_batch_upload_async_flags(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                                   ptrdiff_t frame_stride, int flags);
 /* detectAndCompute on frames 0..nframes-1 (async on the context stream). */
 int slamx_batch_detect_and_compute(slamx_batch* b, int nframes);
 /* match(desc[k], desc[k-1], kps[k], kps[k-1]) for k = 1..nframes-1; frame 0 is matched against
@@ -204,6 +211,13 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes);
  * filterAndSortMatches (async). */
 int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints,
                                   int first_train_frame);
+/* The two calls above for the slots [first, first + count) only (frames handed over chunk by chunk): detect + describe
+ * of those frames; then each of them matched against its predecessor -- frame `first` against frame first - 1, which an
+ * earlier call described, or, when first == 0, against first_train_frame as above.  Results are exactly those of the
+ * whole-batch calls (a frame's results do not depend on its neighbours in the launch). */
+int slamx_batch_detect_and_compute_range(slamx_batch* b, int first, int count);
+int slamx_batch_match_consecutive_range(slamx_batch* b, slamx_matcher* m, int first, int count, int use_keypoints,
+                                        int first_train_frame);
 /* Synchronize and copy out.  A frame whose candidate/keypoint count exceeded the shape's
  * capacity makes these return SLAMX_ERR_CAPACITY. */
 int slamx_batch_counts(slamx_batch* b, int nframes, int32_t* n_candidates, int32_t* n_keypoints, int32_t* n_matches);
@@ -214,6 +228,10 @@ int slamx_batch_download(slamx_batch* b, int frame, slamx_keypoint* kps, uint8_t
 int slamx_batch_download_image(slamx_batch* b, int frame, int blurred, uint8_t* out, ptrdiff_t stride);
 int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, int apply_filter, slamx_match* out,
                                  int cap, int* n);
+/* The matcher's filterAndSortMatches step (feature_matcher.cpp:191-204: partial_sort + truncate to GoodMatchesCount, or
+ * sort, when FilterMatches is set; nothing otherwise) on a raw match list the caller already holds on the host (a frame's
+ * range of the packed download): in place, *n_out = the number of matches left.  Host only: no device work. */
+int slamx_matcher_filter_matches(const slamx_matcher* m, slamx_match* matches, int n, int* n_out);
 /* The streaming form of the downloads: queues the copy of the results of frames [0, nframes) into
  * PAGE-LOCKED host memory (slamx_host_alloc) on the context stream and returns; any pointer may be
  * NULL.  Layout = the device's capacity-padded arrays: kps [nframes][max_keypoints],

@@ -110,9 +110,10 @@ EXPORTS = [
     "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
-    "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async",
+    "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async", "slamx_batch_upload_async_flags",
+    "slamx_batch_detect_and_compute_range", "slamx_batch_match_consecutive_range",
     "slamx_batch_detect_and_compute", "slamx_batch_match_consecutive", "slamx_batch_counts", "slamx_batch_download",
-    "slamx_batch_download_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_packed_bound", "slamx_batch_download_packed_async",
+    "slamx_batch_download_matches", "slamx_matcher_filter_matches", "slamx_batch_download_image", "slamx_batch_download_results_async", "slamx_batch_packed_bound", "slamx_batch_download_packed_async",
     "slamx_batch_download_packed_tail", "slamx_batch_set_profiling", "slamx_batch_set_profiling_every", "slamx_batch_stage_ms", "slamx_synth_frame", "slamx_pnp_dlt_batch",
     "slamx_count_inliers_batch", "slamx_pnp_ransac", "slamx_essential_ransac", "slamx_recover_pose", "slamx_triangulate", "slamx_camera_load",
     "slamx_essential_from_samples", "slamx_pnp_from_samples", "slamx_pnp_from_samples_mode", "slamx_pose_create", "slamx_pose_destroy", "slamx_batch_pose",
@@ -179,11 +180,14 @@ def load_library():
     lib.slamx_batch_frames.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.slamx_batch_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
     lib.slamx_batch_upload_async.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
+    lib.slamx_batch_upload_async_flags.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t, C.c_int]
     lib.slamx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     lib.slamx_host_free.argtypes = [vp]
     lib.slamx_host_free.restype = None
     lib.slamx_batch_detect_and_compute.argtypes = [vp, C.c_int]
     lib.slamx_batch_match_consecutive.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.slamx_batch_detect_and_compute_range.argtypes = [vp, C.c_int, C.c_int]
+    lib.slamx_batch_match_consecutive_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.slamx_batch_counts.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.slamx_batch_download.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_batch_download_image.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
@@ -712,20 +716,24 @@ class Batch(_Owner):
             f = f[None]
         _check(self.lib.slamx_batch_upload(self.h, first, f.shape[0], _ptr(f), f.strides[1], f.strides[0]))
 
-    def upload_async(self, frames, first=0):
+    def upload_async(self, frames, first=0, slots_idle=False):
         """Queue the copy and return; `frames` must be (a view of) a pinned_array() and stay untouched
-        until the context has been synchronised."""
+        until the context has been synchronised.  slots_idle: SLAMX_UPLOAD_SLOTS_IDLE (nothing queued earlier touches
+        the target slots: the copy runs beside that work instead of behind it)."""
         f = frames if frames.ndim == 3 else frames[None]
         if f.dtype != np.uint8 or f.strides[2] != 1:
             raise ValueError("upload_async: uint8 frames with unit pixel stride")
-        _check(self.lib.slamx_batch_upload_async(self.h, first, f.shape[0], f.ctypes.data, f.strides[1], f.strides[0]))
+        _check(self.lib.slamx_batch_upload_async_flags(self.h, first, f.shape[0], f.ctypes.data, f.strides[1], f.strides[0],
+                                                       1 if slots_idle else 0))
 
-    def detect_and_compute(self, nframes):
-        _check(self.lib.slamx_batch_detect_and_compute(self.h, nframes))
+    def detect_and_compute(self, nframes, first=0):
+        """Frames [first, first + nframes)."""
+        _check(self.lib.slamx_batch_detect_and_compute_range(self.h, first, nframes))
 
-    def match_consecutive(self, matcher, nframes, use_keypoints=True, first_train_frame=-1):
-        _check(self.lib.slamx_batch_match_consecutive(self.h, matcher.h, nframes, 1 if use_keypoints else 0,
-                                                      first_train_frame))
+    def match_consecutive(self, matcher, nframes, use_keypoints=True, first_train_frame=-1, first=0):
+        """Frames [first, first + nframes), each against its predecessor (frame 0 against first_train_frame, or not at all)."""
+        _check(self.lib.slamx_batch_match_consecutive_range(self.h, matcher.h, first, nframes, 1 if use_keypoints else 0,
+                                                            first_train_frame))
 
     def counts(self, nframes):
         a, b, c = (np.zeros(nframes, np.int32) for _ in range(3))

@@ -895,7 +895,12 @@ void slamx_host_free(void* p) {
 }
 
 int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
-                             ptrdiff_t frame_stride) try {
+                             ptrdiff_t frame_stride) {
+    return slamx_batch_upload_async_flags(b, first, n, host, stride, frame_stride, 0);
+}
+
+int slamx_batch_upload_async_flags(slamx_batch* b, int first, int n, const uint8_t* host, ptrdiff_t stride,
+                                   ptrdiff_t frame_stride, int flags) try {
     if (first < 0 || n < 0 || first + n > b->shape.max_frames || host == nullptr || stride < b->v.cols) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "upload range/stride invalid");
     }
@@ -922,8 +927,10 @@ int slamx_batch_upload_async(slamx_batch* b, int first, int n, const uint8_t* ho
             HIP_TRY(hipEventCreateWithFlags(&c->e_copy_before, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c->e_copy_after, hipEventDisableTiming));
         }
-        HIP_TRY(hipEventRecord(c->e_copy_before, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->copy, c->e_copy_before, 0));
+        if ((flags & SLAMX_UPLOAD_SLOTS_IDLE) == 0) {
+            HIP_TRY(hipEventRecord(c->e_copy_before, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->copy, c->e_copy_before, 0));
+        }  // (else: nothing queued earlier touches these slots, the caller says: the copy may run beside that work)
         s = c->copy;
     }
     uint8_t* dst = b->frames + static_cast<size_t>(first) * b->v.frame_stride;
@@ -979,9 +986,77 @@ int slamx_batch_detect_and_compute(slamx_batch* b, int nframes) try {
     return SLAMX_OK;
 } SLAMX_CATCH
 
+namespace {
+// The view of frames [first, ...) of a batch: every per-frame array moved on by `first` frames (strides as
+// slamx_batch_create lays them out), so that a kernel launched for `count` frames works on slots first .. first + count - 1.
+BatchView shifted_view(const BatchView& v, int first) {
+    BatchView s = v;
+    const size_t f = static_cast<size_t>(first);
+    const size_t nwords = static_cast<size_t>(v.rows) * v.nw;
+    auto move = [&](auto*& p, size_t per_frame) {
+        if (p != nullptr) {
+            p += f * per_frame;
+        }
+    };
+    move(s.frames, v.frame_stride);
+    move(s.blurred, v.frame_stride);
+    move(s.masks, nwords);
+    move(s.wordoff, nwords);
+    move(s.wordcnt, nwords);
+    move(s.tile_count, static_cast<size_t>(v.fast_tiles));
+    move(s.tile_list, static_cast<size_t>(v.fast_tiles) * CORNER_LIST_CAP);
+    move(s.n_cand, 1);
+    move(s.cand_xy, static_cast<size_t>(v.maxM));
+    move(s.keys, static_cast<size_t>(v.maxM));
+    move(s.sorted, static_cast<size_t>(v.maxM));
+    move(s.rank_of, static_cast<size_t>(v.maxM));
+    move(s.state, static_cast<size_t>(v.maxM));
+    move(s.nbr_cnt, static_cast<size_t>(v.maxM));
+    move(s.nbr, static_cast<size_t>(v.maxM) * NBR_CAP);
+    move(s.segstart, v.segstart_stride);
+    move(s.seglist, static_cast<size_t>(3) * v.maxSeg);
+    move(s.kps, static_cast<size_t>(v.maxK));
+    move(s.n_kp, 1);
+    move(s.desc, static_cast<size_t>(v.maxK) * v.width);
+    move(s.visit, static_cast<size_t>(v.maxK));
+    move(s.region_first, static_cast<size_t>((v.cols + 239) / 240) * v.nbands + 1);
+    move(s.region_list, static_cast<size_t>(v.maxK));
+    move(s.moments, static_cast<size_t>(v.maxK));
+    move(s.cos_sin, static_cast<size_t>(v.maxK));
+    move(s.status, 1);
+    return s;
+}
+}  // namespace
+
+int slamx_batch_detect_and_compute_range(slamx_batch* b, int first, int count) try {
+    if (b == nullptr || first < 0 || count < 0 || first + count > b->shape.max_frames) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "detect_and_compute_range: first / count out of range");
+    }
+    if (count == 0) {
+        return SLAMX_OK;
+    }
+    if (first == 0) {
+        return slamx_batch_detect_and_compute(b, count);
+    }
+    // the same launches on the view of the slots from `first` on (kernel arguments are taken at launch)
+    const BatchView whole = b->v;
+    const int frames_before = b->last_frames;
+    b->v = shifted_view(whole, first);
+    const int rc = slamx_batch_detect_and_compute(b, count);
+    b->v = whole;
+    b->last_frames = std::max(frames_before, first + count);
+    return rc;
+} SLAMX_CATCH
+
 int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes, int use_keypoints,
-                                  int first_train_frame) try {
-    if (nframes < 0 || nframes > b->shape.max_frames || first_train_frame >= b->shape.max_frames) {
+                                  int first_train_frame) {
+    return slamx_batch_match_consecutive_range(b, m, 0, nframes, use_keypoints, first_train_frame);
+}
+
+int slamx_batch_match_consecutive_range(slamx_batch* b, slamx_matcher* m, int first, int nframes, int use_keypoints,
+                                        int first_train_frame) try {
+    if (b == nullptr || m == nullptr || first < 0 || nframes < 0 || first + nframes > b->shape.max_frames ||
+        first_train_frame >= b->shape.max_frames) {
         return fail(SLAMX_ERR_INVALID_ARGUMENT, "nframes / first_train_frame out of range");
     }
     if (m->cfg.distance_type != 0) {
@@ -1023,7 +1098,10 @@ int slamx_batch_match_consecutive(slamx_batch* b, slamx_matcher* m, int nframes,
         record(b, 10);
     }
     hipEvent_t mid = event_slot(b, 11);
-    if (first_train_frame >= 0) {
+    if (first > 0) {
+        // frames first .. first + nframes - 1, each against its predecessor (frame first - 1 was described by an earlier call)
+        launch_match_consecutive(mv, first, nframes, -1, b->det->ctx->stream, mid);
+    } else if (first_train_frame >= 0) {
         launch_match_consecutive(mv, 0, nframes, first_train_frame, b->det->ctx->stream, mid);
     } else {
         launch_match_consecutive(mv, 1, nframes - 1, -1, b->det->ctx->stream, mid);
@@ -1244,6 +1322,22 @@ int slamx_batch_download_matches(slamx_batch* b, slamx_matcher* m, int frame, in
     }
     if (out != nullptr && !v.empty()) {
         std::memcpy(out, v.data(), sizeof(slamx_match) * v.size());
+    }
+    return SLAMX_OK;
+} SLAMX_CATCH
+
+// filterAndSortMatches (feature_matcher.cpp:191-204) on a caller's raw match list, in place, on the host: the step
+// slamx_batch_download_matches applies after its copy, for callers that already hold the raw lists (the packed download)
+int slamx_matcher_filter_matches(const slamx_matcher* m, slamx_match* matches, int n, int* n_out) try {
+    if (m == nullptr || n < 0 || (n > 0 && matches == nullptr) || n_out == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "filter_matches: arguments invalid");
+    }
+    *n_out = n;
+    if (m->cfg.filter_matches != 0 && n > 0) {
+        std::vector<slamx_match> v(matches, matches + n);
+        filter_and_sort(v, m->cfg.good_matches_count);
+        std::memcpy(matches, v.data(), sizeof(slamx_match) * v.size());
+        *n_out = static_cast<int>(v.size());
     }
     return SLAMX_OK;
 } SLAMX_CATCH

@@ -52,9 +52,12 @@ def keypoints(rng, slamx, n, kind):
     return k
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def main(cases=None, seed=None):
+    """cases / seed: from the command line when None (tests/test_fuzz_smoke_gpu.py passes fixed ones)."""
+    if cases is None:
+        cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    if seed is None:
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     slamx = importlib.import_module("slam-cin0051_amd")
     oracle = oracle_binding.load()
     rng = np.random.default_rng(seed)

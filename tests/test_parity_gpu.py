@@ -1226,3 +1226,39 @@ def test_matcher_against_committed_golden_vectors(slamx, det, ref_data):
             assert m_ship.match(d1, d2, k1, k2).tobytes() == g[tag + "_match_kp"].tobytes(), tag + " with keypoints"
             assert m_ship.match(d1, d2).tobytes() == g[tag + "_match_nokp"].tobytes(), tag + " without keypoints"
             assert m_all.match(d1, d2, k1, k2).tobytes() == g[tag + "_best_kp"].tobytes(), tag + " unfiltered"
+
+
+@pytest.mark.parametrize("shape,dense", [((200, 300), False), ((480, 640), True)])
+def test_batch_in_chunks_equals_whole_batch(slamx, shape, dense):
+    """slamx_batch_detect_and_compute_range / _match_consecutive_range / _upload_async_flags(SLOTS_IDLE) (round 5: what
+    slam::FrameBatch::processSequence pipelines a sequence with): a batch filled and processed chunk by chunk -- uneven
+    chunks, a one-frame chunk, an empty frame at a chunk's start -- must leave exactly the bytes the whole-batch calls
+    leave: every count, keypoint, descriptor and match, through the packed download.  Sparse frames (popcount matcher,
+    per-keypoint describe tiles) and dense ones (matrix-core matcher in spatial order, region tiles)."""
+    rows, cols = shape
+    d = slamx.FeatureDetector(cfg_of(slamx, window=6 if dense else 8))
+    m = slamx.FeatureMatcher(mcfg(slamx, 0, 1, 1, 0.8))
+    counts = (5000, 4000, 0, 4500, 5200, 3000, 4800, 5100, 100, 4900, 5000) if dense else (250, 120, 0, 400, 60, 300, 10, 350, 200, 90, 310)
+    frames = np.stack([synth(slamx, k, rows, cols, n, rmin=3 if dense else 4, rmax=16 if dense else 24) for k, n in enumerate(counts)])
+    frames[2][:] = 77
+    F = len(frames)
+    pin = slamx.pinned_array(frames.shape)
+    pin[...] = frames
+
+    def run(chunks):
+        b = slamx.Batch(d, rows, cols, F, 32768, 4096)
+        for first, n in chunks:
+            b.upload_async(pin[first:first + n], first, slots_idle=len(chunks) > 1)
+            b.detect_and_compute(n, first)
+            b.match_consecutive(m, n, use_keypoints=True, first_train_frame=-1, first=first)
+        buf = b.packed_buffer(F)
+        b.download_packed_async(F, buf)
+        d.ctx.synchronize()
+        total = int(slamx.packed_header(buf)["total_bytes"])
+        nc, nk, nm = b.counts(F)
+        return bytes(buf[:total]), nc.tolist(), nk.tolist(), nm.tolist()
+
+    whole = run([(0, F)])
+    assert max(whole[2]) > (1024 if dense else 50) and whole[3][0] == 0 and sum(whole[3]) > 0
+    for chunks in ([(0, 3), (3, 1), (4, 5), (9, 2)], [(0, 1), (1, 1), (2, 8), (10, 1)], [(0, 6), (6, 5)]):
+        assert run(chunks) == whole, chunks

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
 
         // ---- the batch
         slam::FrameBatch batch(detector, static_cast<int>(images[0].rows()), static_cast<int>(images[0].cols()), n);
-        double t_batch = 0.0;
+        double t_batch = 0.0, t_pipe = 0.0;
         for (int pass = 0; pass < 2; ++pass) {  // pass 0 warms up (first-use allocations of the batch)
             t0 = std::chrono::steady_clock::now();
             for (int k = 0; k < n; ++k) {
@@ -68,6 +68,35 @@ int main(int argc, char** argv) {
             batch.matchConsecutive(matcher, n);
             batch.fetch(n);
             t_batch = seconds_since(t0);
+        }
+        // what the three calls left, frame by frame, to compare the pipelined run with
+        std::vector<std::vector<slam::Keypoint>> sk(static_cast<size_t>(n));
+        std::vector<slam::DescriptorMatrix> sd(static_cast<size_t>(n));
+        std::vector<std::vector<slam::Match>> sm(static_cast<size_t>(n));
+        for (int k = 0; k < n; ++k) {
+            batch.keypoints(k, sk[static_cast<size_t>(k)]);
+            batch.descriptors(k, sd[static_cast<size_t>(k)]);
+            if (k > 0) {
+                batch.matches(matcher, k, sm[static_cast<size_t>(k)]);
+            }
+        }
+        // ---- the same sequence PIPELINED: host copy | upload | kernels overlap chunk by chunk (FrameBatch::processSequence)
+        std::vector<const slam::EigenGrayMatrix*> seq(static_cast<size_t>(n));
+        for (int k = 0; k < n; ++k) {
+            seq[static_cast<size_t>(k)] = &image_of(k);
+        }
+        for (int pass = 0; pass < 3; ++pass) {
+            t0 = std::chrono::steady_clock::now();
+            batch.processSequence(seq, &matcher);
+            batch.fetch(n);
+            const double t = seconds_since(t0);
+            t_pipe = pass == 0 ? t : std::min(t_pipe, t);
+        }
+        if (n <= 64) {
+            // a short sequence is one chunk by default: once more in chunks of three frames on three copy threads, so that the
+            // comparison below sees a pipeline with chunk borders (frame 3 k matched against a frame of the chunk before)
+            batch.processSequence(seq, &matcher, true, -1, 3, 3);
+            batch.fetch(n);
         }
         size_t total_kps = 0, total_matches = 0;
         int bad = 0;
@@ -86,7 +115,14 @@ int main(int argc, char** argv) {
             const bool same_k = bk.size() == rk.size() && (bk.empty() || std::memcmp(bk.data(), rk.data(), bk.size() * sizeof(slam::Keypoint)) == 0);
             const bool same_d = bd.rows() == rd.rows() && bd.cols() == rd.cols() &&
                                 (bd.size() == 0 || std::memcmp(bd.data(), rd.data(), static_cast<size_t>(bd.size())) == 0);
-            const bool same_m = bm.size() == rm.size() && (bm.empty() || std::memcmp(bm.data(), rm.data(), bm.size() * sizeof(slam::Match)) == 0);
+            bool same_m = bm.size() == rm.size() && (bm.empty() || std::memcmp(bm.data(), rm.data(), bm.size() * sizeof(slam::Match)) == 0);
+            // ... and the unpipelined batch calls left the same
+            const auto& qk = sk[static_cast<size_t>(k)];
+            const auto& qd = sd[static_cast<size_t>(k)];
+            const auto& qm = sm[static_cast<size_t>(k)];
+            same_m = same_m && qk.size() == rk.size() && (qk.empty() || std::memcmp(qk.data(), rk.data(), qk.size() * sizeof(slam::Keypoint)) == 0) &&
+                     qd.rows() == rd.rows() && (qd.size() == 0 || std::memcmp(qd.data(), rd.data(), static_cast<size_t>(qd.size())) == 0) &&
+                     qm.size() == rm.size() && (qm.empty() || std::memcmp(qm.data(), rm.data(), qm.size() * sizeof(slam::Match)) == 0);
             if (!same_k || !same_d || !same_m) {
                 std::fprintf(stderr, "frame %d differs: keypoints %s (%zu / %zu), descriptors %s, matches %s (%zu / %zu)\n", k,
                              same_k ? "equal" : "DIFFER", bk.size(), rk.size(), same_d ? "equal" : "DIFFER", same_m ? "equal" : "DIFFER",
@@ -98,7 +134,10 @@ int main(int argc, char** argv) {
         }
         std::printf("%d frames of %td x %td: %zu keypoints, %zu matches\n", n, images[0].cols(), images[0].rows(), total_kps, total_matches);
         std::printf("frame by frame (detectAndCompute + match): %.3f ms, %.0f frames/s\n", t_single * 1e3, n / t_single);
-        std::printf("one FrameBatch (copy in, detectAndCompute, matchConsecutive, fetch): %.3f ms, %.0f frames/s\n", t_batch * 1e3, n / t_batch);
+        std::printf("one FrameBatch, its calls one after another (setFrame x %d, detectAndCompute, matchConsecutive, fetch): %.3f ms, %.0f frames/s\n",
+                    n, t_batch * 1e3, n / t_batch);
+        std::printf("one FrameBatch, pipelined (processSequence: host copy | upload | kernels chunk by chunk, then fetch): %.3f ms, %.0f frames/s\n",
+                    t_pipe * 1e3, n / t_pipe);
         std::printf("batch == frame by frame: %s\n", bad == 0 ? "yes" : "NO");
         // ---- the pose stage of the same batch, when the configuration directory holds a camera.yml: every frame pair's
         //      essential-matrix RANSAC, cheirality vote, map points and PnP in twelve launches, from the arrays in HBM
