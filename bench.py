@@ -979,6 +979,21 @@ def facade_latency(reps=50):
                                       "note": "host images in, keypoints + descriptors + matches of every frame out, both ways"}
     except Exception as e:
         out["gpu_facade_sequence"] = {"error": repr(e)[:200]}
+    # ... and on frames of the headline workload (1080p, ~2k keypoints), to set beside end_to_end: the C++ facade's sequence
+    # interface against the bench's own rotating lanes over the C ABI
+    try:
+        p = subprocess.run([os.path.join(ROOT, "tools", "bin", "test_frame_batch"), os.path.join(ref, "feature_detector.yml"),
+                            os.path.join(ref, "feature_matcher.yml"), "1", "synth:1080x1920:6800:3:24:512"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+        text = p.stdout.decode()
+        rates = [float(x) for x in re.findall(r"([0-9.]+) frames/s", text)]
+        out["gpu_facade_sequence_1080p"] = {"frames": 512, "frame_by_frame_fps": rates[0], "frame_batch_fps": rates[2],
+                                            "frame_batch_unpipelined_fps": rates[1],
+                                            "results_identical": "batch == frame by frame: yes" in text,
+                                            "note": "512 synthetic 1080p frames of the headline workload through slam::FrameBatch::processSequence + "
+                                                    "fetch; compare with end_to_end.value"}
+    except Exception as e:
+        out["gpu_facade_sequence_1080p"] = {"error": repr(e)[:200]}
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding

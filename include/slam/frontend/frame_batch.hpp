@@ -142,7 +142,7 @@ public:
         const int C = chunkFrames > 0 ? std::min(chunkFrames, n) : std::max(16, std::min(128, (n + 7) / 8));
         const int nchunks = (n + C - 1) / C;
         unsigned hw = std::thread::hardware_concurrency();
-        const int T = std::max(1, std::min(copyThreads > 0 ? copyThreads : 6, static_cast<int>(hw == 0 ? 4 : hw)));
+        const int T = std::max(1, std::min(copyThreads > 0 ? copyThreads : 8, static_cast<int>(hw == 0 ? 4 : hw)));
         const size_t frameBytes = static_cast<size_t>(m_rows) * m_cols;
         std::atomic<int> next{0};
         std::vector<std::atomic<int>> done(static_cast<size_t>(nchunks));

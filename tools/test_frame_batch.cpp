@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <string>
@@ -23,7 +24,7 @@ double seconds_since(const std::chrono::steady_clock::time_point& t0) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 6) {
+    if (argc < 5) {
         std::fprintf(stderr, "usage: %s <feature_detector.yml> <feature_matcher.yml> <repeat> <img0.png> <img1.png> ...\n", argv[0]);
         return -1;
     }
@@ -32,7 +33,19 @@ int main(int argc, char** argv) {
         slam::FeatureMatcher matcher(argv[2]);
         const int repeat = std::max(1, std::atoi(argv[3]));
         std::vector<slam::EigenGrayMatrix> images;
-        for (int i = 4; i < argc; ++i) {
+        // "synth:ROWSxCOLS:NRECT:RMIN:RMAX:COUNT" instead of image files: COUNT frames of bench.py's synthetic sequence
+        // (slamx_synth_frame) -- e.g. synth:1080x1920:6800:3:24:64 = frames of the headline workload
+        int srows = 0, scols = 0, snrect = 0, srmin = 0, srmax = 0, scount = 0;
+        if (argc == 5 && std::sscanf(argv[4], "synth:%dx%d:%d:%d:%d:%d", &srows, &scols, &snrect, &srmin, &srmax, &scount) == 6) {
+            for (int k = 0; k < scount; ++k) {
+                slam::EigenGrayMatrix im(srows, scols);
+                if (slamx_synth_frame(0x5EED0051ull, k, srows, scols, snrect, srmin, srmax, im.data()) != SLAMX_OK) {
+                    throw std::runtime_error("slamx_synth_frame failed");
+                }
+                images.push_back(std::move(im));
+            }
+        }
+        for (int i = 4; i < argc && scount == 0; ++i) {
             images.push_back(slamx_tools::read_png_gray(argv[i]));
             if (images.back().rows() != images[0].rows() || images.back().cols() != images[0].cols()) {
                 throw std::runtime_error(std::string("image of another size: ") + argv[i]);
@@ -57,7 +70,9 @@ int main(int argc, char** argv) {
         const double t_single = seconds_since(t0);
 
         // ---- the batch
-        slam::FrameBatch batch(detector, static_cast<int>(images[0].rows()), static_cast<int>(images[0].cols()), n);
+        // (synthetic frames: bench.py's capacities for them; image files: the facade's defaults)
+        slam::FrameBatch batch(detector, static_cast<int>(images[0].rows()), static_cast<int>(images[0].cols()), n, scount > 0 ? 32768 : 0,
+                               scount > 0 ? 4096 : 0);
         double t_batch = 0.0, t_pipe = 0.0;
         for (int pass = 0; pass < 2; ++pass) {  // pass 0 warms up (first-use allocations of the batch)
             t0 = std::chrono::steady_clock::now();
@@ -85,12 +100,20 @@ int main(int argc, char** argv) {
         for (int k = 0; k < n; ++k) {
             seq[static_cast<size_t>(k)] = &image_of(k);
         }
-        for (int pass = 0; pass < 3; ++pass) {
+        // (experiment switches: FB_CHUNK = frames per chunk, FB_THREADS = copy threads; 0 / unset = the defaults)
+        const int fb_chunk = std::getenv("FB_CHUNK") != nullptr ? std::atoi(std::getenv("FB_CHUNK")) : 0;
+        const int fb_threads = std::getenv("FB_THREADS") != nullptr ? std::atoi(std::getenv("FB_THREADS")) : 0;
+        double t_queued = 0.0;
+        for (int pass = 0; pass < 4; ++pass) {
             t0 = std::chrono::steady_clock::now();
-            batch.processSequence(seq, &matcher);
+            batch.processSequence(seq, &matcher, true, -1, fb_chunk, fb_threads);
+            const double tq = seconds_since(t0);
             batch.fetch(n);
             const double t = seconds_since(t0);
-            t_pipe = pass == 0 ? t : std::min(t_pipe, t);
+            if (pass == 0 || t < t_pipe) {
+                t_pipe = t;
+                t_queued = tq;
+            }
         }
         if (n <= 64) {
             // a short sequence is one chunk by default: once more in chunks of three frames on three copy threads, so that the
@@ -138,6 +161,7 @@ int main(int argc, char** argv) {
                     n, t_batch * 1e3, n / t_batch);
         std::printf("one FrameBatch, pipelined (processSequence: host copy | upload | kernels chunk by chunk, then fetch): %.3f ms, %.0f frames/s\n",
                     t_pipe * 1e3, n / t_pipe);
+        std::printf("   (of that: %.3f ms until the last chunk was queued, %.3f ms waiting in fetch)\n", t_queued * 1e3, (t_pipe - t_queued) * 1e3);
         std::printf("batch == frame by frame: %s\n", bad == 0 ? "yes" : "NO");
         // ---- the pose stage of the same batch, when the configuration directory holds a camera.yml: every frame pair's
         //      essential-matrix RANSAC, cheirality vote, map points and PnP in twelve launches, from the arrays in HBM
