@@ -549,6 +549,18 @@ int slamx_mapgather_create(slamx_ctx* ctx, const uint8_t id[SLAMX_MAPGATHER_ID_B
 void slamx_mapgather_destroy(slamx_mapgather* g);
 int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts /* [world] */,
                               double* out, int cap_points, int* total);
+/* The same exchange as ONE collective, for callers whose ranks agree on a capacity beforehand (a batch's max_keypoints:
+ * a frame pair has at most that many matches, hence map points): every rank sends a block of per_rank_cap + 1 rows of three
+ * doubles whose first row carries {count, status}; one ncclAllGather, one copy of the gathered blocks to the host, one
+ * synchronisation -- no host round trip between collectives (the two-step form above needs the counts on the host before
+ * it can size the payload).  slamx_mapgather_reserve(g, per_rank_cap): local, allocates the blocks, to be called by every
+ * rank with the SAME capacity before the first exchange (a rank that fails here must not enter the exchange alone: treat
+ * it like a failed slamx_mapgather_create).  _allgather_fixed: as slamx_mapgather_allgather; a rank with more points than
+ * the capacity, or any other local problem, still enters the collective (with no points) and every rank returns an error
+ * afterwards. */
+int slamx_mapgather_reserve(slamx_mapgather* g, int per_rank_cap);
+int slamx_mapgather_allgather_fixed(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts /* [world] */,
+                                    double* out, int cap_points, int* total);
 /* The host-side bookkeeping of the exchange on its own (no GPU, no RCCL): the padded per-rank capacity (largest
  * count, at least 1) and the total for a list of counts; and the unpacking of a gathered padded payload
  * [world][padded_cap][3] into `out`.  slamx_mapgather_allgather uses exactly these. */

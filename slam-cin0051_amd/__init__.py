@@ -124,7 +124,7 @@ EXPORTS = [
     "slamx_pyramid_detect_and_compute",
     "slamx_gn_create", "slamx_gn_destroy", "slamx_gn_upload", "slamx_gn_iterate", "slamx_gn_download",
     "slamx_gn_normal_equations", "slamx_gn_set_profiling", "slamx_gn_stage_ms",
-    "slamx_mapgather_unique_id", "slamx_mapgather_create", "slamx_mapgather_destroy", "slamx_mapgather_allgather",
+    "slamx_mapgather_unique_id", "slamx_mapgather_create", "slamx_mapgather_destroy", "slamx_mapgather_allgather", "slamx_mapgather_reserve", "slamx_mapgather_allgather_fixed",
     "slamx_mapgather_plan", "slamx_mapgather_unpack",
 ]
 
@@ -197,6 +197,8 @@ def load_library():
     lib.slamx_mapgather_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.slamx_mapgather_destroy.argtypes = [vp]
     lib.slamx_mapgather_allgather.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    lib.slamx_mapgather_reserve.argtypes = [vp, C.c_int]
+    lib.slamx_mapgather_allgather_fixed.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_mapgather_plan.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.slamx_mapgather_unpack.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
     lib.slamx_batch_packed_bound.argtypes = [vp, C.c_int]
@@ -999,6 +1001,19 @@ class MapGather(_Owner):
         total = C.c_int()
         _check(self.lib.slamx_mapgather_allgather(self.h, _ptr(p), p.shape[0], _ptr(counts), _ptr(out), cap_points,
                                                   C.byref(total)))
+        return counts, out[: total.value].copy()
+
+    def reserve(self, per_rank_cap):
+        _check(self.lib.slamx_mapgather_reserve(self.h, int(per_rank_cap)))
+
+    def allgather_fixed(self, xyz, cap_points=1 << 20):
+        """The exchange as ONE collective (after reserve(per_rank_cap) on every rank): count and status travel in the payload."""
+        p = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        counts = np.zeros(self.world, np.int32)
+        out = np.empty((cap_points, 3))
+        total = C.c_int()
+        _check(self.lib.slamx_mapgather_allgather_fixed(self.h, _ptr(p), p.shape[0], _ptr(counts), _ptr(out), cap_points,
+                                                        C.byref(total)))
         return counts, out[: total.value].copy()
 
 

@@ -2578,6 +2578,11 @@ struct slamx_mapgather {
     int cap = 0;
     std::vector<double> h_recv;
     std::vector<int32_t> h_counts;
+    // the one-collective form (slamx_mapgather_reserve / _allgather_fixed): blocks of fixed_rows x 3 doubles, row 0 = header
+    size_t fixed_rows = 0;
+    double* d_fsend = nullptr;  // [fixed_rows][3]
+    double* d_frecv = nullptr;  // [world][fixed_rows][3]
+    double* h_fsend = nullptr;  // page-locked: this rank's block, then the gathered blocks
 };
 
 extern "C" {
@@ -2640,6 +2645,11 @@ void slamx_mapgather_destroy(slamx_mapgather* g) {
     dev_free(g->d_counts);
     dev_free(g->d_send);
     dev_free(g->d_recv);
+    dev_free(g->d_fsend);
+    dev_free(g->d_frecv);
+    if (g->h_fsend != nullptr) {
+        (void)hipHostFree(g->h_fsend);
+    }
     delete g;
 }
 
@@ -2744,6 +2754,106 @@ int slamx_mapgather_allgather(slamx_mapgather* g, const double* xyz, int n_point
     HIP_TRY(hipStreamSynchronize(s));
     // 4. unpack (reports a too small `out` only now: no rank may leave before the collectives)
     return slamx_mapgather_unpack(g->h_recv.data(), counts, g->world, cap, out, cap_points);
+} SLAMX_CATCH
+
+// ---- the same exchange as ONE collective (round 5): every rank sends a fixed-capacity block whose first
+// row carries {count, status}; nothing is read back between collectives because there is only one.
+int slamx_mapgather_reserve(slamx_mapgather* g, int per_rank_cap) try {
+    if (g == nullptr || per_rank_cap < 0) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_reserve: bad arguments");
+    }
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    const size_t rows = static_cast<size_t>(per_rank_cap) + 1;  // + the header row
+    if (g->fixed_rows >= rows) {
+        return SLAMX_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    dev_free(g->d_fsend);
+    dev_free(g->d_frecv);
+    if (g->h_fsend != nullptr) {
+        (void)hipHostFree(g->h_fsend);
+        g->h_fsend = nullptr;
+    }
+    g->fixed_rows = 0;
+    SLAMX_TRY(dev_alloc(&g->d_fsend, rows * 3));
+    SLAMX_TRY(dev_alloc(&g->d_frecv, static_cast<size_t>(g->world) * rows * 3));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g->h_fsend), (static_cast<size_t>(g->world) + 1) * rows * 3 * sizeof(double), hipHostMallocDefault));
+    g->fixed_rows = rows;
+    return SLAMX_OK;
+} SLAMX_CATCH
+
+int slamx_mapgather_allgather_fixed(slamx_mapgather* g, const double* xyz, int n_points, int32_t* counts, double* out,
+                                    int cap_points, int* total) try {
+    if (g == nullptr || n_points < 0 || (xyz == nullptr && n_points > 0) || counts == nullptr) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_allgather_fixed: bad arguments");
+    }
+    if (g->fixed_rows == 0) {
+        // (the same on every rank of a correct program: nobody enters the collective)
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "mapgather_allgather_fixed: call slamx_mapgather_reserve with the agreed capacity first");
+    }
+    // A local problem travels in the header row; the rank still enters the collective (with no points), and every rank
+    // reports the failure afterwards -- nobody is left waiting.
+    int local_rc = SLAMX_OK;
+    std::string local_msg;
+    const size_t rows = g->fixed_rows, W = static_cast<size_t>(g->world);
+    if (static_cast<size_t>(n_points) + 1 > rows) {
+        local_rc = SLAMX_ERR_CAPACITY;
+        local_msg = "more points (" + std::to_string(n_points) + ") than the reserved capacity per rank (" + std::to_string(rows - 1) + ")";
+        n_points = 0;
+    }
+    if (hipSetDevice(g->ctx->device) != hipSuccess && local_rc == SLAMX_OK) {
+        local_rc = SLAMX_ERR_HIP;
+        local_msg = "hipSetDevice";
+    }
+    hipStream_t s = g->ctx->stream;
+    double* mine = g->h_fsend;  // page-locked: [rows][3], then the gathered [world][rows][3]
+    mine[0] = static_cast<double>(n_points);
+    mine[1] = static_cast<double>(local_rc);
+    mine[2] = 0.0;
+    if (n_points > 0) {
+        std::memcpy(mine + 3, xyz, static_cast<size_t>(n_points) * 3 * sizeof(double));
+    }
+    // only the rows in use cross to the device; the rows behind them keep whatever an earlier call left (never read)
+    const size_t used = (static_cast<size_t>(n_points) + 1) * 3;
+    const bool up_ok = hipMemcpyAsync(g->d_fsend, mine, used * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    constexpr int kFloat64 = 8;  // ncclFloat64
+    RCCL_TRY(rccl().AllGather(g->d_fsend, g->d_frecv, rows * 3, kFloat64, g->comm, s));
+    double* all = g->h_fsend + rows * 3;
+    HIP_TRY(hipMemcpyAsync(all, g->d_frecv, W * rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the one synchronisation of the exchange
+    int tot = 0, first_bad = -1;
+    for (size_t r = 0; r < W; ++r) {
+        const double* blk = all + r * rows * 3;
+        const int c = static_cast<int>(blk[0]);
+        if (blk[1] != 0.0 && first_bad < 0) {
+            first_bad = static_cast<int>(r);
+        }
+        counts[r] = c < 0 || static_cast<size_t>(c) + 1 > rows ? 0 : c;
+        tot += counts[r];
+    }
+    if (total != nullptr) {
+        *total = tot;
+    }
+    if (local_rc != SLAMX_OK) {
+        return fail(local_rc, "mapgather_allgather_fixed: " + local_msg + " (the collective was entered with no points)");
+    }
+    if (!up_ok) {
+        return fail(SLAMX_ERR_HIP, "mapgather_allgather_fixed: the upload of this rank's block failed");
+    }
+    if (first_bad >= 0) {
+        return fail(SLAMX_ERR_RUNTIME, "mapgather_allgather_fixed: rank " + std::to_string(first_bad) + " reported a local failure");
+    }
+    if (tot > cap_points) {
+        return fail(SLAMX_ERR_CAPACITY, "mapgather_allgather_fixed: " + std::to_string(tot) + " points gathered, room for " + std::to_string(cap_points));
+    }
+    if (out != nullptr) {
+        size_t at = 0;
+        for (size_t r = 0; r < W; ++r) {
+            std::memcpy(out + at * 3, all + r * rows * 3 + 3, static_cast<size_t>(counts[r]) * 3 * sizeof(double));
+            at += static_cast<size_t>(counts[r]);
+        }
+    }
+    return SLAMX_OK;
 } SLAMX_CATCH
 
 }  // extern "C"

@@ -269,6 +269,19 @@ def test_mapgather_world_of_one(slamx, gpu_ctx):
     assert counts.tolist() == [0] and out.shape == (0, 3)
     with pytest.raises(slamx.CapacityError):
         g.allgather(big, cap_points=100)
+    # the one-collective form: count and status in the header row of a fixed-capacity block
+    with pytest.raises(ValueError):
+        g.allgather_fixed(pts)  # no capacity agreed yet
+    g.reserve(6000)
+    for p in (pts, big, np.zeros((0, 3)), pts[:1]):
+        counts, out = g.allgather_fixed(p)
+        assert counts.tolist() == [len(p)] and np.array_equal(out, p)
+    with pytest.raises(slamx.CapacityError):
+        g.allgather_fixed(np.zeros((6001, 3)))  # more than the reserved capacity: refused AFTER the collective ran
+    counts, out = g.allgather_fixed(big)  # ... and the communicator is still usable
+    assert counts.tolist() == [5000] and np.array_equal(out, big)
+    with pytest.raises(slamx.CapacityError):
+        g.allgather_fixed(big, cap_points=100)
     g.close()
 
 

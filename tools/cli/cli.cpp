@@ -64,6 +64,9 @@ static void runChunk(int rank, int world, const uint8_t* gatherId, const std::st
         slamx_ctx* ctx = slam::useDevice(rank);  // everything this thread creates below lives on GPU `rank`
         if (world > 1 || gatherId != nullptr) {
             slam::detail::check(slamx_mapgather_create(ctx, gatherId, rank, world, &gather));  // every rank must arrive here
+            // the capacity every rank's block has in the one-collective exchange at the end: an equal share of the 2^22
+            // doubles the gathered points may fill (1.4 M points in all)
+            slam::detail::check(slamx_mapgather_reserve(gather, (1 << 22) / 3 / world));
         }
         slam::FeatureDetector detector(fs::path(configPath) / "feature_detector.yml");
         slam::FeatureMatcher matcher(fs::path(configPath) / "feature_matcher.yml");
@@ -175,8 +178,9 @@ static void runChunk(int rank, int world, const uint8_t* gatherId, const std::st
             out->gatheredCounts.assign(static_cast<size_t>(world), 0);
             std::vector<double> all(static_cast<size_t>(1) << 22);
             int total = 0;
-            slam::detail::check(slamx_mapgather_allgather(gather, out->mapPoints.data(), n, out->gatheredCounts.data(), all.data(),
-                                                          static_cast<int>(all.size() / 3), &total));
+            // ONE collective: the per-rank capacity was agreed (reserved) right after the communicator was made
+            slam::detail::check(slamx_mapgather_allgather_fixed(gather, out->mapPoints.data(), n, out->gatheredCounts.data(), all.data(),
+                                                                static_cast<int>(all.size() / 3), &total));
             out->gatheredTotal = total;
         } catch (...) {
             if (!out->error) {
