@@ -128,6 +128,8 @@ __device__ __forceinline__ int rank_below(unsigned long long m) {  // set bits o
 // pipeline -- the two-ended chunk walk of wave_partition is a chain of dependent LDS round trips.
 // scr: last-first 16-bit entries of LDS private to the segment.
 __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last, int lane) {
+    first = __builtin_amdgcn_readfirstlane(first);  // (wave-uniform by construction; said once so that the loop counters
+    last = __builtin_amdgcn_readfirstlane(last);    //  and the regime tests below stay on the scalar unit)
     const int ia = first + 1;
     const int ib = first + (last - first) / 2;
     const int ic = last - 1;
@@ -162,50 +164,69 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
     const int lo = first + 1;
     const int hi = last;
     const int n = hi - lo;
-    // pass 1: number of right stoppers.  Chunks are read four at a time so that the LDS latency is
-    // paid once per 256 keys.
+    // pass 1: number of right stoppers.  Chunks are read four at a time so that the LDS latency is paid once per 256
+    // keys; whole groups need neither clamped addresses nor range masks.
     constexpr int U = 4;
     int nr = 0;
-    for (int base = lo; base < hi; base += 64 * U) {
+    int base1 = lo;
+    const int ngroups = n / (64 * U);  // whole groups of U chunks
+    for (int g = 0; g < ngroups; ++g, base1 += 64 * U) {
         uint32_t sc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            sc[u] = score_of(a[min(base + u * 64 + lane, hi - 1)]);
+            sc[u] = score_of(a[base1 + u * 64 + lane]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            nr += __popcll(__ballot(base + u * 64 + lane < hi) & __ballot(sc[u] >= p));
+            nr += __popcll(__ballot(sc[u] >= p));
         }
     }
-    // pass 2: classify, list the swapped positions by rank
+    if (base1 < hi) {
+        uint32_t sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sc[u] = score_of(a[min(base1 + u * 64 + lane, hi - 1)]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            nr += __popcll(__ballot(base1 + u * 64 + lane < hi) & __ballot(sc[u] >= p));
+        }
+    }
+    nr = __builtin_amdgcn_readfirstlane(nr);  // (a sum of ballot counts: uniform, and the regime tests below must be scalar)
+    // pass 2: classify, list the swapped positions by rank.  h(i) = (R stoppers right of i) - (L stoppers left of i) only
+    // falls along the segment, so the swapped L stoppers are a prefix of the L stoppers and the swapped R stoppers a suffix
+    // of the R stoppers: a chunk is (a) before the crossing -- every L stopper of it is swapped, no R stopper is --, (b)
+    // behind it -- the reverse -- or (c) at the crossing, and which one the chunk's stopper counts tell (wave-uniform).
+    // Only (c), a chunk or two per partition, needs the per-lane swap rule (round 5: until then every chunk paid for it).
     uint16_t* lpos = scr;
     uint16_t* rpos = scr + n / 2;
     int run_l = 0, run_r = 0, K = 0;
-    int cut_l = 0x7fffffff, cut_r = 0x7fffffff;
-    for (int base0 = lo; base0 < hi; base0 += 64 * U) {
-        uint32_t scs[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            scs[u] = score_of(a[min(base0 + u * 64 + lane, hi - 1)]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int base = base0 + u * 64;
-            if (base >= hi) {
-                break;  // wave-uniform
+    int cut_l = 0x7fffffff;  // the first L stopper that is NOT swapped
+    auto classify = [&](int base, uint32_t sc, bool in, unsigned long long m_in) {
+        const int i = base + lane;
+        const bool is_l = in && sc <= p;
+        const bool is_r = in && sc >= p;
+        const unsigned long long ml = __ballot(sc <= p) & m_in;
+        const unsigned long long mr = __ballot(sc >= p) & m_in;
+        const int cl = __popcll(ml), cr = __popcll(mr);
+        const int rem_r = nr - run_r;  // R stoppers from this chunk's first key on
+        if (rem_r - cr >= run_l + cl) {
+            // (a): for every lane r_right >= rem_r - cr >= run_l + cl >= l_left + 1
+            if (is_l) {
+                lpos[run_l + rank_below(ml)] = static_cast<uint16_t>(i - first);
             }
-            const int i = base + lane;
-            const bool in = i < hi;
-            const uint32_t sc = scs[u];
-            const bool is_l = in && sc <= p;
-            const bool is_r = in && sc >= p;
-            // ballots of single comparisons, combined on the scalar side: the ballot of a compound predicate
-            // compiles to v_cndmask + v_cmp_ne on top of the comparisons
-            const unsigned long long m_in = __ballot(in);
-            const unsigned long long ml = __ballot(sc <= p) & m_in;
-            const unsigned long long mr = __ballot(sc >= p) & m_in;
-            const int l_left = run_l + rank_below(ml);                            // L stoppers left of i
-            const int r_right = nr - (run_r + rank_below(mr) + (is_r ? 1 : 0));  // R stoppers right of i
+            K += cl;
+        } else if (run_l >= rem_r) {
+            // (b): for every R stopper l_left >= run_l >= rem_r >= r_right + 1, and no L stopper has r_right >= l_left + 1
+            if (is_r) {
+                rpos[rem_r - 1 - rank_below(mr)] = static_cast<uint16_t>(i - first);
+            }
+            if (cut_l == 0x7fffffff && ml != 0) {
+                cut_l = base + __ffsll(static_cast<long long>(ml)) - 1;
+            }
+        } else {
+            const int l_left = run_l + rank_below(ml);                       // L stoppers left of i
+            const int r_right = rem_r - (rank_below(mr) + (is_r ? 1 : 0));  // R stoppers right of i
             const bool swap_l = is_l && r_right >= l_left + 1;
             const bool swap_r = is_r && l_left >= r_right + 1;
             if (swap_l) {
@@ -214,21 +235,47 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
             if (swap_r) {
                 rpos[r_right] = static_cast<uint16_t>(i - first);
             }
-            const unsigned long long sl = __ballot(r_right >= l_left + 1) & ml;
+            const unsigned long long sl = __ballot(swap_l);
             const unsigned long long stay = ml & ~sl;
-            const unsigned long long moved = __ballot(l_left >= r_right + 1) & mr;
             K += __popcll(sl);
-            if (stay != 0 && cut_l == 0x7fffffff) {
+            if (cut_l == 0x7fffffff && stay != 0) {
                 cut_l = base + __ffsll(static_cast<long long>(stay)) - 1;
             }
-            if (moved != 0 && cut_r == 0x7fffffff) {
-                cut_r = base + __ffsll(static_cast<long long>(moved)) - 1;
+        }
+        run_l += cl;
+        run_r += cr;
+    };
+    int base2 = lo;
+    for (int g = 0; g < ngroups; ++g, base2 += 64 * U) {
+        uint32_t scs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            scs[u] = score_of(a[base2 + u * 64 + lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            classify(base2 + u * 64, scs[u], true, ~0ull);
+        }
+    }
+    if (base2 < hi) {
+        uint32_t scs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            scs[u] = score_of(a[min(base2 + u * 64 + lane, hi - 1)]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int base = base2 + u * 64;
+            if (base >= hi) {
+                break;  // wave-uniform
             }
-            run_l += __popcll(ml);
-            run_r += __popcll(mr);
+            classify(base, scs[u], base + lane < hi, __ballot(base + lane < hi));
         }
     }
     wave_mem_fence();
+    // the lowest swapped R stopper is the one with K - 1 R stoppers to its right
+    // (every lane reads the same entry: made a scalar again, or the caller's first / last would turn into vector values)
+    const int cut_r = K > 0 ? first + __builtin_amdgcn_readfirstlane(static_cast<int>(rpos[K - 1])) : 0x7fffffff;
     // pass 3: exchange the K pairs
     for (int k = lane; k < K; k += 64) {
         const int i = first + lpos[k];
@@ -481,6 +528,11 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     int my_swaps = 0;
     int min_unswapped_l = 0x7fffffff;
     int min_swapped_r = 0x7fffffff;
+    // The three regimes of wave_partition_cf's chunks (before / behind / at the crossing of the two scans), with the
+    // stoppers of the other waves' slices counted in: only a chunk at the crossing needs the per-lane swap rule.
+    nr = __builtin_amdgcn_readfirstlane(nr);
+    l_before = __builtin_amdgcn_readfirstlane(l_before);
+    r_after = __builtin_amdgcn_readfirstlane(r_after);
     auto classify = [&](int base, uint32_t sc) {
         const int i = base + lane;
         const bool in = i < w_hi;
@@ -489,31 +541,52 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
         const unsigned long long m_in = __ballot(in);
         const unsigned long long ml = __ballot(sc <= p) & m_in;
         const unsigned long long mr = __ballot(sc >= p) & m_in;
-        const uint32_t l_left = l_before + run_l + static_cast<uint32_t>(rank_below(ml));  // L at positions < i
-        const uint32_t r_le = run_r + static_cast<uint32_t>(rank_below(mr)) + (is_r ? 1u : 0u);
-        const uint32_t r_right = r_after + (nr - r_le);  // R at positions > i
-        // L stopper of 0-based rank l_left: its partner R_{l_left} exists to the right iff r_right >= l_left + 1;
-        // R stopper of rank-from-the-right r_right: its partner lies to the left iff l_left >= r_right + 1
-        const bool swap_l = is_l && r_right >= l_left + 1u;
-        const bool swap_r = is_r && l_left >= r_right + 1u;
-        if (swap_l) {
-            lpos[l_left] = static_cast<PosT>(i - first);
+        const uint32_t cl = static_cast<uint32_t>(__popcll(ml)), cr = static_cast<uint32_t>(__popcll(mr));
+        const uint32_t l_base = l_before + run_l;       // L stoppers left of this chunk
+        const uint32_t rem = r_after + (nr - run_r);    // R stoppers from this chunk's first key on
+        if (rem >= cr + l_base + cl) {
+            // (a) every L stopper of the chunk is swapped (r_right >= rem - cr >= l_left + 1), no R stopper is
+            if (is_l) {
+                lpos[l_base + static_cast<uint32_t>(rank_below(ml))] = static_cast<PosT>(i - first);
+            }
+            my_swaps += static_cast<int>(cl);
+        } else if (l_base >= rem) {
+            // (b) every R stopper is swapped (l_left >= l_base >= rem >= r_right + 1), no L stopper is
+            if (is_r) {
+                rpos[rem - 1u - static_cast<uint32_t>(rank_below(mr))] = static_cast<PosT>(i - first);
+            }
+            if (min_unswapped_l == 0x7fffffff && ml != 0) {
+                min_unswapped_l = base + __ffsll(static_cast<long long>(ml)) - 1;
+            }
+            if (min_swapped_r == 0x7fffffff && mr != 0) {
+                min_swapped_r = base + __ffsll(static_cast<long long>(mr)) - 1;
+            }
+        } else {
+            const uint32_t l_left = l_base + static_cast<uint32_t>(rank_below(ml));  // L at positions < i
+            const uint32_t r_right = rem - (static_cast<uint32_t>(rank_below(mr)) + (is_r ? 1u : 0u));  // R at positions > i
+            // L stopper of 0-based rank l_left: its partner R_{l_left} exists to the right iff r_right >= l_left + 1;
+            // R stopper of rank-from-the-right r_right: its partner lies to the left iff l_left >= r_right + 1
+            const bool swap_l = is_l && r_right >= l_left + 1u;
+            const bool swap_r = is_r && l_left >= r_right + 1u;
+            if (swap_l) {
+                lpos[l_left] = static_cast<PosT>(i - first);
+            }
+            if (swap_r) {
+                rpos[r_right] = static_cast<PosT>(i - first);
+            }
+            const unsigned long long sl = __ballot(swap_l);
+            const unsigned long long stay = ml & ~sl;
+            const unsigned long long moved = __ballot(swap_r);
+            my_swaps += __popcll(sl);
+            if (stay != 0 && min_unswapped_l == 0x7fffffff) {
+                min_unswapped_l = base + __ffsll(static_cast<long long>(stay)) - 1;
+            }
+            if (moved != 0 && min_swapped_r == 0x7fffffff) {
+                min_swapped_r = base + __ffsll(static_cast<long long>(moved)) - 1;
+            }
         }
-        if (swap_r) {
-            rpos[r_right] = static_cast<PosT>(i - first);
-        }
-        const unsigned long long sl = __ballot(r_right >= l_left + 1u) & ml;
-        const unsigned long long stay = ml & ~sl;
-        const unsigned long long moved = __ballot(l_left >= r_right + 1u) & mr;
-        my_swaps += __popcll(sl);
-        if (stay != 0 && min_unswapped_l == 0x7fffffff) {
-            min_unswapped_l = base + __ffsll(static_cast<long long>(stay)) - 1;
-        }
-        if (moved != 0 && min_swapped_r == 0x7fffffff) {
-            min_swapped_r = base + __ffsll(static_cast<long long>(moved)) - 1;
-        }
-        run_l += static_cast<uint32_t>(__popcll(ml));
-        run_r += static_cast<uint32_t>(__popcll(mr));
+        run_l += cl;
+        run_r += cr;
     };
     if (in_regs) {
 #pragma unroll
