@@ -154,6 +154,9 @@ int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int c
  * sorts n scores (each an integer 0..4095) descending exactly as libstdc++'s introsort
  * permutes them; perm_out[r] = input index that lands at sorted position r. */
 int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out);
+/* ... through the two-launch form of the sort that launches of few frames take (groups > 1: sort_split_kernel, then
+ * `groups` workgroups of sort_pieces_kernel; groups == 1: the call above).  Same permutation. */
+int slamx_debug_sort_desc_groups(slamx_ctx* ctx, const uint32_t* scores, int n, int groups, uint32_t* perm_out);
 /* The glibc libm calls of computeOrientation / computeBRIEFDescriptor
  * (feature_detector.cpp:229, 247-249) as evaluated on the device. */
 int slamx_debug_trig(slamx_ctx* ctx, const float* m01, const float* m10, int n, float* angle_deg, float* cos_out,

@@ -107,7 +107,7 @@ EXPORTS = [
     "slamx_ctx_stream", "slamx_ctx_device_name", "slamx_ctx_timer_start", "slamx_ctx_timer_stop_ms",
     "slamx_detector_context", "slamx_detector_config_load", "slamx_matcher_config_load", "slamx_loop_closure_config_load", "slamx_detector_create", "slamx_detector_destroy",
     "slamx_detector_pattern", "slamx_detector_descriptor_width", "slamx_detect", "slamx_compute",
-    "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc",
+    "slamx_detect_and_compute", "slamx_fast_candidates", "slamx_gaussian_blur", "slamx_debug_sort_desc", "slamx_debug_sort_desc_groups",
     "slamx_debug_trig", "slamx_debug_penalty", "slamx_matcher_create", "slamx_matcher_destroy", "slamx_matcher_match",
     "slamx_batch_create", "slamx_batch_destroy", "slamx_batch_frames", "slamx_batch_upload",
     "slamx_host_alloc", "slamx_host_free", "slamx_batch_upload_async", "slamx_batch_upload_async_flags",
@@ -169,6 +169,7 @@ def load_library():
     lib.slamx_fast_candidates.argtypes = img + [vp, C.c_int, C.POINTER(C.c_int)]
     lib.slamx_gaussian_blur.argtypes = img + [vp]
     lib.slamx_debug_sort_desc.argtypes = [vp, vp, C.c_int, vp]
+    lib.slamx_debug_sort_desc_groups.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.slamx_debug_trig.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     lib.slamx_debug_penalty.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.slamx_matcher_create.argtypes = [vp, C.POINTER(MatcherConfig), C.POINTER(vp)]
@@ -435,10 +436,11 @@ class Context(_Owner):
         _check(self.lib.slamx_ctx_timer_stop_ms(self.h, C.byref(ms)))
         return ms.value
 
-    def debug_sort_desc(self, scores):
+    def debug_sort_desc(self, scores, groups=1):
+        """The std::sort permutation of `scores` (descending); groups > 1: through the two-launch form of the sort."""
         s = np.ascontiguousarray(scores, dtype=np.uint32)
         perm = np.empty(s.shape[0], np.uint32)
-        _check(self.lib.slamx_debug_sort_desc(self.h, _ptr(s), s.shape[0], _ptr(perm)))
+        _check(self.lib.slamx_debug_sort_desc_groups(self.h, _ptr(s), s.shape[0], int(groups), _ptr(perm)))
         return perm
 
     # ---- small dense pose solves (rows a11-a14) ----

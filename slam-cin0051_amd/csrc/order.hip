@@ -115,6 +115,10 @@ struct SortShared {
     int n_big[2];
     int q_head, q_tail, q_pending;  // segment work queue (see SegQueue)
     uint8_t sel[16][2][64];  // per wave (wave_small_introsort): lane of the k-th swapped L / R stopper of a range
+#ifdef SLAMX_SORT_CLOCKS
+    unsigned long long stamp[16];  // development: wall_clock64() (100 MHz) at phase borders, printed by the kernel
+    int n_stamp;
+#endif
 };
 
 __device__ __forceinline__ int rank_below(unsigned long long m) {  // set bits of m below this lane
@@ -633,7 +637,8 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     return cut;
 }
 
-__device__ int SORT_BLOCK_MIN = 3072;  // segments at least this long are partitioned by the whole workgroup
+__device__ int SORT_BLOCK_MIN = 4096;  // segments at least this long are partitioned by the whole workgroup (round 5: 3072
+                                        // until the wave-level partition got cheaper; 1080p_2k 0.411 -> 0.404, c2 0.652 -> 0.641 ms)
 
 // Work queue of the wave-level segments of one introsort_levels call (LDS): a bounded ring with a
 // sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
@@ -653,6 +658,7 @@ constexpr int SORT_QCAP = SLAMX_SORT_QCAP;
 // keys, so the 20-24k candidates of a pyramid level paid a workgroup-wide partition level in global memory first.
 constexpr int SORT_LDS_KEYS_MAX = SLAMX_SORT_LDS_KEYS;
 constexpr int PIECE_NO_LEVELS = 0x7f;  // depth field of a piece that is a single leaf: it only takes the leaf pass
+constexpr int PIECE_SORTED = 0x7e;     // ... of a piece the depth-limit heapsort has sorted already: every key is its own leaf
 static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
 
 struct SegQueue {
@@ -735,8 +741,27 @@ __device__ bool seg_pop(const SegQueue& q, SortShared& sh, int2* item) {
 // wave's own partitions behind the keys in LDS when scr_lds_word >= 0 (the word offset of that area in `a`), else
 // scr16 as well.  Two call sites, so that each form keeps its address space.  (The same for block_partition made it
 // a called function: 74 registers and a stack; inlined three times the kernel grew from 55 to 74 KB.)
+// SPLIT (the two-kernel form for few frames, sort_split_kernel): the levels stop at segments of at most `stop` (>= 64) keys,
+// which are appended to `ready` as pieces {first, last | code << 24} in global positions (bit_base + ...) for the workgroups
+// of sort_pieces_kernel; sh.counters[3] counts them.  Every key ends up in exactly one piece.
+template <bool SPLIT>
 __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, int scr_lds_word, const SegQueue& q, int len, int depth,
-                                 uint32_t* segbits, int bit_base, SortShared& sh) {
+                                 uint32_t* segbits, int bit_base, SortShared& sh, int stop = 0, int2* ready = nullptr,
+                                 int maxSeg = 0) {
+    // one lane: [f, l) is finished as far as this call goes; d = remaining depth, or PIECE_SORTED
+    auto emit_piece = [&](int f, int l, int d) {
+        if (l <= f) {
+            return;
+        }
+        const int code = d == PIECE_SORTED ? PIECE_SORTED : (l - f > SORT_LEAF ? d : PIECE_NO_LEVELS);
+        const int slot = atomicAdd(&sh.counters[3], 1);
+        if (slot < maxSeg) {
+            ready[slot] = make_int2(bit_base + f, (bit_base + l) | (code << 24));
+        } else {
+            sh.counters[2] = 1;
+        }
+    };
+    const int keep_above = SPLIT ? stop : SORT_LEAF;  // children longer than this go on through the levels
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -755,8 +780,10 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
         if (len >= SORT_BLOCK_MIN) {
             sh.big[0][0] = make_int2(0, len);
             sh.n_big[0] = 1;
-        } else if (len > SORT_LEAF) {
+        } else if (len > keep_above) {
             seg_push(q, sh, 0, len, depth);
+        } else if (SPLIT) {
+            emit_piece(0, len, depth);
         }
     }
     __threadfence_block();
@@ -785,6 +812,9 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
                 for (int i = seg.x + tid; i < seg.y; i += blockDim.x) {
                     mark_leaf_boundary(i);
                 }
+                if (SPLIT && tid == 0) {
+                    emit_piece(seg.x, seg.y, PIECE_SORTED);
+                }
                 continue;
             }
             const int cut = block_partition(a, scr16 + seg.x, seg.x, seg.y, sh);  // (workgroup-wide: lists in global memory)
@@ -800,8 +830,10 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
                         } else {
                             sh.counters[2] = 1;
                         }
-                    } else if (size > SORT_LEAF) {
+                    } else if (size > keep_above) {
                         seg_push(q, sh, child[c].x, child[c].y, depth - 1);
+                    } else if (SPLIT) {
+                        emit_piece(child[c].x, child[c].y, depth - 1);
                     }
                 }
             }
@@ -816,7 +848,16 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
         cur ^= 1;
         __syncthreads();
     }
+#ifdef SLAMX_SORT_CLOCKS
+    if (tid == 0) {
+        sh.stamp[sh.n_stamp++] = wall_clock64();  // end of the workgroup-wide levels
+    }
+#endif
     // ---- phase 2: the queue
+#ifdef SLAMX_EXP_SKIP_QUEUE
+    __syncthreads();
+    return;
+#endif
     bool have = false;
     int first = 0, last = 0, dep = 0;
     while (true) {
@@ -843,19 +884,40 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
             for (int i = first + lane; i < last; i += 64) {
                 mark_leaf_boundary(i);
             }
-        } else if (last - first <= 64) {
+            if (SPLIT && lane == 0) {
+                emit_piece(first, last, PIECE_SORTED);
+            }
+        } else if (!SPLIT && last - first <= 64) {
+#ifndef SLAMX_EXP_SKIP_SMALL
             wave_small_introsort(a, first, last, dep, lane, sh.sel[wave], segbits, bit_base);
+#endif
         } else {
+#ifdef SLAMX_SORT_CLOCKS
+            const unsigned long long tw0 = clock64();
+#endif
             const int cut = scr_lds_word >= 0
                                 ? wave_partition_cf(a, reinterpret_cast<uint16_t*>(a + scr_lds_word) + first, first, last, lane)
                                 : wave_partition_cf(a, scr16 + first, first, last, lane);
+#ifdef SLAMX_SORT_CLOCKS
+            if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && last - first > 300) {
+                printf("    wave %d partition of %d keys: %llu cycles (cut at %d)\n", wave, last - first, clock64() - tw0, cut - first);
+            }
+#endif
             const int size_l = cut - first;
             const int size_r = last - cut;
             if (lane == 0) {
                 mark_leaf_boundary(cut);
             }
-            const bool keep_l = size_l > SORT_LEAF;
-            const bool keep_r = size_r > SORT_LEAF;
+            const bool keep_l = size_l > keep_above;
+            const bool keep_r = size_r > keep_above;
+            if (SPLIT && lane == 0) {  // a child that stops here is a piece
+                if (!keep_l) {
+                    emit_piece(first, cut, dep - 1);
+                }
+                if (!keep_r) {
+                    emit_piece(cut, last, dep - 1);
+                }
+            }
             if (keep_l && keep_r) {
                 // continue with the larger child, queue the other one
                 const bool go_left = size_l >= size_r;
@@ -887,6 +949,94 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
     }
     __threadfence_block();
     __syncthreads();
+}
+
+// One piece {first, last | code << 24} of a frame's keys: load it into LDS, run its introsort levels there, and
+// __final_insertion_sort straight from LDS into the output -- a stable sort inside each leaf: rank counting, one
+// lane per element.  (Until late in round 3 the pieces of a long array went back to global memory and ONE leaf pass
+// read them again from there: 0.23 ms of c3's 1.73.)  (x,y) in sorted order is written over the piece's dead unsorted
+// keys for the greedy NMS, which then streams its input (the gather is cheaper here, spread over 16 waves, than in
+// that single-wave kernel).  rank_of (optional): the inverse permutation, a divergent scatter.
+// segbits: leaf flags indexed by GLOBAL position, with the flags at both ends of the piece set.
+__device__ __forceinline__ void finish_piece(uint32_t* gkeys, uint32_t* out, uint32_t* lds, int lds_keys, uint32_t* segbits, int nwords,
+                                             const SegQueue& queue, int2 seg, SortShared& sh, uint32_t* rank_of, const uint32_t* xy) {
+    const int tid = threadIdx.x;
+    const bool sorted_xy = xy != nullptr;  // a loaded piece's keys in gkeys are dead: (x,y) in sorted order go there
+    {
+        const int first = seg.x;
+        const int last = seg.y & 0xffffff;
+        const int depth = seg.y >> 24;
+        const int len = last - first;
+        for (int i = tid; i < len; i += blockDim.x) {
+            lds[i] = gkeys[first + i];
+        }
+        __syncthreads();
+        if (depth == PIECE_SORTED) {
+            for (int i = first + tid; i < last; i += blockDim.x) {
+                atomicOr(&segbits[i >> 5], 1u << (i & 31));
+            }
+            __syncthreads();
+        } else if (depth != PIECE_NO_LEVELS) {
+            // 16-bit position lists of this piece's partitions (len entries): behind its keys while there is room (19k
+            // keys), else the piece's range of the output array
+            const int len4 = (len + 3) & ~3;
+            const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
+            introsort_levels<false>(lds, reinterpret_cast<uint16_t*>(out + first), scr_lds_word, queue, len, depth, segbits, first, sh);
+        }
+        constexpr int LU = 4;  // elements per thread and step: their gathers are in flight together
+#ifdef SLAMX_EXP_SKIP_LEAF
+        for (int i0 = first + tid; i0 < first; i0 += LU * blockDim.x) {
+#else
+        for (int i0 = first + tid; i0 < last; i0 += LU * blockDim.x) {
+#endif
+            uint32_t me[LU], pxy[LU];
+            int lo_[LU], hi_[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = min(i0 + u * static_cast<int>(blockDim.x), last - 1);
+                me[u] = lds[i - first];
+                // A leaf has at most SORT_LEAF = 16 elements, so its start flag lies in (i-16, i] and its
+                // end flag in (i, i+16]: both inside the 64 flag bits that start at word (i-16)/32
+                // (flags 0 and n are always set, and so are those at a piece's ends).
+                const int w0 = max(i - 16, 0) >> 5;
+                const unsigned long long x = static_cast<unsigned long long>(segbits[w0]) |
+                                             (static_cast<unsigned long long>(segbits[min(w0 + 1, nwords - 1)]) << 32);
+                const int rel = i - w0 * 32;  // <= 47
+                const unsigned long long upto = x & low_mask(rel + 1);
+                const unsigned long long above = x & ~low_mask(rel + 1);
+                lo_[u] = w0 * 32 + (63 - __clzll(static_cast<long long>(upto)));
+                hi_[u] = w0 * 32 + (__ffsll(static_cast<long long>(above)) - 1);
+            }
+            if (sorted_xy) {
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    pxy[u] = xy[me[u] & INDEX_MASK];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * static_cast<int>(blockDim.x);
+                if (i >= last) {
+                    break;
+                }
+                const uint32_t sc = score_of(me[u]);
+                int pos = lo_[u];
+                for (int j = lo_[u]; j < hi_[u]; ++j) {
+                    const uint32_t o = score_of(lds[j - first]);
+                    pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
+                }
+                out[pos] = me[u];
+                if (rank_of != nullptr) {
+                    rank_of[me[u] & INDEX_MASK] = static_cast<uint32_t>(pos);
+                }
+                if (sorted_xy) {
+                    gkeys[pos] = pxy[u];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // Sort n keys descending by score exactly as std::sort does.  One workgroup.
@@ -1014,82 +1164,11 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
     }
     __threadfence_block();
     __syncthreads();
-    // phase B: every piece (an LDS-sized segment; the whole array when it fits): load, introsort levels in LDS, and
-    // __final_insertion_sort straight from LDS into the output -- a stable sort inside each leaf: rank counting, one
-    // lane per element.  (Until late in round 3 the pieces of a long array went back to global memory and ONE leaf pass
-    // read them again from there: 0.23 ms of c3's 1.73.)  (x,y) in sorted order is written over the piece's dead unsorted
-    // keys for the greedy NMS, which then streams its input (the gather is cheaper here, spread over 16 waves, than in
-    // that single-wave kernel).  rank_of (optional): the inverse permutation, a
-    // divergent scatter.
+    // phase B: every piece (an LDS-sized segment; the whole array when it fits): finish_piece
     (void)all_in_lds;
-    const bool sorted_xy = xy != nullptr;  // a loaded piece's keys in gkeys are dead: (x,y) in sorted order go there
     const int n_ready = min(sh.counters[3], maxSeg);
     for (int r = 0; r < n_ready; ++r) {
-        const int2 seg = ready[r];
-        const int first = seg.x;
-        const int last = seg.y & 0xffffff;
-        const int depth = seg.y >> 24;
-        const int len = last - first;
-        for (int i = tid; i < len; i += blockDim.x) {
-            lds[i] = gkeys[first + i];
-        }
-        __syncthreads();
-        if (depth != PIECE_NO_LEVELS) {
-            // 16-bit position lists of this piece's partitions (len entries): behind its keys while there is room (19k
-            // keys), else the piece's range of the output array
-            const int len4 = (len + 3) & ~3;
-            const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
-            introsort_levels(lds, reinterpret_cast<uint16_t*>(out + first), scr_lds_word, queue, len, depth, segbits, first, sh);
-        }
-        constexpr int LU = 4;  // elements per thread and step: their gathers are in flight together
-        for (int i0 = first + tid; i0 < last; i0 += LU * blockDim.x) {
-            uint32_t me[LU], pxy[LU];
-            int lo_[LU], hi_[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = min(i0 + u * static_cast<int>(blockDim.x), last - 1);
-                me[u] = lds[i - first];
-                // A leaf has at most SORT_LEAF = 16 elements, so its start flag lies in (i-16, i] and its
-                // end flag in (i, i+16]: both inside the 64 flag bits that start at word (i-16)/32
-                // (flags 0 and n are always set, and so are those at a piece's ends).
-                const int w0 = max(i - 16, 0) >> 5;
-                const unsigned long long x = static_cast<unsigned long long>(segbits[w0]) |
-                                             (static_cast<unsigned long long>(segbits[min(w0 + 1, nwords - 1)]) << 32);
-                const int rel = i - w0 * 32;  // <= 47
-                const unsigned long long upto = x & low_mask(rel + 1);
-                const unsigned long long above = x & ~low_mask(rel + 1);
-                lo_[u] = w0 * 32 + (63 - __clzll(static_cast<long long>(upto)));
-                hi_[u] = w0 * 32 + (__ffsll(static_cast<long long>(above)) - 1);
-            }
-            if (sorted_xy) {
-#pragma unroll
-                for (int u = 0; u < LU; ++u) {
-                    pxy[u] = xy[me[u] & INDEX_MASK];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = i0 + u * static_cast<int>(blockDim.x);
-                if (i >= last) {
-                    break;
-                }
-                const uint32_t sc = score_of(me[u]);
-                int pos = lo_[u];
-                for (int j = lo_[u]; j < hi_[u]; ++j) {
-                    const uint32_t o = score_of(lds[j - first]);
-                    pos += (o > sc || (o == sc && j < i)) ? 1 : 0;
-                }
-                out[pos] = me[u];
-                if (rank_of != nullptr) {
-                    rank_of[me[u] & INDEX_MASK] = static_cast<uint32_t>(pos);
-                }
-                if (sorted_xy) {
-                    gkeys[pos] = pxy[u];
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
+        finish_piece(gkeys, out, lds, lds_keys, segbits, nwords, queue, ready[r], sh, rank_of, xy);
     }
     const int overflow = sh.counters[2];
     __threadfence_block();
@@ -1119,6 +1198,274 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_kernel(BatchView v, int lds
     const int st = block_sort_desc(gkeys, out, dyn_lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, rank_of, xy);
     if (threadIdx.x == 0 && st != 0) {
         atomicOr(&v.status[f], st);
+    }
+}
+
+// ---------------- the same sort in TWO launches, for launches of few frames (round 5) ----------------
+// One workgroup per frame leaves all but a frame's CU idle when a launch holds fewer frames than the chip has CUs -- the
+// reference's API is one frame per call (feature_detector.hpp:114-135), where the sort was 155 of a KITTI frame's 290 us of
+// kernels.  After the top levels of the introsort the segments are independent by construction, so:
+//   sort_split_kernel   one workgroup per frame: the levels (workgroup-wide, then the wave queue) down to segments of at
+//                       most `stop` = max(256, n / (2 groups)) keys, which it lists as pieces; keys back to global memory;
+//   sort_pieces_kernel  `groups` workgroups per frame: piece r of the list goes to workgroup r mod groups -- its remaining
+//                       levels, the leaf pass, the by-products -- on a CU of its own.
+// Same partitions on the same segments in either form (a segment's partition depends on its keys only), hence the same
+// permutation; frames with more keys than LDS holds go through the global-memory levels first, as in sort_kernel.
+// The piece count of a frame travels in lists[3 maxSeg - 1].x.
+__global__ __launch_bounds__(SORT_THREADS) void sort_split_kernel(BatchView v, int lds_keys, int groups, int split_small,
+                                                                  int need_rank_of) {
+    __shared__ SortShared sh;
+    const int f = blockIdx.x;
+    const int n = v.n_cand[f];
+    const int tid = threadIdx.x;
+    int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
+    const int maxSeg = v.maxSeg - 1;  // (the last entry of the ready list carries the count)
+    int2* ready = lists + 2 * v.maxSeg;
+    if (n == 0) {
+        if (tid == 0) {
+            lists[3 * v.maxSeg - 1] = make_int2(0, 0);
+        }
+        return;
+    }
+    uint32_t* gkeys = v.keys + static_cast<size_t>(f) * v.maxM;
+    uint32_t* out = v.sorted + static_cast<size_t>(f) * v.maxM;
+    uint32_t* lds = dyn_lds;
+    if (n <= lds_keys && split_small == 0) {
+        // A frame whose keys fit LDS is sorted here, by this workgroup alone, exactly as sort_kernel does it: measured
+        // (round 5, a KITTI frame of 11,329 keys on an otherwise idle GPU) the split form is no faster for it -- 3.4 us
+        // load + 28 us for the three workgroup-wide levels + 58 us for three levels of wave partitions + 3 us store in
+        // this kernel, then 57 us for the 53 pieces on 16 workgroups: 138 against 137 us, because what bounds ONE frame is
+        // the chain of dependent levels (a partition of 2.8k keys by one wave: 20k cycles), not the work.  The pieces of
+        // a frame that does NOT fit (below) are LDS-sized sorts of their own: those do spread.
+        uint32_t* gsegbits = reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
+        uint32_t* rank_of = need_rank_of != 0 ? v.rank_of + static_cast<size_t>(f) * v.maxM : nullptr;
+        const uint32_t* xy = need_rank_of != 0 ? nullptr : v.cand_xy + static_cast<size_t>(f) * v.maxM;
+        const int st = block_sort_desc(gkeys, out, lds, lds_keys, gsegbits, lists, v.maxSeg, n, sh, rank_of, xy);
+        if (tid == 0) {
+            lists[3 * v.maxSeg - 1] = make_int2(0, 0);  // nothing left for sort_pieces_kernel
+            if (st != 0) {
+                atomicOr(&v.status[f], st);
+            }
+        }
+        return;
+    }
+    if (tid == 0) {
+        sh.counters[2] = 0;  // overflow flag
+        sh.counters[3] = 0;  // number of pieces
+    }
+    __syncthreads();
+#ifdef SLAMX_SORT_CLOCKS
+    if (tid == 0) {
+        sh.n_stamp = 0;
+        sh.stamp[sh.n_stamp++] = wall_clock64();
+    }
+#endif
+    const int depth0 = n > 1 ? 2 * (31 - __clz(n)) : 0;  // std::__lg(n) * 2
+    int stop = (n + 2 * groups - 1) / (2 * groups);
+    stop = stop < 256 ? 256 : stop;
+    if (n <= lds_keys) {
+        const int nwords = (n + 32) / 32;
+        uint32_t* segbits = lds + lds_keys;  // (cut marks of this kernel's levels: not needed later, every cut is a piece border)
+        SegQueue queue;
+        queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
+        queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
+        queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
+        for (int i = tid; i < nwords; i += blockDim.x) {
+            segbits[i] = 0u;
+        }
+        for (int i = tid; i < n; i += blockDim.x) {
+            lds[i] = gkeys[i];
+        }
+        __syncthreads();
+#ifdef SLAMX_SORT_CLOCKS
+        if (tid == 0) {
+            sh.stamp[sh.n_stamp++] = wall_clock64();  // keys loaded
+        }
+#endif
+        const int len4 = (n + 3) & ~3;
+        const int scr_lds_word = len4 + (len4 >> 1) <= lds_keys ? len4 : -1;
+        introsort_levels<true>(lds, reinterpret_cast<uint16_t*>(out), scr_lds_word, queue, n, depth0, segbits, 0, sh, stop, ready, maxSeg);
+#ifdef SLAMX_SORT_CLOCKS
+        if (tid == 0) {
+            sh.stamp[sh.n_stamp++] = wall_clock64();  // levels done
+        }
+#endif
+        for (int i = tid; i < n; i += blockDim.x) {
+            gkeys[i] = lds[i];
+        }
+    } else {
+        // global-memory levels until every segment fits LDS (sort_kernel's phase A); those segments are the pieces
+        if (tid == 0) {
+            lists[0] = make_int2(0, n);
+            sh.counters[0] = 1;
+            sh.counters[1] = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        int cur = 0;
+        int depth = depth0;
+        while (true) {
+            const int count = sh.counters[0];
+            if (count == 0) {
+                break;
+            }
+            int2* src = lists + cur * v.maxSeg;
+            int2* dst = lists + (cur ^ 1) * v.maxSeg;
+            for (int sidx = 0; sidx < count; ++sidx) {
+                const int2 seg = src[sidx];
+                if (depth == 0) {
+                    if (tid == 0) {
+                        heap_sort_(gkeys + seg.x, seg.y - seg.x);
+                        // (sorted: handed on in LDS-sized slices, every key its own leaf)
+                        for (int at = seg.x; at < seg.y; at += lds_keys) {
+                            const int slot = sh.counters[3]++;
+                            if (slot < maxSeg) {
+                                ready[slot] = make_int2(at, min(at + lds_keys, seg.y) | (PIECE_SORTED << 24));
+                            } else {
+                                sh.counters[2] = 1;
+                            }
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    continue;
+                }
+                const int cut = block_partition(gkeys, out, seg.x, seg.y, sh);
+                if (tid == 0) {
+                    const int2 child[2] = {make_int2(cut, seg.y), make_int2(seg.x, cut)};
+                    for (int c = 0; c < 2; ++c) {
+                        const int size = child[c].y - child[c].x;
+                        if (size <= 0) {
+                            continue;
+                        }
+                        if (size <= lds_keys) {
+                            const int slot = sh.counters[3]++;
+                            if (slot < maxSeg) {
+                                ready[slot] = make_int2(child[c].x, child[c].y | ((size > SORT_LEAF ? depth - 1 : PIECE_NO_LEVELS) << 24));
+                            } else {
+                                sh.counters[2] = 1;
+                            }
+                        } else {
+                            const int slot = sh.counters[1]++;
+                            if (slot < v.maxSeg) {
+                                dst[slot] = child[c];
+                            } else {
+                                sh.counters[2] = 1;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) {
+                sh.counters[0] = min(sh.counters[1], v.maxSeg);
+                sh.counters[1] = 0;
+            }
+            depth = depth > 0 ? depth - 1 : 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    __threadfence();
+    __syncthreads();
+#ifdef SLAMX_SORT_CLOCKS
+    if (tid == 0 && f == 0) {
+        sh.stamp[sh.n_stamp++] = wall_clock64();
+        printf("split n %d stop %d pieces %d: load %.1f block %.1f queue %.1f store %.1f us\n", n, stop, sh.counters[3],
+               (sh.stamp[1] - sh.stamp[0]) * 0.01, (sh.stamp[2] - sh.stamp[1]) * 0.01, (sh.stamp[3] - sh.stamp[2]) * 0.01,
+               (sh.stamp[4] - sh.stamp[3]) * 0.01);
+    }
+#endif
+    if (tid == 0) {
+        lists[3 * v.maxSeg - 1] = make_int2(min(sh.counters[3], maxSeg), 0);
+        if (sh.counters[2] != 0) {
+            atomicOr(&v.status[f], STATUS_SEG_OVERFLOW);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_pieces_kernel(BatchView v, int lds_keys, int need_rank_of) {
+    __shared__ SortShared sh;
+    const int f = blockIdx.y;
+    const int n = v.n_cand[f];
+    if (n == 0) {
+        return;
+    }
+    const int tid = threadIdx.x;
+    int2* lists = v.seglist + static_cast<size_t>(f) * 3 * v.maxSeg;
+    const int2* ready = lists + 2 * v.maxSeg;
+    const int n_ready = lists[3 * v.maxSeg - 1].x;
+    if (static_cast<int>(blockIdx.x) >= n_ready) {
+        return;
+    }
+    uint32_t* gkeys = v.keys + static_cast<size_t>(f) * v.maxM;
+    uint32_t* out = v.sorted + static_cast<size_t>(f) * v.maxM;
+    uint32_t* rank_of = need_rank_of != 0 ? v.rank_of + static_cast<size_t>(f) * v.maxM : nullptr;
+    const uint32_t* xy = need_rank_of != 0 ? nullptr : v.cand_xy + static_cast<size_t>(f) * v.maxM;
+    uint32_t* lds = dyn_lds;
+    // leaf flags by global position: in LDS when the frame's flag words fit behind the keys, else the frame's global words
+    // (each workgroup only touches the words of its own pieces, whose end flags it sets itself; a word shared by two
+    // neighbouring pieces is updated with atomics)
+    const int nwords = (n + 32) / 32;
+    const bool flags_in_lds = nwords <= lds_keys / 32 + 2;
+    uint32_t* segbits = flags_in_lds ? lds + lds_keys : reinterpret_cast<uint32_t*>(v.segstart + static_cast<size_t>(f) * v.segstart_stride);
+    SegQueue queue;
+    queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
+    queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
+    queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
+    if (tid == 0) {
+        sh.counters[2] = 0;
+    }
+    for (int r = blockIdx.x; r < n_ready; r += gridDim.x) {
+        const int2 seg = ready[r];
+        const int first = seg.x, last = seg.y & 0xffffff;
+        // this piece's flag words: cleared between its ends, both end flags set
+        __syncthreads();
+        if (flags_in_lds) {
+            for (int w = (first >> 5) + tid; w <= (last >> 5); w += blockDim.x) {
+                segbits[w] = 0u;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                segbits[first >> 5] |= 1u << (first & 31);
+                segbits[last >> 5] |= 1u << (last & 31);
+            }
+        } else {
+            // global words are shared with the neighbours' pieces: clear only this piece's own bits (first, last), atomically
+            for (int w = (first >> 5) + tid; w <= (last >> 5); w += blockDim.x) {
+                // (the end flags themselves are shared with the neighbours, which may be reading them: never cleared)
+                uint32_t keep = 0u;
+                if (w == (first >> 5)) {
+                    keep |= static_cast<uint32_t>(low_mask((first & 31) + 1));  // bits up to `first`: the piece before, and the shared flag
+                }
+                if (w == (last >> 5)) {
+                    keep |= ~static_cast<uint32_t>(low_mask(last & 31));        // bits from `last` on: the shared flag, the piece behind
+                }
+                atomicAnd(&segbits[w], keep);
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                atomicOr(&segbits[first >> 5], 1u << (first & 31));
+                atomicOr(&segbits[last >> 5], 1u << (last & 31));
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+#ifdef SLAMX_SORT_CLOCKS
+        const unsigned long long tp0 = wall_clock64();
+#endif
+        finish_piece(gkeys, out, lds, lds_keys, segbits, nwords, queue, seg, sh, rank_of, xy);
+#ifdef SLAMX_SORT_CLOCKS
+        if (tid == 0 && f == 0 && blockIdx.x < 2) {
+            printf("  piece wg %d r %d len %d code %d: %.1f us\n", (int)blockIdx.x, r, last - first, seg.y >> 24, (wall_clock64() - tp0) * 0.01);
+        }
+#endif
+    }
+    if (tid == 0 && sh.counters[2] != 0) {
+        atomicOr(&v.status[f], STATUS_SEG_OVERFLOW);
     }
 }
 
@@ -1153,7 +1500,7 @@ void allow_big_lds(const void* fn, std::atomic<unsigned long long>& done) {
 
 void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_rank_of) {
     // Experiment switch ("environment"): SLAMX_SORT_BLOCK_MIN = smallest segment that is still
-    // partitioned by the whole workgroup (default 3072 keys).  Any value gives the same permutation;
+    // partitioned by the whole workgroup (default 4096 keys).  Any value gives the same permutation;
     // values outside [128, 65536] are ignored.  Read once, on the first launch of the process.
     static const bool once_bm = [] {
         if (const char* e = getenv("SLAMX_SORT_BLOCK_MIN")) {
@@ -1172,6 +1519,34 @@ void launch_sort(const BatchView& v, int nframes, hipStream_t stream, bool need_
     static std::atomic<unsigned long long> lds_done{0};
     allow_big_lds(reinterpret_cast<const void*>(sort_kernel), lds_done);
     const int lds_keys = lds_keys_for(v.maxM);
+    // Few frames (a call of the reference's one-frame API, configs[0]'s 50-frame job): the two-launch form, whose second
+    // kernel spreads a frame's pieces over `groups` CUs.  SLAMX_SORT_SPLIT_MAX_FRAMES: the largest launch that takes it
+    // (default 128: from two workgroups per frame on; 0 = never).  Same permutation either way.
+    static const int split_max = [] {
+        const char* e = getenv("SLAMX_SORT_SPLIT_MAX_FRAMES");
+        return e != nullptr ? atoi(e) : 128;
+    }();
+    const int groups = nframes > 0 ? std::min(16, 256 / nframes) : 1;
+    static const int split_small_env = [] {
+        const char* e = getenv("SLAMX_SORT_SPLIT_SMALL");
+        return e != nullptr && atoi(e) != 0 ? 1 : 0;
+    }();
+    // (a batch whose candidate capacity fits LDS has no frame for the second kernel: one launch then)
+    if (nframes <= split_max && groups >= 2 && (v.maxM > lds_keys || split_small_env != 0)) {
+        static std::atomic<unsigned long long> lds_done_a{0}, lds_done_b{0};
+        allow_big_lds(reinterpret_cast<const void*>(sort_split_kernel), lds_done_a);
+        allow_big_lds(reinterpret_cast<const void*>(sort_pieces_kernel), lds_done_b);
+        // SLAMX_SORT_SPLIT_SMALL=1 (experiment switch): frames that fit LDS are split into pieces too
+        static const int split_small = [] {
+            const char* e = getenv("SLAMX_SORT_SPLIT_SMALL");
+            return e != nullptr && atoi(e) != 0 ? 1 : 0;
+        }();
+        hipLaunchKernelGGL(sort_split_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys, groups,
+                           split_small, need_rank_of ? 1 : 0);
+        hipLaunchKernelGGL(sort_pieces_kernel, dim3(groups, nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys,
+                           need_rank_of ? 1 : 0);
+        return;
+    }
     hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys,
                        need_rank_of ? 1 : 0);
 }
@@ -1183,6 +1558,27 @@ void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2
     const int lds_keys = lds_keys_for(n);
     hipLaunchKernelGGL(debug_sort_kernel, dim3(1), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, keys, sorted,
                        segstart, seglist, maxSeg, n, status, lds_keys);
+}
+
+void launch_debug_sort_split(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n, int* status,
+                             int* n_cand, uint32_t* rank_of, int groups, hipStream_t stream) {
+    static std::atomic<unsigned long long> lds_done_a{0}, lds_done_b{0};
+    allow_big_lds(reinterpret_cast<const void*>(sort_split_kernel), lds_done_a);
+    allow_big_lds(reinterpret_cast<const void*>(sort_pieces_kernel), lds_done_b);
+    BatchView v{};
+    v.n_cand = n_cand;
+    v.keys = keys;
+    v.sorted = sorted;
+    v.rank_of = rank_of;
+    v.segstart = segstart;
+    v.segstart_stride = (static_cast<size_t>(n) + 32) / 32 * 4 + 8;
+    v.seglist = seglist;
+    v.maxM = n;
+    v.maxSeg = maxSeg;
+    v.status = status;
+    const int lds_keys = lds_keys_for(n);
+    hipLaunchKernelGGL(sort_split_kernel, dim3(1), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys, groups, 1, 1);
+    hipLaunchKernelGGL(sort_pieces_kernel, dim3(groups, 1), dim3(SORT_THREADS), sort_lds_bytes(lds_keys), stream, v, lds_keys, 1);
 }
 
 }  // namespace slamx

@@ -1532,9 +1532,13 @@ int slamx_gaussian_blur(slamx_detector* det, const uint8_t* img, int rows, int c
     return SLAMX_OK;
 } SLAMX_CATCH
 
-int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out) try {
-    if (n < 0 || n > MAX_CANDIDATES_HARD) {
-        return fail(SLAMX_ERR_INVALID_ARGUMENT, "n out of range");
+int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_t* perm_out) {
+    return slamx_debug_sort_desc_groups(ctx, scores, n, 1, perm_out);
+}
+
+int slamx_debug_sort_desc_groups(slamx_ctx* ctx, const uint32_t* scores, int n, int groups, uint32_t* perm_out) try {
+    if (n < 0 || n > MAX_CANDIDATES_HARD || groups < 1 || groups > 64) {
+        return fail(SLAMX_ERR_INVALID_ARGUMENT, "n / groups out of range");
     }
     if (n == 0) {
         return SLAMX_OK;
@@ -1551,8 +1555,12 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
     uint8_t* dseg = nullptr;
     int2* dlist = nullptr;
     int* dstatus = nullptr;
+    int* dn = nullptr;
+    uint32_t* drank = nullptr;
     const int maxSeg = n / 16 + 16;
     int rc = dev_alloc(&dk, n);
+    if (rc == SLAMX_OK && groups > 1) rc = dev_alloc(&dn, 1);
+    if (rc == SLAMX_OK && groups > 1) rc = dev_alloc(&drank, n);
     if (rc == SLAMX_OK) rc = dev_alloc(&ds, n);
     if (rc == SLAMX_OK) rc = dev_alloc(&dseg, (static_cast<size_t>(n) + 32) / 32 * 4 + 8);
     if (rc == SLAMX_OK) rc = dev_alloc(&dlist, static_cast<size_t>(3) * maxSeg);
@@ -1561,8 +1569,16 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
     hipError_t e = hipSuccess;
     if (rc == SLAMX_OK) {
         e = hipMemcpyAsync(dk, keys.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && groups > 1) {
+            e = hipMemcpyAsync(dn, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(dstatus, 0, sizeof(int), ctx->stream);
+        }
         if (e == hipSuccess) {
-            launch_debug_sort(dk, ds, dseg, dlist, maxSeg, n, dstatus, ctx->stream);
+            if (groups > 1) {
+                launch_debug_sort_split(dk, ds, dseg, dlist, maxSeg, n, dstatus, dn, drank, groups, ctx->stream);
+            } else {
+                launch_debug_sort(dk, ds, dseg, dlist, maxSeg, n, dstatus, ctx->stream);
+            }
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), ds, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
@@ -1574,6 +1590,8 @@ int slamx_debug_sort_desc(slamx_ctx* ctx, const uint32_t* scores, int n, uint32_
     dev_free(dseg);
     dev_free(dlist);
     dev_free(dstatus);
+    dev_free(dn);
+    dev_free(drank);
     if (rc != SLAMX_OK) {
         return rc;
     }

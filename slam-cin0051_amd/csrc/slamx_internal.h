@@ -430,6 +430,10 @@ void launch_undistort(const uint8_t* img, int rows, int cols, int pitch, const s
 
 void launch_debug_sort(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n,
                        int* status, hipStream_t stream);
+// the two-launch form of the sort (sort_split_kernel + sort_pieces_kernel) on one array: n_cand = device int holding n,
+// rank_of = n words of scratch
+void launch_debug_sort_split(uint32_t* keys, uint32_t* sorted, uint8_t* segstart, int2* seglist, int maxSeg, int n, int* status,
+                             int* n_cand, uint32_t* rank_of, int groups, hipStream_t stream);
 void launch_debug_penalty(const int* dist, const float* qx, const float* qy, const float* tx, const float* ty, int n,
                           int* out, hipStream_t stream);
 void launch_debug_trig(const float* m01, const float* m10, int n, float* deg, float* c, float* s, hipStream_t stream);

@@ -135,11 +135,14 @@ def test_fast_candidates_strided_input(det, oracle, P, slamx):
 
 # ---------------------------------------------------------------- std::sort emulation
 def _check_sort(gpu_ctx, oracle, scores):
+    """The permutation of the one-launch sort (a workgroup per frame) AND of the two-launch form that launches of few
+    frames take (round 5: the top levels in sort_split_kernel, the pieces on 2 / 16 workgroups of sort_pieces_kernel)."""
     scores = np.asarray(scores, np.uint32)
-    got = gpu_ctx.debug_sort_desc(scores)
     ref = oracle.sort_desc(scores)
-    assert np.array_equal(got, ref), "introsort permutation differs (n=%d), first at %d" % (
-        len(scores), int(np.nonzero(got != ref)[0][0]))
+    for groups in (1, 2, 16):
+        got = gpu_ctx.debug_sort_desc(scores, groups)
+        assert np.array_equal(got, ref), "introsort permutation differs (n=%d, %d group(s)), first at %d" % (
+            len(scores), groups, int(np.nonzero(got != ref)[0][0]))
 
 
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 18, 31, 32, 33, 63, 64, 65, 66, 100, 127, 128, 129, 130, 200, 255, 256,
