@@ -114,8 +114,9 @@ public:
     // fetch() waits.  The results are those of setFrame / detectAndCompute / matchConsecutive on the same frames, byte for
     // byte (tools/test_frame_batch.cpp compares them).  Must not run while an earlier call's uploads may still be reading
     // the block: call fetch() (or synchronise the context) between two sequences.
+    // chunkSizes (optional): the chunks' frame counts one by one (the last entry repeats); else chunkFrames, else automatic.
     void processSequence(const std::vector<const EigenGrayMatrix*>& images, const FeatureMatcher* matcher, bool useKeypoints = true,
-                         int firstTrainFrame = -1, int chunkFrames = 0, int copyThreads = 0) {
+                         int firstTrainFrame = -1, int chunkFrames = 0, int copyThreads = 0, const std::vector<int>& chunkSizes = {}) {
         const int n = static_cast<int>(images.size());
         if (n > m_maxFrames) {
             throw std::invalid_argument("FrameBatch::processSequence: more images than the batch has slots");
@@ -140,7 +141,22 @@ public:
         // a chunk should keep every stage busy for about the same time and leave a short fill and drain: an eighth of the
         // sequence, at least 16 frames (the sort and the NMS run one workgroup per frame: small launches are all latency)
         const int C = chunkFrames > 0 ? std::min(chunkFrames, n) : std::max(16, std::min(128, (n + 7) / 8));
-        const int nchunks = (n + C - 1) / C;
+        // chunk borders: firstOf[c] .. firstOf[c + 1]
+        std::vector<int> firstOf{0};
+        for (size_t c = 0; firstOf.back() < n; ++c) {
+            int size = C;
+            if (!chunkSizes.empty() && firstTrainFrame < 0) {
+                size = std::max(1, chunkSizes[std::min(c, chunkSizes.size() - 1)]);
+            }
+            firstOf.push_back(std::min(n, firstOf.back() + size));
+        }
+        const int nchunks = static_cast<int>(firstOf.size()) - 1;
+        std::vector<int> chunkOf(static_cast<size_t>(n));
+        for (int c = 0; c < nchunks; ++c) {
+            for (int i = firstOf[static_cast<size_t>(c)]; i < firstOf[static_cast<size_t>(c) + 1]; ++i) {
+                chunkOf[static_cast<size_t>(i)] = c;
+            }
+        }
         unsigned hw = std::thread::hardware_concurrency();
         const int T = std::max(1, std::min(copyThreads > 0 ? copyThreads : 8, static_cast<int>(hw == 0 ? 4 : hw)));
         const size_t frameBytes = static_cast<size_t>(m_rows) * m_cols;
@@ -155,7 +171,7 @@ public:
                 return false;
             }
             std::memcpy(m_frames + static_cast<size_t>(i) * frameBytes, images[static_cast<size_t>(i)]->data(), frameBytes);
-            done[static_cast<size_t>(i / C)].fetch_add(1, std::memory_order_release);
+            done[static_cast<size_t>(chunkOf[static_cast<size_t>(i)])].fetch_add(1, std::memory_order_release);
             return true;
         };
         struct Joiner {
@@ -177,8 +193,8 @@ public:
         }
         try {
             for (int c = 0; c < nchunks; ++c) {
-                const int first = c * C;
-                const int cnt = std::min(C, n - first);
+                const int first = firstOf[static_cast<size_t>(c)];
+                const int cnt = firstOf[static_cast<size_t>(c) + 1] - first;
                 while (done[static_cast<size_t>(c)].load(std::memory_order_acquire) < cnt) {
                     if (!copyOne()) {  // this thread copies too; once no frame is left it only waits for the others
                         std::this_thread::yield();

@@ -40,6 +40,10 @@ def main():
         "stats_c2_kernel_stats.csv": "bench_c2_kernel_stats.csv", "stats_c3p_kernel_stats.csv": "bench_c3p_kernel_stats.csv",
         "stats_c3_pose_kernel_stats.csv": "bench_c3_pose_kernel_stats.csv",
         "pmc_pose.csv": "pmc_pose_stage_c3_b64.csv", "pmc_c3p.csv": "pmc_instruction_mix_c3p_b64.csv",
+        "pmc_sort_c3.csv": "pmc_sort_c3_b128.csv", "facade_latency.json": "facade_latency.json",
+        "facade_latency_under_rocprof.json": "facade_latency_under_rocprof.json",
+        "stats_facade_kernel_stats.csv": "facade_latency_kernel_stats.csv",
+        "frame_batch_kitti_250.txt": "frame_batch_kitti_250.txt", "frame_batch_1080p_512.txt": "frame_batch_1080p_512.txt",
     }
     for a, b in plain.items():
         if os.path.exists(os.path.join(src, a)):

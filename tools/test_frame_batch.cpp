@@ -103,10 +103,20 @@ int main(int argc, char** argv) {
         // (experiment switches: FB_CHUNK = frames per chunk, FB_THREADS = copy threads; 0 / unset = the defaults)
         const int fb_chunk = std::getenv("FB_CHUNK") != nullptr ? std::atoi(std::getenv("FB_CHUNK")) : 0;
         const int fb_threads = std::getenv("FB_THREADS") != nullptr ? std::atoi(std::getenv("FB_THREADS")) : 0;
+        std::vector<int> fb_sizes;  // FB_SIZES=16,32,32,...: the chunks' sizes one by one (the last repeats)
+        if (const char* e = std::getenv("FB_SIZES")) {
+            for (const char* q = e; *q != 0;) {
+                fb_sizes.push_back(std::atoi(q));
+                while (*q != 0 && *q != ',') {
+                    ++q;
+                }
+                q += *q == ',' ? 1 : 0;
+            }
+        }
         double t_queued = 0.0;
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < 6; ++pass) {
             t0 = std::chrono::steady_clock::now();
-            batch.processSequence(seq, &matcher, true, -1, fb_chunk, fb_threads);
+            batch.processSequence(seq, &matcher, true, -1, fb_chunk, fb_threads, fb_sizes);
             const double tq = seconds_since(t0);
             batch.fetch(n);
             const double t = seconds_since(t0);
