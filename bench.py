@@ -166,7 +166,7 @@ def pmc_traffic_bytes(kernel, batch):
     # a STORED figure (profiles/README.md): the newest round's counter file that names the kernel, not a measurement of this run
     scale = batch / 256.0
     name = kernel.split("<")[0]
-    for r in (4, 3, 2):
+    for r in (5, 4, 3, 2):
         path = os.path.join(ROOT, "profiles", "r0%d_pmc_hbm_traffic_b256.csv" % r)
         if not os.path.exists(path):
             continue
