@@ -34,6 +34,7 @@ for i in $(seq 0 $(( ${POSE_LEGS:-8} - 1 ))); do run_leg pose fuzz_pose.py 250 $
 for i in $(seq 0 $(( ${PYR_LEGS:-10} - 1 ))); do run_leg pyr fuzz_pyramid.py 400 $(( ${PYR0:-500} + i )) 300 40; done
 for i in $(seq 0 $(( ${BAT_LEGS:-5} - 1 ))); do run_leg batch fuzz_batch.py 400 $(( ${BAT0:-600} + i )) 300 60; done
 for i in $(seq 0 $(( ${GN_LEGS:-2} - 1 ))); do run_leg gn fuzz_gn.py 300 $(( ${GN0:-700} + i )) 300 60; done
+for i in $(seq 0 $(( ${SORT_LEGS:-3} - 1 ))); do run_leg sort fuzz_sort.py 600 $(( ${SORT0:-800} + i )) 300 60; done
 echo "campaign: $(( $(date +%s) - t_start )) s of $budget;" $(for k in "${!done_cases[@]}"; do echo -n " $k: ${done_cases[$k]} cases identical;"; done)
 [ -n "$skipped" ] && echo "not started (budget):$skipped"
 exit 0

@@ -3,7 +3,7 @@ fuzzers found three bugs no parity test saw -- one a GPU memory fault reachable 
 hand-started campaigns.  Each test runs one fuzzer's own case generator and checks (random shapes, thresholds, arc lengths,
 PatchSize / NumBRIEFPairs / suppression windows / strided views for the detector; set sizes, widths, live bits, duplicate
 clusters, keypoint layouts and both scans for the matcher; mixed batches; pyramids; pose scenes incl. both geometry modes;
-Gauss-Newton windows) against the oracle with FIXED seeds and case counts sized for about a minute in total.  The long
+Gauss-Newton windows; the exact sort in its one- and two-launch forms) against the oracle with FIXED seeds and case counts sized for about a minute in total.  The long
 campaigns stay in tests/fuzz/campaign.sh."""
 import importlib
 import os
@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     ("fuzz_pyramid", 40, 9004),
     ("fuzz_pose", 30, 9005),
     ("fuzz_gn", 20, 9006),
+    ("fuzz_sort", 150, 9007),
 ])
 def test_fuzz_smoke(name, cases, seed, capsys):
     mod = importlib.import_module(name)
