@@ -148,6 +148,50 @@ def test_preprocessing_program(slamx, oracle, ref_data, tmp_path):
     assert p.returncode != 0 and b"Number of timestamps does not match" in p.stderr
 
 
+@pytest.mark.parametrize("colour", ["mono", "420jpeg", "444"])
+def test_preprocessing_program_on_an_uncompressed_video(slamx, oracle, ref_data, tmp_path, colour):
+    """The video branch of slam::Preprocessor (preprocessor.cpp:84-93, :124-131): cv::VideoCapture in the reference; this
+    build reads the one container that needs no codec, uncompressed YUV4MPEG2 -- frame k = the k-th luma plane, found by
+    seeking as the reference seeks, its position k / frame rate in whole milliseconds -- and refuses every other file with the
+    reference's message for a capture that cannot be opened."""
+    names = ["0000000000.png", "0000000001.png", "0000000002.png"]
+    imgs = [load_gray(os.path.join(ref_data, "images", n)) for n in names]
+    rows, cols = imgs[0].shape
+    video = tmp_path / "sequence.y4m"
+    with open(video, "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d F30000:1001 Ip A1:1 C%s XYSCSS=%s\n" % (cols, rows, colour, colour.upper())).encode())
+        for k, img in enumerate(imgs):
+            f.write(b"FRAME\n")
+            f.write(img.tobytes())
+            if colour.startswith("420"):
+                f.write(bytes([100 + k]) * (2 * ((rows + 1) // 2) * ((cols + 1) // 2)))
+            elif colour == "444":
+                f.write(bytes([100 + k]) * (2 * rows * cols))
+    cam_yml = os.path.join(ref_data, "camera.yml")
+    cam = slamx.load_camera(cam_yml)
+    text = _run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]), str(video), "3"])
+    lines = [l for l in text.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 3
+    for k, img in enumerate(imgs):
+        ref = oracle.undistort(img, cam)
+        fields = lines[k].split()
+        assert int(fields[2]) == rows and int(fields[4]) == cols
+        assert abs(float(fields[8]) - ref.sum()) < 1e-9 * ref.sum()
+        assert int(fields[6]) == int(1000.0 * k * 1001 / 30000)
+    # a fourth yield is past the end; a file that is no YUV4MPEG2 stream cannot be opened, as in the reference without a codec
+    p = subprocess.run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]), str(video), "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"No frames yielded" in p.stderr
+    p = subprocess.run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]),
+                        os.path.join(ref_data, "images", names[1]), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"Could not open video file" in p.stderr
+    if colour == "mono":
+        cut = tmp_path / "cut.y4m"
+        cut.write_bytes(open(video, "rb").read()[:-1000])  # the last frame cut short: two whole frames remain
+        text = _run([os.path.join(BIN, "test_preprocessing"), cam_yml, os.path.join(ref_data, "images", names[0]), str(cut), "2"])
+        assert len([l for l in text.splitlines() if l.startswith("frame ")]) == 2
+
+
 @pytest.mark.parametrize("min_matches", [20, 4])
 def test_loop_closure_program(slamx, ref_data, tmp_path, min_matches):
     """slam::LoopClosure (facade) on the reference's loop-test images, replayed step by step through
