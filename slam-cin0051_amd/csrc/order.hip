@@ -118,6 +118,11 @@ struct SortShared {
 #ifdef SLAMX_SORT_CLOCKS
     unsigned long long stamp[16];  // development: wall_clock64() (100 MHz) at phase borders, printed by the kernel
     int n_stamp;
+    // ... and a timeline of the queue phase: per wave up to 80 entries {start, end (s_memtime cycles since the phase began),
+    // keys | kind << 24} (kind 0 = wave partition, 1 = register solver, 2 = waiting for a segment), printed after the sort
+    unsigned int tl_a[16][80], tl_b[16][80], tl_c[16][80];
+    int tl_n[16];
+    unsigned long long tl_t0;
 #endif
 };
 
@@ -860,13 +865,36 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
 #endif
     bool have = false;
     int first = 0, last = 0, dep = 0;
+#ifdef SLAMX_SORT_CLOCKS
+    if (tid == 0) {
+        sh.tl_t0 = clock64();
+    }
+    if (lane == 0) {
+        sh.tl_n[wave] = 0;
+    }
+    __syncthreads();
+    auto tl_log = [&](unsigned long long t_start, int keys, int kind) {
+        if (lane == 0 && sh.tl_n[wave] < 80) {
+            const int e = sh.tl_n[wave]++;
+            sh.tl_a[wave][e] = static_cast<unsigned int>(t_start - sh.tl_t0);
+            sh.tl_b[wave][e] = static_cast<unsigned int>(clock64() - sh.tl_t0);
+            sh.tl_c[wave][e] = static_cast<unsigned int>(keys) | (static_cast<unsigned int>(kind) << 24);
+        }
+    };
+#endif
     while (true) {
         if (!have) {
             int got = 0;
             int2 item = make_int2(0, 0);
+#ifdef SLAMX_SORT_CLOCKS
+            const unsigned long long t_wait = clock64();
+#endif
             if (lane == 0) {
                 got = seg_pop(q, sh, &item) ? 1 : 0;
             }
+#ifdef SLAMX_SORT_CLOCKS
+            tl_log(t_wait, 0, 2);
+#endif
             if (__builtin_amdgcn_readfirstlane(got) == 0) {
                 break;
             }
@@ -888,8 +916,14 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
                 emit_piece(first, last, PIECE_SORTED);
             }
         } else if (!SPLIT && last - first <= 64) {
+#ifdef SLAMX_SORT_CLOCKS
+            const unsigned long long t_small = clock64();
+#endif
 #ifndef SLAMX_EXP_SKIP_SMALL
             wave_small_introsort(a, first, last, dep, lane, sh.sel[wave], segbits, bit_base);
+#endif
+#ifdef SLAMX_SORT_CLOCKS
+            tl_log(t_small, last - first, 1);
 #endif
         } else {
 #ifdef SLAMX_SORT_CLOCKS
@@ -899,9 +933,7 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
                                 ? wave_partition_cf(a, reinterpret_cast<uint16_t*>(a + scr_lds_word) + first, first, last, lane)
                                 : wave_partition_cf(a, scr16 + first, first, last, lane);
 #ifdef SLAMX_SORT_CLOCKS
-            if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && last - first > 300) {
-                printf("    wave %d partition of %d keys: %llu cycles (cut at %d)\n", wave, last - first, clock64() - tw0, cut - first);
-            }
+            tl_log(tw0, last - first, 0);
 #endif
             const int size_l = cut - first;
             const int size_r = last - cut;
@@ -949,6 +981,25 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SLAMX_SORT_CLOCKS
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && len > 8000) {
+        const unsigned int t_end = static_cast<unsigned int>(clock64() - sh.tl_t0);
+        printf("queue phase of %d keys: %u cycles\n", len, t_end);
+        for (int w = 0; w < 16; ++w) {
+            unsigned int busy_p = 0, busy_s = 0, idle = 0;
+            for (int e = 0; e < sh.tl_n[w]; ++e) {
+                const unsigned int d = sh.tl_b[w][e] - sh.tl_a[w][e];
+                const unsigned int kind = sh.tl_c[w][e] >> 24;
+                (kind == 0 ? busy_p : kind == 1 ? busy_s : idle) += d;
+            }
+            printf("  wave %2d: %2d entries, partitions %6u small %6u waiting %6u cycles;", w, sh.tl_n[w], busy_p, busy_s, idle);
+            for (int e = 0; e < sh.tl_n[w] && e < 14; ++e) {
+                printf(" %c%u@%u+%u", "PSW"[sh.tl_c[w][e] >> 24], sh.tl_c[w][e] & 0xffffffu, sh.tl_a[w][e], sh.tl_b[w][e] - sh.tl_a[w][e]);
+            }
+            printf("\n");
+        }
+    }
+#endif
 }
 
 // One piece {first, last | code << 24} of a frame's keys: load it into LDS, run its introsort levels there, and
