@@ -118,10 +118,12 @@ struct SortShared {
 #ifdef SLAMX_SORT_CLOCKS
     unsigned long long stamp[16];  // development: wall_clock64() (100 MHz) at phase borders, printed by the kernel
     int n_stamp;
-    // ... and a timeline of the queue phase: per wave up to 80 entries {start, end (s_memtime cycles since the phase began),
+    // ... and a timeline of the queue phase: per wave up to 40 entries {start, end (s_memtime cycles since the phase began),
     // keys | kind << 24} (kind 0 = wave partition, 1 = register solver, 2 = waiting for a segment), printed after the sort
-    unsigned int tl_a[16][80], tl_b[16][80], tl_c[16][80];
+    unsigned int tl_a[16][40], tl_b[16][40], tl_c[16][40];
     int tl_n[16];
+    unsigned int tl_bucket[16][3][24];  // cycles per wave, kind and 16384-cycle bucket of the START of an entry (all entries)
+    unsigned int tl_calls[16][3];
     unsigned long long tl_t0;
 #endif
 };
@@ -131,6 +133,9 @@ __device__ __forceinline__ int rank_below(unsigned long long m) {  // set bits o
                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
 }
 
+#ifdef SLAMX_SORT_PASS_CLOCKS
+__device__ unsigned long long wp_acc[8];  // wave partitions of >= 1024 keys: cycles of pivot / pass 1 / 2 / 3, keys, calls, swaps
+#endif
 // ---------------- one wave: pivot + Hoare partition, closed form ----------------
 // The same rule as block_partition evaluated by a single wave over its whole segment: no step
 // depends on an LDS result of the previous one (only on running counts), so the chunk loads
@@ -139,6 +144,9 @@ __device__ __forceinline__ int rank_below(unsigned long long m) {  // set bits o
 __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last, int lane) {
     first = __builtin_amdgcn_readfirstlane(first);  // (wave-uniform by construction; said once so that the loop counters
     last = __builtin_amdgcn_readfirstlane(last);    //  and the regime tests below stay on the scalar unit)
+#ifdef SLAMX_SORT_PASS_CLOCKS
+    const unsigned long long wp_t0 = clock64();
+#endif
     const int ia = first + 1;
     const int ib = first + (last - first) / 2;
     const int ic = last - 1;
@@ -176,6 +184,9 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
     // pass 1: number of right stoppers.  Chunks are read four at a time so that the LDS latency is paid once per 256
     // keys; whole groups need neither clamped addresses nor range masks.
     constexpr int U = 4;
+#ifdef SLAMX_SORT_PASS_CLOCKS
+    const unsigned long long wp_t1 = clock64();
+#endif
     int nr = 0;
     int base1 = lo;
     const int ngroups = n / (64 * U);  // whole groups of U chunks
@@ -207,6 +218,9 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
     // of the R stoppers: a chunk is (a) before the crossing -- every L stopper of it is swapped, no R stopper is --, (b)
     // behind it -- the reverse -- or (c) at the crossing, and which one the chunk's stopper counts tell (wave-uniform).
     // Only (c), a chunk or two per partition, needs the per-lane swap rule (round 5: until then every chunk paid for it).
+#ifdef SLAMX_SORT_PASS_CLOCKS
+    const unsigned long long wp_t2 = clock64();
+#endif
     uint16_t* lpos = scr;
     uint16_t* rpos = scr + n / 2;
     int run_l = 0, run_r = 0, K = 0;
@@ -282,6 +296,9 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
         }
     }
     wave_mem_fence();
+#ifdef SLAMX_SORT_PASS_CLOCKS
+    const unsigned long long wp_t3 = clock64();
+#endif
     // the lowest swapped R stopper is the one with K - 1 R stoppers to its right
     // (every lane reads the same entry: made a scalar again, or the caller's first / last would turn into vector values)
     const int cut_r = K > 0 ? first + __builtin_amdgcn_readfirstlane(static_cast<int>(rpos[K - 1])) : 0x7fffffff;
@@ -295,6 +312,18 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
         a[j] = vi;
     }
     wave_mem_fence();
+#ifdef SLAMX_SORT_PASS_CLOCKS  // (with SLAMX_SORT_CLOCKS; the atomics disturb the timeline of a full batch: lone frames only)
+    if (lane == 0 && n >= 1024) {
+        const unsigned long long wp_t4 = clock64();
+        atomicAdd(&wp_acc[0], wp_t1 - wp_t0);
+        atomicAdd(&wp_acc[1], wp_t2 - wp_t1);
+        atomicAdd(&wp_acc[2], wp_t3 - wp_t2);
+        atomicAdd(&wp_acc[3], wp_t4 - wp_t3);
+        atomicAdd(&wp_acc[4], static_cast<unsigned long long>(n));
+        atomicAdd(&wp_acc[5], 1ull);
+        atomicAdd(&wp_acc[6], static_cast<unsigned long long>(K));
+    }
+#endif
     return min(cut_l, cut_r);
 }
 
@@ -871,10 +900,23 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
     }
     if (lane == 0) {
         sh.tl_n[wave] = 0;
+        for (int k = 0; k < 3; ++k) {
+            sh.tl_calls[wave][k] = 0;
+            for (int bk = 0; bk < 24; ++bk) {
+                sh.tl_bucket[wave][k][bk] = 0;
+            }
+        }
     }
     __syncthreads();
     auto tl_log = [&](unsigned long long t_start, int keys, int kind) {
-        if (lane == 0 && sh.tl_n[wave] < 80) {
+        if (lane == 0) {
+            const unsigned int ts = static_cast<unsigned int>(t_start - sh.tl_t0);
+            const unsigned int te = static_cast<unsigned int>(clock64() - sh.tl_t0);
+            const unsigned int bk = ts >> 14;
+            sh.tl_bucket[wave][kind][bk < 24 ? bk : 23] += te - ts;
+            sh.tl_calls[wave][kind]++;
+        }
+        if (lane == 0 && sh.tl_n[wave] < 40) {
             const int e = sh.tl_n[wave]++;
             sh.tl_a[wave][e] = static_cast<unsigned int>(t_start - sh.tl_t0);
             sh.tl_b[wave][e] = static_cast<unsigned int>(clock64() - sh.tl_t0);
@@ -985,6 +1027,18 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && len > 8000) {
         const unsigned int t_end = static_cast<unsigned int>(clock64() - sh.tl_t0);
         printf("queue phase of %d keys: %u cycles\n", len, t_end);
+#ifdef SLAMX_SORT_PASS_CLOCKS
+        printf("wave partitions >= 1024 keys so far: %llu calls, %llu keys, %llu swaps; cycles pivot %llu pass1 %llu pass2 %llu pass3 %llu\n",
+               wp_acc[5], wp_acc[4], wp_acc[6], wp_acc[0], wp_acc[1], wp_acc[2], wp_acc[3]);
+#endif
+        // cycles per wave in partitions / register solver / waiting, by 16384-cycle bucket of the entry's start (>> 10)
+        for (int w = 0; w < 16; ++w) {
+            printf("  buckets wave %2d (calls P %u S %u W %u):", w, sh.tl_calls[w][0], sh.tl_calls[w][1], sh.tl_calls[w][2]);
+            for (int bk = 0; bk < 24; ++bk) {
+                printf(" %u/%u/%u", sh.tl_bucket[w][0][bk] >> 10, sh.tl_bucket[w][1][bk] >> 10, sh.tl_bucket[w][2][bk] >> 10);
+            }
+            printf("\n");
+        }
         for (int w = 0; w < 16; ++w) {
             unsigned int busy_p = 0, busy_s = 0, idle = 0;
             for (int e = 0; e < sh.tl_n[w]; ++e) {

@@ -1,0 +1,89 @@
+// development microbenchmark: one wave's Hoare partition (order.hip: wave_partition_cf) on an otherwise idle CU, variants side by side
+#include "../../slam-cin0051_amd/csrc/order.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+
+namespace slamx {
+namespace {
+#include "wp_variants.inc"
+
+__global__ __launch_bounds__(64) void wp_bench_kernel(const uint32_t* keys, int n, int variant, int reps, unsigned long long* cycles,
+                                                      uint32_t* out_keys, int* out_cut) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint16_t* scr = reinterpret_cast<uint16_t*>(lds + ((n + 3) & ~3));
+    unsigned long long best = ~0ull;
+    int cut = 0;
+    for (int r = 0; r < reps; ++r) {
+        for (int i = lane; i < n; i += 64) {
+            lds[i] = keys[i];
+        }
+        wave_mem_fence();
+        const unsigned long long t0 = clock64();
+        if (variant == 0) {
+            cut = wave_partition_cf(lds, scr, 0, n, lane);
+        } else if (variant == 1) {
+            cut = wave_partition_v1(lds, scr, 0, n, lane);
+        } else if (variant == 2) {
+            cut = wave_partition_v2(lds, scr, 0, n, lane);
+        } else if (variant == 3) {
+            cut = wave_partition_v3(lds, scr, 0, n, lane);
+        } else if (variant == 4) {
+            cut = wave_partition_v3s(lds, scr, 0, n, lane);
+        } else if (variant == 5) {
+            cut = wave_partition_v5(lds, scr, 0, n, lane);
+        } else {
+            cut = wave_partition_v6(lds, scr, 0, n, lane);
+        }
+        const unsigned long long t1 = clock64();
+        best = t1 - t0 < best ? t1 - t0 : best;
+    }
+    for (int i = lane; i < n; i += 64) {
+        out_keys[i] = lds[i];
+    }
+    if (lane == 0) {
+        *cycles = best;
+        *out_cut = cut;
+    }
+}
+}  // namespace
+}  // namespace slamx
+
+int main() {
+    using namespace slamx;
+    const int sizes[] = {200, 368, 700, 1500, 3103, 6000, 12000};
+    uint32_t* d_keys; uint32_t* d_out; unsigned long long* d_cyc; int* d_cut;
+    hipMalloc(&d_keys, 16384 * 4); hipMalloc(&d_out, 16384 * 4); hipMalloc(&d_cyc, 8); hipMalloc(&d_cut, 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wp_bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120000);
+    for (int dist = 0; dist < 3; ++dist) {
+        for (int n : sizes) {
+            std::mt19937 rng(1234 + n);
+            std::vector<uint32_t> h(n);
+            for (int i = 0; i < n; ++i) {
+                // dist 0: FAST-like scores, many ties (geometric-ish); 1: uniform wide; 2: all equal
+                uint32_t sc = dist == 0 ? 20 + (rng() % 8) * (rng() % 8) : dist == 1 ? rng() % 4000 : 77;
+                h[i] = (sc << SCORE_SHIFT) | static_cast<uint32_t>(i);
+            }
+            hipMemcpy(d_keys, h.data(), n * 4, hipMemcpyHostToDevice);
+            std::vector<uint32_t> ref;
+            int ref_cut = 0;
+            printf("dist %d n %5d:", dist, n);
+            for (int variant = 0; variant < 7; ++variant) {
+                const size_t lds_bytes = ((n + 3) & ~3) * 4 + (n + 80) * 2;
+                hipLaunchKernelGGL(wp_bench_kernel, dim3(1), dim3(64), lds_bytes, 0, d_keys, n, variant, 5, d_cyc, d_out, d_cut);
+                if (hipDeviceSynchronize() != hipSuccess) { printf(" launch failed\n"); return 1; }
+                unsigned long long cyc; int cut; std::vector<uint32_t> o(n);
+                hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&cut, d_cut, 4, hipMemcpyDeviceToHost);
+                hipMemcpy(o.data(), d_out, n * 4, hipMemcpyDeviceToHost);
+                if (variant == 0) { ref = o; ref_cut = cut; }
+                const bool same = o == ref && cut == ref_cut;
+                printf(" v%d %6llu %.2f%s", variant, cyc, double(cyc) / n, same ? "" : " DIFFERENT");
+            }
+            unsigned long long st[8];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(wp_stamps), sizeof(st));
+            printf("  cut %d | pivot %llu p1 %llu p2 %llu p3 %llu\n", ref_cut, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+        }
+    }
+    return 0;
+}
