@@ -114,7 +114,8 @@ struct SortShared {
     int2 big[2][32];  // large segments of the current / next level (n <= 16384 keys => at most 8)
     int n_big[2];
     int q_head, q_tail, q_pending;  // segment work queue (see SegQueue)
-    uint8_t sel[16][2][64];  // per wave (wave_small_introsort): lane of the k-th swapped L / R stopper of a range
+    uint8_t sel[16][2][128];  // per wave: lane (wave_small_introsort) or position (wave_partition_small) of the k-th swapped
+                              // L / R stopper of a range
 #ifdef SLAMX_SORT_CLOCKS
     unsigned long long stamp[16];  // development: wall_clock64() (100 MHz) at phase borders, printed by the kernel
     int n_stamp;
@@ -327,13 +328,172 @@ __device__ int wave_partition_cf(uint32_t* a, uint16_t* scr, int first, int last
     return min(cut_l, cut_r);
 }
 
+
+// ---------------- one wave: pivot + Hoare partition of a segment of 65 .. 257 keys, from registers ----------------
+// Most partition calls of a frame are this small (about 300 of 380 at 14.5k keys), and what they cost wave_partition_cf is
+// fixed: two passes over at most four chunks through the general loops, their tails and branches, a list read for the cut.
+// Here the four chunks are read ONCE, together with the median candidates (one LDS latency); the pivot swap is patched into
+// the registers; pass 1's stopper counts are the popcounts of the ballots pass 2 needs anyway; the per-lane swap rule (case (c)
+// of wave_partition_cf, valid for any chunk) is evaluated for the four chunks without a branch; the list stores go out under
+// the swap masks themselves; the first unswapped L stopper and the lowest swapped R stopper are read off those masks.  The
+// lists are bytes (position - first - 1 < 256) in the wave's own scratch, whatever memory the caller's 16-bit lists live in.
+// Same swaps, same cut as wave_partition_cf (tools/dev/wp_bench compares the two key by key for every length).
+template <int NC>
+__device__ __forceinline__ void masked_store_u8(const uint32_t (&addr)[4], const uint32_t (&val)[4], const unsigned long long (&mask)[4]) {
+    // store u < NC under the lanes of mask[u]: exec is set from the masks directly (the compiler's only form for a store under
+    // a ballot is a compare, a saved exec and a branch around the store)
+    unsigned long long saved;
+    if (NC == 2) {
+        asm volatile(
+            "s_mov_b64 %0, exec\n\t"
+            "s_mov_b64 exec, %5\n\tds_write_b8 %1, %3\n\t"
+            "s_mov_b64 exec, %6\n\tds_write_b8 %2, %4\n\t"
+            "s_mov_b64 exec, %0"
+            : "=&s"(saved)
+            : "v"(addr[0]), "v"(addr[1]), "v"(val[0]), "v"(val[1]), "s"(mask[0]), "s"(mask[1])
+            : "memory");
+    } else if (NC == 3) {
+        asm volatile(
+            "s_mov_b64 %0, exec\n\t"
+            "s_mov_b64 exec, %7\n\tds_write_b8 %1, %4\n\t"
+            "s_mov_b64 exec, %8\n\tds_write_b8 %2, %5\n\t"
+            "s_mov_b64 exec, %9\n\tds_write_b8 %3, %6\n\t"
+            "s_mov_b64 exec, %0"
+            : "=&s"(saved)
+            : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2])
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b64 %0, exec\n\t"
+            "s_mov_b64 exec, %9\n\tds_write_b8 %1, %5\n\t"
+            "s_mov_b64 exec, %10\n\tds_write_b8 %2, %6\n\t"
+            "s_mov_b64 exec, %11\n\tds_write_b8 %3, %7\n\t"
+            "s_mov_b64 exec, %12\n\tds_write_b8 %4, %8\n\t"
+            "s_mov_b64 exec, %0"
+            : "=&s"(saved)
+            : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "s"(mask[0]),
+              "s"(mask[1]), "s"(mask[2]), "s"(mask[3])
+            : "memory");
+    }
+}
+
+template <int NC>  // chunks of 64 keys behind the pivot: n <= 64 NC
+__device__ int wave_partition_small(uint32_t* a, uint8_t (*sel)[128], int first, int last, int lane) {
+    first = __builtin_amdgcn_readfirstlane(first);
+    last = __builtin_amdgcn_readfirstlane(last);
+    const int lo = first + 1;
+    const int hi = last;
+    const int n = hi - lo;  // <= 64 NC
+    // __move_median_to_first(first, first+1, mid, last-1), and the chunks in the same round trip
+    const int ia = first + 1;
+    const int ib = first + (last - first) / 2;
+    const int ic = last - 1;
+    const uint32_t vf = a[first];
+    const uint32_t va = a[ia];
+    const uint32_t vb = a[ib];
+    const uint32_t vc = a[ic];
+    uint32_t k[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        k[u] = a[min(lo + u * 64 + lane, hi - 1)];
+    }
+    int im;
+    uint32_t vm;
+    if (comp(va, vb)) {
+        if (comp(vb, vc)) {
+            im = ib, vm = vb;
+        } else if (comp(va, vc)) {
+            im = ic, vm = vc;
+        } else {
+            im = ia, vm = va;
+        }
+    } else if (comp(va, vc)) {
+        im = ia, vm = va;
+    } else if (comp(vb, vc)) {
+        im = ic, vm = vc;
+    } else {
+        im = ib, vm = vb;
+    }
+    im = __builtin_amdgcn_readfirstlane(im);
+    wave_mem_fence();
+    if (lane == 0) {
+        a[first] = vm;
+        a[im] = vf;
+    }
+    // (the registers were read before that swap: position im now holds the old first key)
+    const int rel_m = im - lo;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        if ((rel_m >> 6) == u && (rel_m & 63) == lane) {
+            k[u] = vf;
+        }
+    }
+    const uint32_t p = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(score_of(vm))));
+    unsigned long long ml[NC], mr[NC];
+    int cl[NC], cr[NC];
+    int nr = 0;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const unsigned long long m_in = low_mask(min(64, max(0, n - 64 * u)));
+        ml[u] = __ballot(score_of(k[u]) <= p) & m_in;
+        mr[u] = __ballot(score_of(k[u]) >= p) & m_in;
+        cl[u] = __popcll(ml[u]);
+        cr[u] = __popcll(mr[u]);
+        nr += cr[u];
+    }
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t lpos_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)sel[0]));
+    const uint32_t rpos_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)sel[1]));
+    unsigned long long sl[4] = {}, sr[4] = {};
+    uint32_t al[4] = {}, ar[4] = {}, val[4] = {};
+    int run_l = 0, rem = nr, K = 0;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const bool is_r = score_of(k[u]) >= p;
+        const int l_left = run_l + rank_below(ml[u]);                 // L stoppers left of i
+        const int r_right = rem - rank_below(mr[u]) - (is_r ? 1 : 0);  // R stoppers right of i
+        sl[u] = ml[u] & __ballot(r_right > l_left);
+        sr[u] = mr[u] & __ballot(l_left > r_right);
+        al[u] = lpos_lds + static_cast<uint32_t>(l_left);
+        ar[u] = rpos_lds + static_cast<uint32_t>(r_right);
+        val[u] = static_cast<uint32_t>(u * 64 + lane);  // i - lo
+        run_l += cl[u];
+        rem -= cr[u];
+        K += __popcll(sl[u]);
+    }
+    masked_store_u8<NC>(al, val, sl);
+    masked_store_u8<NC>(ar, val, sr);
+    int cut_l = 0x7fffffff, cut_r = 0x7fffffff;
+#pragma unroll
+    for (int u = NC - 1; u >= 0; --u) {
+        const unsigned long long stay = ml[u] & ~sl[u];
+        if (stay != 0) {
+            cut_l = lo + u * 64 + __ffsll(static_cast<long long>(stay)) - 1;
+        }
+        if (sr[u] != 0) {
+            cut_r = lo + u * 64 + __ffsll(static_cast<long long>(sr[u])) - 1;
+        }
+    }
+    // exchange the K <= 128 pairs
+    for (int kk = lane; kk < K; kk += 64) {
+        const int i = lo + sel[0][kk];
+        const int j = lo + sel[1][kk];
+        const uint32_t vi = a[i];
+        const uint32_t vj = a[j];
+        a[i] = vj;
+        a[j] = vi;
+    }
+    wave_mem_fence();
+    return min(cut_l, cut_r);
+}
+
 // ---------------- one wave: a segment of at most 64 elements, all its remaining levels ----------------
 // Lane i holds element first+i in a register; the sub-segments of a level are disjoint lane ranges
 // and advance together (median of three by shuffles, stopper ranks by ballots restricted to the
 // lane's own range, the closed-form swap rule of block_partition, partners found through the
 // wave's LDS rank scratch).  Replaces one wave_partition call per sub-segment -- thousands of
 // nearly empty waves at the deep levels -- by ~4 short steps per 64 elements.
-__device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth, int lane, uint8_t (*sel)[64],
+__device__ void wave_small_introsort(uint32_t* a, int first, int last, int depth, int lane, uint8_t (*sel)[128],
                                      uint32_t* segbits, int bit_base) {
     const int m = last - first;  // 17 .. 64
     uint32_t v = lane < m ? a[first + lane] : 0u;
@@ -971,7 +1131,10 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
 #ifdef SLAMX_SORT_CLOCKS
             const unsigned long long tw0 = clock64();
 #endif
-            const int cut = scr_lds_word >= 0
+            const int cut = last - first <= 129   ? wave_partition_small<2>(a, sh.sel[wave], first, last, lane)
+                            : last - first <= 193 ? wave_partition_small<3>(a, sh.sel[wave], first, last, lane)
+                            : last - first <= 257 ? wave_partition_small<4>(a, sh.sel[wave], first, last, lane)
+                            : scr_lds_word >= 0
                                 ? wave_partition_cf(a, reinterpret_cast<uint16_t*>(a + scr_lds_word) + first, first, last, lane)
                                 : wave_partition_cf(a, scr16 + first, first, last, lane);
 #ifdef SLAMX_SORT_CLOCKS

@@ -33,8 +33,12 @@ __global__ __launch_bounds__(64) void wp_bench_kernel(const uint32_t* keys, int 
             cut = wave_partition_v3s(lds, scr, 0, n, lane);
         } else if (variant == 5) {
             cut = wave_partition_v5(lds, scr, 0, n, lane);
-        } else {
+        } else if (variant == 6) {
             cut = wave_partition_v6(lds, scr, 0, n, lane);
+        } else if (variant == 7) {
+            cut = wave_partition_v7(lds, scr, 0, n, lane);
+        } else {
+            cut = wave_partition_v8(lds, scr, 0, n, lane);
         }
         const unsigned long long t1 = clock64();
         best = t1 - t0 < best ? t1 - t0 : best;
@@ -50,27 +54,34 @@ __global__ __launch_bounds__(64) void wp_bench_kernel(const uint32_t* keys, int 
 }  // namespace
 }  // namespace slamx
 
-int main() {
+int main(int argc, char** argv) {
     using namespace slamx;
-    const int sizes[] = {200, 368, 700, 1500, 3103, 6000, 12000};
+    const bool sweep = argc > 1;
+    std::vector<int> sizes = {200, 368, 700, 1500, 3103, 6000, 12000};
+    if (sweep) {
+        sizes.clear();
+        for (int n = 18; n <= 300; ++n) sizes.push_back(n);
+        for (int n = 301; n <= 1100; n += 7) sizes.push_back(n);
+    }
     uint32_t* d_keys; uint32_t* d_out; unsigned long long* d_cyc; int* d_cut;
     hipMalloc(&d_keys, 16384 * 4); hipMalloc(&d_out, 16384 * 4); hipMalloc(&d_cyc, 8); hipMalloc(&d_cut, 4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wp_bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120000);
-    for (int dist = 0; dist < 3; ++dist) {
+    int bad = 0;
+    for (int dist = 0; dist < (sweep ? 5 : 3); ++dist) {
         for (int n : sizes) {
             std::mt19937 rng(1234 + n);
             std::vector<uint32_t> h(n);
             for (int i = 0; i < n; ++i) {
                 // dist 0: FAST-like scores, many ties (geometric-ish); 1: uniform wide; 2: all equal
-                uint32_t sc = dist == 0 ? 20 + (rng() % 8) * (rng() % 8) : dist == 1 ? rng() % 4000 : 77;
+                uint32_t sc = dist == 0 ? 20 + (rng() % 8) * (rng() % 8) : dist == 1 ? rng() % 4000 : dist == 2 ? 77 : dist == 3 ? 50 + rng() % 2 : (i * 37) % 101;
                 h[i] = (sc << SCORE_SHIFT) | static_cast<uint32_t>(i);
             }
             hipMemcpy(d_keys, h.data(), n * 4, hipMemcpyHostToDevice);
             std::vector<uint32_t> ref;
             int ref_cut = 0;
-            printf("dist %d n %5d:", dist, n);
-            for (int variant = 0; variant < 7; ++variant) {
-                const size_t lds_bytes = ((n + 3) & ~3) * 4 + (n + 80) * 2;
+            if (!sweep) printf("dist %d n %5d:", dist, n);
+            for (int variant = 0; variant < 9; ++variant) {
+                const size_t lds_bytes = ((n + 3) & ~3) * 4 + (n + 80) * 2 + 256;
                 hipLaunchKernelGGL(wp_bench_kernel, dim3(1), dim3(64), lds_bytes, 0, d_keys, n, variant, 5, d_cyc, d_out, d_cut);
                 if (hipDeviceSynchronize() != hipSuccess) { printf(" launch failed\n"); return 1; }
                 unsigned long long cyc; int cut; std::vector<uint32_t> o(n);
@@ -78,12 +89,15 @@ int main() {
                 hipMemcpy(o.data(), d_out, n * 4, hipMemcpyDeviceToHost);
                 if (variant == 0) { ref = o; ref_cut = cut; }
                 const bool same = o == ref && cut == ref_cut;
-                printf(" v%d %6llu %.2f%s", variant, cyc, double(cyc) / n, same ? "" : " DIFFERENT");
+                if (!sweep) printf(" v%d %6llu %.2f%s", variant, cyc, double(cyc) / n, same ? "" : " DIFFERENT");
+                if (!same) { bad++; if (sweep) printf("DIFFERENT dist %d n %d variant %d cut %d ref %d\n", dist, n, variant, cut, ref_cut); }
             }
+            if (sweep) continue;
             unsigned long long st[8];
             hipMemcpyFromSymbol(st, HIP_SYMBOL(wp_stamps), sizeof(st));
             printf("  cut %d | pivot %llu p1 %llu p2 %llu p3 %llu\n", ref_cut, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
         }
     }
-    return 0;
+    printf("%d differences\n", bad);
+    return bad != 0;
 }
