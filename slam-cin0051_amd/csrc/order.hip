@@ -834,10 +834,11 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
 __device__ int SORT_BLOCK_MIN = 4096;  // segments at least this long are partitioned by the whole workgroup (round 5: 3072
                                         // until the wave-level partition got cheaper; 1080p_2k 0.411 -> 0.404, c2 0.652 -> 0.641 ms)
 
-// Work queue of the wave-level segments of one introsort_levels call (LDS): a bounded ring with a
-// sequence number per slot (slot s is free for ticket t when seq == t, holds ticket t when
-// seq == t + 1).  Queued segments are disjoint ranges of more than SORT_LEAF keys, so at most
-// len / 17 of them exist at any time: with SORT_QCAP >= lds_keys / 17 + 32 the ring never fills.
+// Work queue of the wave-level segments of one introsort_levels call (LDS): SORT_QCAP slots, each written once per call
+// (seg_push).  Queued segments are the children of splits into two ranges of more than SORT_LEAF keys, so at most len / 17
+// are ever queued; SORT_QCAP >= lds_keys / 17 + 32 leaves room for them and for the one ticket each of the sixteen waves
+// holds when the work runs out.  (Until late in round 5 a ring with a sequence word per slot: two more LDS round trips per
+// push and three per pop.)
 #ifndef SLAMX_SORT_QCAP
 #define SLAMX_SORT_QCAP 2048
 #endif
@@ -860,66 +861,56 @@ struct SegQueue {
     uint32_t* seq;
 };
 
-__device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ int lds_load_relaxed(int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// one lane: queue [first, last) at the given remaining depth (counted in q_pending until finished)
+// one lane: queue [first, last) at the given remaining depth (counted in q_pending until its chain is finished).
+// A push is ONE ticket and one 8-byte store: a piece never issues more than len / 17 tickets in its lifetime (every queued
+// segment is one of two children of more than SORT_LEAF keys), so the ring never wraps within a piece, a slot is written
+// once, and the entry is its own "published" mark (first >= 0; slots start as {-1, 0}).  LDS operations of one wave are
+// performed in issue order, so the keys the wave moved before the push are in place when another wave sees the entry.
 __device__ void seg_push(const SegQueue& q, SortShared& sh, int first, int last, int depth) {
+    atomicAdd(&sh.q_pending, 1);  // (before the ticket: from here on the segment counts as outstanding)
     const int ticket = atomicAdd(&sh.q_tail, 1);
-    uint32_t* sq = q.seq + (ticket & (SORT_QCAP - 1));
-    int spins = 0;
-    while (lds_load_acquire(sq) != static_cast<uint32_t>(ticket)) {  // cannot happen (see above); bounded anyway
-        if (++spins > 100000) {
-            sh.counters[2] = 1;  // reported as STATUS_SEG_OVERFLOW
-            return;
-        }
-        __builtin_amdgcn_s_sleep(1);
+    if (ticket >= SORT_QCAP) {
+        sh.counters[2] = 1;  // cannot happen (see above); reported as STATUS_SEG_OVERFLOW
+        return;
     }
-    atomicAdd(&sh.q_pending, 1);
-    q.data[ticket & (SORT_QCAP - 1)] = make_int2(first, last | (depth << 24));
-    lds_store_release(sq, static_cast<uint32_t>(ticket) + 1u);
+    wave_mem_fence();
+    const unsigned long long entry = static_cast<unsigned long long>(static_cast<uint32_t>(first)) |
+                                     (static_cast<unsigned long long>(static_cast<uint32_t>(last | (depth << 24))) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(q.data + ticket), entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// lane 0 of a wave: next queued segment, or false once every segment is finished
-// Every wait below is bounded and gives up through the overflow flag (reported as
+// lane 0 of a wave: next queued segment, or false once every segment is finished.  A pop is a ticket as well: the wave
+// waits for ITS slot, which the next push fills (segments go to waiting waves in the order they asked).  q_pending counts
+// the segments queued or in work; at zero no push can follow (a wave's pushes precede its own decrement), so a slot still
+// empty then stays empty.  Every wait is bounded and gives up through the overflow flag (reported as
 // STATUS_SEG_OVERFLOW by the caller): a protocol error must end in a loud failure, never in a hang.
 __device__ bool seg_pop(const SegQueue& q, SortShared& sh, int2* item) {
+    const int h = atomicAdd(&sh.q_head, 1);
+    if (h >= SORT_QCAP) {
+        sh.counters[2] = 1;
+        return false;
+    }
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(q.data + h);
     for (int spins = 0;; ++spins) {
-        if (lds_load_relaxed(&sh.counters[2]) != 0) {
-            return false;
+        unsigned long long e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (static_cast<int>(static_cast<uint32_t>(e)) < 0 && lds_load_relaxed(&sh.q_pending) == 0) {
+            e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a push that preceded the last decrement)
+            if (static_cast<int>(static_cast<uint32_t>(e)) < 0) {
+                return false;  // nothing queued and nobody working: no segment can appear any more
+            }
         }
-        if (spins > 4000000) {
+        if (static_cast<int>(static_cast<uint32_t>(e)) >= 0) {
+            wave_mem_fence();
+            *item = make_int2(static_cast<int>(static_cast<uint32_t>(e)), static_cast<int>(static_cast<uint32_t>(e >> 32)));
+            return true;
+        }
+        if (spins > 4000000 || lds_load_relaxed(&sh.counters[2]) != 0) {
             sh.counters[2] = 1;
             return false;
-        }
-        const int h = lds_load_relaxed(&sh.q_head);
-        const int t = lds_load_relaxed(&sh.q_tail);
-        if (h < t) {
-            if (atomicCAS(&sh.q_head, h, h + 1) == h) {
-                uint32_t* sq = q.seq + (h & (SORT_QCAP - 1));
-                int waits = 0;
-                while (lds_load_acquire(sq) != static_cast<uint32_t>(h) + 1u) {  // its producer is between ticket and publish
-                    if (++waits > 1000000 || lds_load_relaxed(&sh.counters[2]) != 0) {
-                        sh.counters[2] = 1;
-                        return false;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                *item = q.data[h & (SORT_QCAP - 1)];
-                lds_store_release(sq, static_cast<uint32_t>(h) + static_cast<uint32_t>(SORT_QCAP));
-                return true;
-            }
-            continue;
-        }
-        if (lds_load_relaxed(&sh.q_pending) == 0) {
-            return false;  // nothing queued and nobody working: no segment can appear any more
         }
         __builtin_amdgcn_s_sleep(2);
     }
@@ -960,7 +951,7 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < SORT_QCAP; i += blockDim.x) {
-        q.seq[i] = static_cast<uint32_t>(i);
+        q.data[i] = make_int2(-1, 0);  // not published
     }
     if (tid == 0) {
         sh.n_big[0] = 0;
