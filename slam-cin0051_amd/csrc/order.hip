@@ -831,8 +831,8 @@ __device__ int block_partition(uint32_t* a, PosT* scratch, int first, int last, 
     return cut;
 }
 
-__device__ int SORT_BLOCK_MIN = 4096;  // segments at least this long are partitioned by the whole workgroup (round 5: 3072
-                                        // until the wave-level partition got cheaper; 1080p_2k 0.411 -> 0.404, c2 0.652 -> 0.641 ms)
+__device__ int SORT_BLOCK_MIN = 6144;  // segments at least this long are partitioned by the whole workgroup (round 5: 3072
+                                        // until the wave-level partition got cheaper, 4096 until the queue did)
 
 // Work queue of the wave-level segments of one introsort_levels call (LDS): SORT_QCAP slots, each written once per call
 // (seg_push).  Queued segments are the children of splits into two ranges of more than SORT_LEAF keys, so at most len / 17
