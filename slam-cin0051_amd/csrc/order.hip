@@ -846,7 +846,7 @@ constexpr int SORT_QCAP = SLAMX_SORT_QCAP;
 #ifndef SLAMX_SORT_LDS_KEYS
 #define SLAMX_SORT_LDS_KEYS 28672
 #endif
-// Keys of one LDS-resident piece: 112 KB of keys + 3.5 KB of leaf flags + the 24 KB ring.  The 16-bit position lists of
+// Keys of one LDS-resident piece: 112 KB of keys + 3.5 KB of leaf flags + the 16 KB of queue slots.  The 16-bit position lists of
 // the partitions sit in the unused tail of the key region while a piece leaves room for them (len * 1.5 <= capacity:
 // 19k keys) and in the piece's range of the OUTPUT array in global memory otherwise (idle until the leaf pass; 2-3 %
 // slower than LDS at 13-14.5k keys) -- until round 3 they had 32 KB of LDS of their own and a piece was at most 16384
@@ -857,8 +857,7 @@ constexpr int PIECE_SORTED = 0x7e;     // ... of a piece the depth-limit heapsor
 static_assert(SORT_LDS_KEYS_MAX / 17 + 32 <= SORT_QCAP, "the segment ring must not be able to fill up");
 
 struct SegQueue {
-    int2* data;      // {first, last | depth << 24}
-    uint32_t* seq;
+    int2* data;  // {first, last | depth << 24}; first < 0: not written yet
 };
 
 __device__ __forceinline__ int lds_load_relaxed(int* p) {
@@ -1316,7 +1315,6 @@ __device__ __forceinline__ int block_sort_desc(uint32_t* gkeys, uint32_t* out, u
     SegQueue queue;
     queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
     queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
-    queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
     for (int i = tid; i < nwords; i += blockDim.x) {
         uint32_t wbits = 0;
         if (i == 0) {
@@ -1528,7 +1526,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_split_kernel(BatchView v, i
         SegQueue queue;
         queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
         queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
-        queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
         for (int i = tid; i < nwords; i += blockDim.x) {
             segbits[i] = 0u;
         }
@@ -1673,7 +1670,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_pieces_kernel(BatchView v, 
     SegQueue queue;
     queue.data = reinterpret_cast<int2*>(lds + lds_keys + lds_keys / 32 + 2);
     queue.data = reinterpret_cast<int2*>((reinterpret_cast<uintptr_t>(queue.data) + 7) & ~static_cast<uintptr_t>(7));
-    queue.seq = reinterpret_cast<uint32_t*>(queue.data + SORT_QCAP);
     if (tid == 0) {
         sh.counters[2] = 0;
     }
@@ -1748,8 +1744,8 @@ int lds_keys_for(int maxM) {
 }
 
 size_t sort_lds_bytes(int lds_keys) {
-    // keys + leaf-flag words + segment queue (data, sequence numbers)
-    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + 32 + static_cast<size_t>(SORT_QCAP) * 12;
+    // keys + leaf-flag words + segment queue slots
+    return (static_cast<size_t>(lds_keys) + lds_keys / 32 + 2) * 4 + 32 + static_cast<size_t>(SORT_QCAP) * 8;
 }
 void allow_big_lds(const void* fn, std::atomic<unsigned long long>& done) {
     allow_dynamic_lds(fn, sort_lds_bytes(SORT_LDS_KEYS_MAX), done);
