@@ -463,9 +463,6 @@ constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
 #ifndef SLAMX_NMS_DENSE_CANDIDATES
 #define SLAMX_NMS_DENSE_CANDIDATES 32768
 #endif
-#ifndef SLAMX_NMS_FLUSH_AT
-#define SLAMX_NMS_FLUSH_AT 44
-#endif
 // Filter waves of the greedy kernel.  Two instantiations: 1 + LOOKAHEAD waves, and -- for batches whose candidate
 // capacity is at least twice NMS_DENSE_CANDIDATES -- 1 + LOOKAHEAD_MAX waves, of which a frame uses LOOKAHEAD filter
 // waves, or all of them when it has NMS_DENSE_CANDIDATES candidates or more (the others only join the barriers:
@@ -496,6 +493,12 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
     __shared__ uint2 stage[64];  // {y << 16 | x, key} of the candidates that passed the grid test, in rank order
     __shared__ uint2 look[2][LMAX][64];  // chunks filtered ahead of wave 0 (double-buffered by group)
     __shared__ unsigned long long look_mask[2][LMAX];
+#ifdef SLAMX_NMS_CLOCKS
+    __shared__ unsigned long long nclk[16];  // development: phase stamps and per-role sums (cycles), printed by block 0
+    const unsigned long long nc_t0 = clock64();
+    unsigned long long nc_flush = 0, nc_filter = 0, nc_barrier = 0, nc_grid = 0, nc_tab = 0, nc_loop = 0;
+    int nc_nflush = 0;
+#endif
     const int f = blockIdx.x;
     const int n = v.n_cand[f];
     if (n == 0) {
@@ -542,7 +545,6 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
         // themselves in rank order and inserts the kept ones.  A candidate is kept iff no earlier kept point
         // is near, and every earlier kept point is either in the grid at that moment or in the same batch.
         int pend = 0;  // wave-uniform
-        constexpr int FLUSH_AT = SLAMX_NMS_FLUSH_AT;
         auto near_kept = [&](uint32_t xy) {  // the grid test: true when a kept point is closer than w
             const int x = static_cast<int>(xy & 0xffffu);
             const int y = static_cast<int>(xy >> 16);
@@ -586,6 +588,10 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
             if (pend == 0) {
                 return;
             }
+#ifdef SLAMX_NMS_CLOCKS
+            const unsigned long long nc_f0 = clock64();
+            nc_nflush++;
+#endif
             wave_mem_fence();
             const bool have = lane < pend;
             const uint2 e = have ? stage[lane] : make_uint2(0u, 0u);  // idle lanes: a valid cell
@@ -597,6 +603,10 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
             const int xr = x - cx * w;
             const int yr = y - cy * w;
             bool alive = have && !near_kept(e.x);  // the grid has grown since the filter ran
+#ifdef SLAMX_NMS_CLOCKS
+            const unsigned long long nc_f1 = clock64();
+            nc_grid += nc_f1 - nc_f0;
+#endif
             // The batch among itself.  Two of its members can only interact when they sit in
             // neighbouring cells, which is rare for 64 candidates on ~10^4 cells: every member
             // counts itself into a table slot hashed from its cell and sums the slots of its
@@ -626,16 +636,37 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
             }
             unsigned long long kept = __ballot(lonely);
             alive = alive && !lonely;
+#ifdef SLAMX_NMS_CLOCKS
+            const unsigned long long nc_f2 = clock64();
+            nc_tab += nc_f2 - nc_f1;
+#endif
             // the rest in rank (= lane) order
+            // Two members per step: the lowest surviving lane l0 is kept; the next one, l1, is kept as well unless l0
+            // suppresses it -- both neighbourhoods are evaluated side by side and the scalar side decides which to apply
+            // (the step's length is its chain of vector -> scalar -> vector hops, not its arithmetic: one member per step
+            // 0.171 ms per 512 default frames, two 0.156; a general form for three, four or six per step pays more for its
+            // scalar bookkeeping than it saves: 0.168 / 0.174 / 0.180).
             unsigned long long a = __ballot(alive);
             while (a != 0) {
                 const int l0 = __ffsll(static_cast<long long>(a)) - 1;
+                const unsigned long long rest = a & (a - 1);  // without l0
+                const int l1 = rest != 0 ? __ffsll(static_cast<long long>(rest)) - 1 : l0;
+                const int dx0 = x - __builtin_amdgcn_readlane(x, l0);
+                const int dy0 = y - __builtin_amdgcn_readlane(y, l0);
+                const int dx1 = x - __builtin_amdgcn_readlane(x, l1);
+                const int dy1 = y - __builtin_amdgcn_readlane(y, l1);
+                const unsigned long long near0 = __ballot(dx0 * dx0 + dy0 * dy0 < w2);  // includes lane l0 itself
+                const unsigned long long near1 = __ballot(dx1 * dx1 + dy1 * dy1 < w2);
                 kept |= 1ull << l0;
-                const int dx = x - __builtin_amdgcn_readlane(x, l0);
-                const int dy = y - __builtin_amdgcn_readlane(y, l0);
-                alive = alive && dx * dx + dy * dy >= w2;  // clears lane l0 itself too
-                a = __ballot(alive);
+                a &= ~near0;
+                if (((near0 >> l1) & 1ull) == 0) {  // l1 survives l0 (l1 == l0, nothing else left: near1 == near0)
+                    kept |= 1ull << l1;
+                    a &= ~near1;
+                }
             }
+#ifdef SLAMX_NMS_CLOCKS
+            nc_loop += clock64() - nc_f2;
+#endif
             const bool mine = (kept >> lane) & 1ull;
             if (mine) {
                 const uint32_t entry = static_cast<uint32_t>((yr << 8) | xr);
@@ -672,6 +703,35 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
             count += __popcll(kept);
             pend = 0;
             wave_mem_fence();
+#ifdef SLAMX_NMS_CLOCKS
+            nc_flush += clock64() - nc_f0;
+#endif
+        };
+        // wave 0: the survivors of one filtered chunk (mask am, na of them, lane l holds entry e) go to the batch in rank
+        // order.  A batch is resolved when it holds 64: a chunk's survivors are split between two batches where they do
+        // not fit (any grouping of the rank order into batches gives the sequential result; what a resolve pass costs,
+        // ~2,900 cycles of dependent LDS round trips, does not depend on how full the batch is -- round 5: until then a
+        // batch was resolved from 44 members on, 38 on average).
+        auto append = [&](unsigned long long am, int na, uint2 e) {
+            const bool mine = ((am >> lane) & 1ull) != 0;
+            const int r = rank_below_mask(am);
+            const int room = 64 - pend;
+            if (na > room) {
+                if (mine && r < room) {
+                    stage[pend + r] = e;
+                }
+                pend = 64;
+                flush();
+                if (mine && r >= room) {
+                    stage[r - room] = e;
+                }
+                pend = na - room;
+            } else {
+                if (mine) {
+                    stage[pend + r] = e;
+                }
+                pend += na;
+            }
         };
         // filter waves 1 .. L: chunk (wave - 1) + L * j at step j, loads two steps ahead; waves beyond L only join the barriers
         const int L = n >= NMS_DENSE_CANDIDATES ? LMAX : (LMAX < LOOKAHEAD ? LMAX : LOOKAHEAD);  // block-uniform
@@ -696,6 +756,9 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                 const uint32_t key_c = chunk_load(sorted, c + 2 * L);
                 const uint32_t xy_c = chunk_load(sorted_xy, c + 2 * L);
                 if (c < nchunks) {
+#ifdef SLAMX_NMS_CLOCKS
+                    const unsigned long long nc_n0 = clock64();
+#endif
                     const bool valid = c * 64 + lane < n;
                     const bool alive = valid && !near_kept(xy_a);
                     const unsigned long long am = __ballot(alive);
@@ -706,13 +769,22 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                     if (valid && !alive && !use_bits) {
                         state[key_a & INDEX_MASK] = NMS_SUPPRESSED;
                     }
+#ifdef SLAMX_NMS_CLOCKS
+                    nc_filter += clock64() - nc_n0;
+#endif
                 }
                 key_a = key_b;
                 key_b = key_c;
                 xy_a = xy_b;
                 xy_b = xy_c;
+#ifdef SLAMX_NMS_CLOCKS
+                const unsigned long long nc_b0 = clock64();
+#endif
                 __threadfence_block();
                 __syncthreads();
+#ifdef SLAMX_NMS_CLOCKS
+                nc_barrier += clock64() - nc_b0;
+#endif
             }
         } else if (wave == 0) {
             for (int g = -1; g < ngroups; ++g) {
@@ -736,13 +808,7 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                             if (na == 0) {
                                 continue;
                             }
-                            if (pend > FLUSH_AT || pend + na > 64) {
-                                flush();
-                            }
-                            if ((am[h] >> lane) & 1ull) {
-                                stage[pend + rank_below_mask(am[h])] = ent[h];
-                            }
-                            pend += na;
+                            append(am[h], na, ent[h]);
                         }
                     } else {
                         for (int h = 0; h < L; ++h) {
@@ -754,13 +820,7 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                             if (na == 0) {
                                 continue;
                             }
-                            if (pend > FLUSH_AT || pend + na > 64) {
-                                flush();
-                            }
-                            if ((am >> lane) & 1ull) {
-                                stage[pend + rank_below_mask(am)] = look[g & 1][h][lane];
-                            }
-                            pend += na;
+                            append(am, na, look[g & 1][h][lane]);
                         }
                     }
                 
@@ -787,6 +847,20 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SLAMX_NMS_CLOCKS
+    if (lane == 0 && wave == 0) {
+        nclk[0] = clock64() - nc_t0;
+        nclk[1] = nc_flush;
+        nclk[2] = static_cast<unsigned long long>(nc_nflush);
+        nclk[5] = nc_grid;
+        nclk[6] = nc_tab;
+        nclk[7] = nc_loop;
+    }
+    if (lane == 0 && wave == 1) {
+        nclk[3] = nc_filter;
+        nclk[4] = nc_barrier;
+    }
+#endif
     const int total_kept = kept_total;
     // raster-order visiting list for the describe kernels (see nms_finish_kernel)
     if (total_kept <= v.maxK && use_bits) {
@@ -868,6 +942,13 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
             __syncthreads();
         }
     }
+#ifdef SLAMX_NMS_CLOCKS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        printf("nms frame 0: %d candidates, %d kept: until the end of the loop %llu cycles (wave 0: %llu flushes, %llu cycles in them = grid test %llu + lonely test %llu + rank-order loop %llu + insert; wave 1: %llu cycles filtering, %llu at the group barriers), whole kernel %llu\n",
+               n, total_kept, nclk[0], nclk[2], nclk[1], nclk[5], nclk[6], nclk[7], nclk[3], nclk[4], clock64() - nc_t0);
+    }
+#endif
     if (threadIdx.x == 0) {
         int total = total_kept;
         if (total > v.maxK) {
