@@ -811,16 +811,19 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                             append(am[h], na, ent[h]);
                         }
                     } else {
-                        for (int h = 0; h < L; ++h) {
-                            if (g * L + h >= nchunks) {
-                                break;
-                            }
-                            const unsigned long long am = look_mask[g & 1][h];
-                            const int na = __popcll(am);
+                        // the group's masks in one LDS round trip, the entries only of the chunks that have survivors
+                        unsigned long long am[LMAX];
+#pragma unroll
+                        for (int h = 0; h < LMAX; ++h) {
+                            am[h] = look_mask[g & 1][h];
+                        }
+#pragma unroll
+                        for (int h = 0; h < LMAX; ++h) {
+                            const int na = h < L && g * L + h < nchunks ? __popcll(am[h]) : 0;
                             if (na == 0) {
                                 continue;
                             }
-                            append(am, na, look[g & 1][h][lane]);
+                            append(am[h], na, look[g & 1][h][lane]);
                         }
                     }
                 
