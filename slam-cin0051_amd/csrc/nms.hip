@@ -484,7 +484,7 @@ extern __shared__ uint32_t nms_grid[];
 
 template <int LMAX>
 __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v, int window, int gx2, int gy2, uint32_t magic,
-                                                                    int tab_mask, int bitmap_words) {
+                                                                    int tab_mask, int scratch_words) {
     constexpr int GREEDY_WAVES = 1 + LMAX;
     constexpr int GREEDY_THREADS = 64 * GREEDY_WAVES;
     __shared__ uint32_t wave_sums[2][GREEDY_WAVES];
@@ -519,16 +519,14 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
     for (int i = threadIdx.x; i <= tab_mask; i += GREEDY_THREADS) {
         tab[i] = 0;
     }
-    // kept candidates as a bitmap over the raster index (for the visiting list at the end); candidate
-    // sets too large for it take the route through `state` in global memory
-    uint32_t* kept_bits = tab + tab_mask + 1;
+    // The visiting list at the end needs the kept candidates as a bitmap over their raster index and the prefix of its
+    // word counts: both are built AFTER the loop in the grid's and the table's own words, which are dead by then (round 5,
+    // late: until then the bitmap had LDS of its own, was filled batch by batch, and at 80k candidates with window 8 --
+    // a 133 KB grid -- there was no room for it: those frames went through `state` in global memory, a byte store per
+    // suppressed candidate and 156 barrier-separated steps at the end, a quarter of the kernel).  Candidate sets too large
+    // even for that (tiny frames full of corners) still take the route through `state`.
     const int n_words = (n + 31) >> 5;
-    const bool use_bits = n_words <= bitmap_words;  // block-uniform
-    if (use_bits) {
-        for (int i = threadIdx.x; i < n_words; i += GREEDY_THREADS) {
-            kept_bits[i] = 0;
-        }
-    }
+    const bool use_bits = 2 * n_words <= scratch_words;  // block-uniform
     __syncthreads();
     {
         const int w = window;
@@ -692,9 +690,6 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
                     } else {
                         slot_of[idx] = static_cast<uint32_t>(pos);
                     }
-                }
-                if (use_bits) {
-                    atomicOr(&kept_bits[idx >> 5], 1u << (idx & 31u));
                 }
             }
             if (have && !use_bits) {
@@ -867,9 +862,19 @@ __global__ __launch_bounds__(64 * (1 + LMAX)) void nms_greedy_kernel(BatchView v
     const int total_kept = kept_total;
     // raster-order visiting list for the describe kernels (see nms_finish_kernel)
     if (total_kept <= v.maxK && use_bits) {
-        // rank of a kept candidate among the kept ones = kept bits before it: exclusive prefix of the word
-        // popcounts (into the survivor table, which is dead now), then one independent lookup per keypoint
-        uint32_t* word_prefix = tab;
+        // rank of a kept candidate among the kept ones = kept bits before it: the bitmap from the slot -> raster index
+        // records, the exclusive prefix of its word popcounts, then one independent lookup per keypoint
+        uint32_t* kept_bits = nms_grid;
+        uint32_t* word_prefix = nms_grid + n_words;
+        for (int i = threadIdx.x; i < n_words; i += GREEDY_THREADS) {
+            kept_bits[i] = 0;
+        }
+        __syncthreads();
+        for (int pos = threadIdx.x; pos < total_kept; pos += GREEDY_THREADS) {
+            const uint32_t idx = slot_of[pos];
+            atomicOr(&kept_bits[idx >> 5], 1u << (idx & 31u));
+        }
+        __syncthreads();
         constexpr int PER = 8;
         uint32_t run_total = 0;  // identical in all threads
         int buf = 0;
@@ -993,27 +998,19 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
             // two frames share a CU in batches of more than 256 frames
             const size_t budget =
                 (bytes + 4096 * 4 <= 80 * 1024 ? 80 * 1024 : static_cast<size_t>(GREEDY_LDS_BUDGET)) - GREEDY_STATIC_LDS;
-            // the kept-candidate bitmap (one bit per candidate, up to 65536 of them) sits behind the table; its
-            // word prefix is built in the table, which therefore has at least as many entries as the bitmap words
-            int bitmap_words = (std::min(v.maxM, 65536) + 31) / 32;
             int tab_entries = 256;
-            while (tab_entries < bitmap_words) {
+            while (tab_entries < 16384 && bytes + static_cast<size_t>(tab_entries) * 8 <= budget) {
                 tab_entries *= 2;
             }
-            if (bytes + static_cast<size_t>(tab_entries + bitmap_words) * 4 > budget) {
-                bitmap_words = 0;  // no room: the kernel goes through `state` in global memory
-                tab_entries = 256;
-            }
-            while (tab_entries < 16384 && bytes + static_cast<size_t>(bitmap_words) * 4 + static_cast<size_t>(tab_entries) * 8 <= budget) {
-                tab_entries *= 2;
-            }
-            const size_t total = bytes + static_cast<size_t>(tab_entries + bitmap_words) * 4;
+            const size_t total = bytes + static_cast<size_t>(tab_entries) * 4;
+            // (grid + table: after the loop they hold the kept-candidate bitmap and the prefix of its word counts)
+            const int scratch_words = gx2 * gy2 + tab_entries;
             if (v.maxM >= 2 * NMS_DENSE_CANDIDATES) {
                 hipLaunchKernelGGL(nms_greedy_kernel<LOOKAHEAD_MAX>, dim3(nframes), dim3(64 * (1 + LOOKAHEAD_MAX)), total, stream, v,
-                                   p.window, gx2, gy2, magic, tab_entries - 1, bitmap_words);
+                                   p.window, gx2, gy2, magic, tab_entries - 1, scratch_words);
             } else {
                 hipLaunchKernelGGL(nms_greedy_kernel<LOOKAHEAD>, dim3(nframes), dim3(64 * (1 + LOOKAHEAD)), total, stream, v, p.window,
-                                   gx2, gy2, magic, tab_entries - 1, bitmap_words);
+                                   gx2, gy2, magic, tab_entries - 1, scratch_words);
             }
             if (ev_mid != nullptr) {
                 (void)hipEventRecord(ev_mid, stream);
