@@ -1085,6 +1085,11 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
     const int by = r / regions_x;
     const int bx = r - by * regions_x;
     const int x0 = bx * RT_W, y0 = by * RT_H;
+#ifdef SLAMX_DESC_CLOCKS
+    const unsigned long long dc0 = clock64();  // development: phase stamps of a few regions of frame 0, printed at the end
+    unsigned long long dc1 = 0, dc2 = 0, dc3 = 0, dc4 = 0;
+    int dc_n = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1177,6 +1182,10 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
             }
         }
         __syncthreads();
+#ifdef SLAMX_DESC_CLOCKS
+        dc1 = clock64();
+        dc_n = nl;
+#endif
         // ---- phase A: moments, a wave takes 4 keypoints per step
         for (int g = wave; g * 4 < nl; g += 4) {  // wave-uniform
             int part[8];
@@ -1222,6 +1231,9 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
             }
         }
         __syncthreads();
+#ifdef SLAMX_DESC_CLOCKS
+        dc2 = clock64();
+#endif
         // ---- phase B: angle, cos, sin -- one keypoint per lane
         for (int k = tid; k < nl; k += 256) {
             const int m01 = l_a[k], m10 = l_b[k];
@@ -1236,6 +1248,9 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
             l_b[k] = __float_as_int(sn);
         }
         __syncthreads();
+#ifdef SLAMX_DESC_CLOCKS
+        dc3 = clock64();
+#endif
         // ---- phase C: BRIEF, a wave per keypoint, lane = pattern pair
         const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
         for (int k = wave; k < nl; k += 4) {  // wave-uniform
@@ -1276,7 +1291,16 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(BatchView v, Detecto
             }
         }
         __syncthreads();  // the lists are refilled by the next pass
+#ifdef SLAMX_DESC_CLOCKS
+        dc4 = clock64();
+#endif
     }
+#ifdef SLAMX_DESC_CLOCKS
+    if (tid == 0 && f == 0 && r % 29 == 7) {
+        printf("describe tile region %d: %d keypoints; cycles: tile + list %llu, moments %llu, trig %llu, brief %llu\n", r, dc_n,
+               dc1 - dc0, dc2 - dc1, dc3 - dc2, dc4 - dc3);
+    }
+#endif
 }
 
 }  // namespace
