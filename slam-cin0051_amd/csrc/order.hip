@@ -932,6 +932,9 @@ template <bool SPLIT>
 __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, int scr_lds_word, const SegQueue& q, int len, int depth,
                                  uint32_t* segbits, int bit_base, SortShared& sh, int stop = 0, int2* ready = nullptr,
                                  int maxSeg = 0) {
+#ifdef SLAMX_SORT_CLOCKS
+    const unsigned long long tl_entry = clock64();  // (the workgroup-wide levels run from here to tl_t0)
+#endif
     // one lane: [f, l) is finished as far as this call goes; d = remaining depth, or PIECE_SORTED
     auto emit_piece = [&](int f, int l, int d) {
         if (l <= f) {
@@ -1179,7 +1182,7 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
 #ifdef SLAMX_SORT_CLOCKS
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && len > 8000) {
         const unsigned int t_end = static_cast<unsigned int>(clock64() - sh.tl_t0);
-        printf("queue phase of %d keys: %u cycles\n", len, t_end);
+        printf("queue phase of %d keys: %u cycles (the workgroup-wide levels before it: %llu cycles)\n", len, t_end, sh.tl_t0 - tl_entry);
 #ifdef SLAMX_SORT_PASS_CLOCKS
         printf("wave partitions >= 1024 keys so far: %llu calls, %llu keys, %llu swaps; cycles pivot %llu pass1 %llu pass2 %llu pass3 %llu\n",
                wp_acc[5], wp_acc[4], wp_acc[6], wp_acc[0], wp_acc[1], wp_acc[2], wp_acc[3]);
