@@ -431,7 +431,7 @@ constexpr int NMS_PARALLEL_ROUNDS = 2;
 
 // ---------------------------------------------------------------------------------------------
 // Fast path (2 <= window <= GREEDY_MAX_WINDOW and the cell grid fits LDS): the reference's loop
-// itself, one workgroup of 1 + LOOKAHEAD_MAX waves per frame (one serial wave, 3 or 7 filter waves at work).
+// itself, one workgroup of 1 + LOOKAHEAD_MAX waves per frame (one serial wave, 4 or 7 filter waves at work).
 //
 // The kept keypoints live in a grid of window x window pixel cells in LDS.  Kept points are at
 // least `window` apart, so a cell holds at most two of them (three points pairwise >= w apart
@@ -455,7 +455,7 @@ constexpr int GREEDY_MAX_WINDOW = 24;
 constexpr int GREEDY_LDS_BUDGET = 150 * 1024;
 constexpr uint32_t CELL_EMPTY = 0x7f7f7f7fu;
 #ifndef SLAMX_NMS_LOOKAHEAD
-#define SLAMX_NMS_LOOKAHEAD 3
+#define SLAMX_NMS_LOOKAHEAD 4
 #endif
 #ifndef SLAMX_NMS_LOOKAHEAD_DENSE
 #define SLAMX_NMS_LOOKAHEAD_DENSE 7
