@@ -459,22 +459,8 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
     uint32_t* xy = v.cand_xy + static_cast<size_t>(f) * v.maxM;
     uint32_t* keys = v.keys + static_cast<size_t>(f) * v.maxM;
     uint2* q = list[wave];
-    // A tile is a chain of three dependent global loads (its corner count, its list entries, the bitmap words and prefixes
-    // the entries point at) in front of two scattered stores, and a wave takes its tiles one after another: the count and the
-    // first 64 entries of the NEXT tile are requested before this tile's words, so that one round trip per tile is left
-    // where there were three (round 5, late).
-    const int t_step = blocks_per_frame * 4;
-    int t = bx * 4 + wave;
-    uint32_t nc_next = t < v.fast_tiles ? tcount[t] : 0u;
-    uint32_t e_next = t < v.fast_tiles ? tlist[static_cast<size_t>(t) * CORNER_LIST_CAP + lane] : 0u;
-    for (; t < v.fast_tiles; t += t_step) {  // wave-uniform
-        const int nc = __builtin_amdgcn_readfirstlane(static_cast<int>(nc_next));
-        const uint32_t e_first = e_next;
-        {
-            const int tn = t + t_step;
-            nc_next = tn < v.fast_tiles ? tcount[tn] : 0u;
-            e_next = tn < v.fast_tiles ? tlist[static_cast<size_t>(tn) * CORNER_LIST_CAP + lane] : 0u;
-        }
+    for (int t = bx * 4 + wave; t < v.fast_tiles; t += blocks_per_frame * 4) {  // wave-uniform
+        const int nc = __builtin_amdgcn_readfirstlane(static_cast<int>(tcount[t]));
         if (nc == 0) {
             continue;
         }
@@ -486,7 +472,7 @@ __global__ __launch_bounds__(256) void expand_kernel(BatchView v, int nframes, i
             for (int base = 0; base < nc; base += 64) {
                 const int i = base + lane;
                 if (i < nc) {
-                    const uint32_t e = base == 0 ? e_first : tlist[static_cast<size_t>(t) * CORNER_LIST_CAP + i];
+                    const uint32_t e = tlist[static_cast<size_t>(t) * CORNER_LIST_CAP + i];
                     const int x = tx * FAST_TILE_W + static_cast<int>(e & 0xffu);
                     const int y = ty * FAST_TILE_H + static_cast<int>((e >> 8) & 0xffu);
                     const int w = y * v.nw + (x >> 6);
