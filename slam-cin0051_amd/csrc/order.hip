@@ -1124,10 +1124,14 @@ __device__ __forceinline__ void introsort_levels(uint32_t* a, uint16_t* scr16, i
 #ifdef SLAMX_SORT_CLOCKS
             const unsigned long long tw0 = clock64();
 #endif
-            const int cut = last - first <= 129   ? wave_partition_small<2>(a, sh.sel[wave], first, last, lane)
+            const int cut =
+#ifndef SLAMX_EXP_NO_SMALL_PARTITION  // (timing comparisons: every segment through wave_partition_cf)
+                            last - first <= 129   ? wave_partition_small<2>(a, sh.sel[wave], first, last, lane)
                             : last - first <= 193 ? wave_partition_small<3>(a, sh.sel[wave], first, last, lane)
                             : last - first <= 257 ? wave_partition_small<4>(a, sh.sel[wave], first, last, lane)
-                            : scr_lds_word >= 0
+                            :
+#endif
+                            scr_lds_word >= 0
                                 ? wave_partition_cf(a, reinterpret_cast<uint16_t*>(a + scr_lds_word) + first, first, last, lane)
                                 : wave_partition_cf(a, scr16 + first, first, last, lane);
 #ifdef SLAMX_SORT_CLOCKS
