@@ -20,6 +20,7 @@
 //                      re-enumeration; dependency chains can be long on straight edges), then
 //                      emits the kept keypoints in rank order (feature_detector.cpp:170, :187).
 #include "slamx_internal.h"
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -1004,7 +1005,10 @@ void launch_nms(const BatchView& v, const DetectorParams& p, int nframes, hipStr
             }
             const size_t total = bytes + static_cast<size_t>(tab_entries) * 4;
             // (grid + table: after the loop they hold the kept-candidate bitmap and the prefix of its word counts)
-            const int scratch_words = gx2 * gy2 + tab_entries;
+            // SLAMX_NMS_STATE_ROUTE=1 (tests): no room for the bitmap -- every frame takes the route through `state`, which
+            // since round 5 only candidate sets too large for grid + table take by themselves
+            const char* force_state = getenv("SLAMX_NMS_STATE_ROUTE");
+            const int scratch_words = force_state != nullptr && force_state[0] == '1' ? 0 : gx2 * gy2 + tab_entries;
             if (v.maxM >= 2 * NMS_DENSE_CANDIDATES) {
                 hipLaunchKernelGGL(nms_greedy_kernel<LOOKAHEAD_MAX>, dim3(nframes), dim3(64 * (1 + LOOKAHEAD_MAX)), total, stream, v,
                                    p.window, gx2, gy2, magic, tab_entries - 1, scratch_words);

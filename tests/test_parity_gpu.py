@@ -805,6 +805,24 @@ def test_block_ids_spill_into_grid_z():
     assert p.returncode == 0 and " passed" in out, out[-2000:]
 
 
+def test_nms_state_route_still_gives_the_oracle_s_keypoints():
+    """The greedy NMS builds its kept-candidate bitmap after the loop in the grid's own LDS words; only candidate sets too
+    large for grid + table go through the `state` array in global memory (until round 5 every frame of 65536+ candidates
+    did).  In a child process SLAMX_NMS_STATE_ROUTE=1 sends every frame that way: the detector tests, dense and tied
+    frames and the batch path must still give the oracle's keypoints in the oracle's order."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SLAMX_NMS_STATE_ROUTE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_parity_gpu.py"), "-k",
+                        "detect_windows_synthetic or detect_dense_candidates or filter_wave_count or batch_equals_single_frame or "
+                        "frontend_against_committed_golden_vectors"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and " passed" in out, out[-2000:]
+
+
 def test_region_tile_describe_on_every_shape():
     """describe_tile_kernel (orientation + BRIEF from shared 240 x 64-pixel region tiles) is what dense frames take; in a
     child process SLAMX_DESCRIBE_TILES=2 sends EVERY frame through it, so that the odd image shapes (narrower than a
